@@ -1,0 +1,245 @@
+/*
+ * q3tts.h — C ABI of the MI355X-native Qwen3-TTS hot path (libq3tts.so, gfx950).
+ *
+ * This is the drop-in boundary for the reference's generation/session API: each entry point
+ * names the reference interface (file:line, relative to the TrevorS/qwen3-tts-rs repo root) it
+ * replaces. A Rust shim (`extern "C"` block) re-exposes the reference's
+ * `Qwen3TTS` / `SynthesisOptions` / `StreamingSession` names on top of these symbols; the Python
+ * mirror in qwen3_tts_rs_amd/api.py does the same over ctypes.
+ *
+ * Conventions: plain pointers and sizes only; every function returns q3_status (0 = OK) and
+ * never throws/aborts across the ABI; `q3_last_error()` returns the thread-local message
+ * (the reference's anyhow::Error text). All `*_host` pointers are host memory; device memory is
+ * owned by the library (model arena, per-session KV pages) except where a function says
+ * "device pointer". One process drives one GPU; the model handle is immutable after
+ * q3_model_finalize and may be shared by any number of sessions on that GPU.
+ */
+#ifndef Q3TTS_H
+#define Q3TTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q3_ABI_VERSION 1
+
+typedef enum q3_status {
+    Q3_OK = 0,
+    Q3_INVALID_ARG = 1,
+    Q3_IO = 2,
+    Q3_MISSING_WEIGHT = 3,   /* lib.rs:226-231, decoder_12hz.rs:176-181 ("Missing weight: ...") */
+    Q3_KV_OVERFLOW = 4,      /* kv_cache.rs:293-300 */
+    Q3_HIP_ERROR = 5,
+    Q3_RCCL_ERROR = 6,
+    Q3_UNSUPPORTED = 7,
+    Q3_OOM = 8
+} q3_status;
+
+/* Shape constants parsed from config.json by the reference (config.rs:238-336 →
+ * talker.rs:176-290 TalkerConfig, code_predictor.rs:48-113, decoder_12hz.rs:14-67). */
+typedef struct q3_config {
+    int32_t text_vocab;   /* 151936 */
+    int32_t text_dim;     /* 2048 */
+    int32_t hidden;       /* 2048 (1.7B) / 1024 (0.6B) */
+    int32_t inter;        /* 6144 / 3072 */
+    int32_t n_layers;     /* 28 */
+    int32_t n_heads;      /* 16 */
+    int32_t n_kv_heads;   /* 8 */
+    int32_t head_dim;     /* 128 (only value supported by the gfx950 kernels) */
+    int32_t codec_vocab;  /* 3072 */
+    int32_t cp_hidden;    /* 1024 */
+    int32_t cp_inter;     /* 3072 */
+    int32_t cp_layers;    /* 5 */
+    int32_t cp_heads;     /* 16 */
+    int32_t cp_kv_heads;  /* 8 */
+    int32_t cp_vocab;     /* 2048 */
+    int32_t n_groups;     /* 16 */
+    float   rms_eps;      /* 1e-6 */
+    float   rope_theta;   /* 1e6 */
+    int32_t dec_cb_dim;   /* 256 */
+    int32_t dec_q_dim;    /* 512 */
+    int32_t dec_latent;   /* 1024 */
+    int32_t dec_hidden;   /* 512 */
+    int32_t dec_layers;   /* 8 */
+    int32_t dec_heads;    /* 16 */
+    int32_t dec_head_dim; /* 64 */
+    int32_t dec_inter;    /* 1024 */
+    int32_t dec_cb_size;  /* 2048 */
+    int32_t dec_dim;      /* 1536 */
+    int32_t dec_up_ratios[2]; /* 2,2 */
+    int32_t dec_up_rates[4];  /* 8,5,4,3 */
+    float   dec_eps;      /* 1e-5 */
+    float   dec_theta;    /* 1e4 */
+} q3_config;
+
+/* SynthesisOptions (lib.rs:1786-1836); f64 fields are f64 in the reference too. */
+typedef struct q3_options {
+    double   temperature;        /* 0.9 */
+    double   top_p;              /* 0.9 */
+    double   repetition_penalty; /* 1.05 */
+    uint64_t seed;               /* used when has_seed != 0 */
+    int32_t  max_length;         /* 2048  (max_new_tokens) */
+    int32_t  top_k;              /* 50 */
+    int32_t  eos_token_id;       /* 2150 (CODEC_EOS_TOKEN_ID, lib.rs:1466); -1 = None */
+    int32_t  chunk_frames;       /* 10 */
+    int32_t  min_new_tokens;     /* 2 */
+    int32_t  has_seed;           /* 0 = None: seeded from the wall clock (sampling.rs:66-82) */
+} q3_options;
+
+enum { Q3_MODE_CUSTOM_VOICE = 0, Q3_MODE_VOICE_CLONE = 1, Q3_MODE_VOICE_DESIGN = 2 };
+enum { Q3_DTYPE_F32 = 0, Q3_DTYPE_BF16 = 1 };
+
+/* One utterance. Replaces the argument lists of synthesize_with_voice (lib.rs:718-724),
+ * synthesize_voice_design (lib.rs:802-808) and the x-vector-only branch of
+ * synthesize_voice_clone (lib.rs:897-951); token ids come from the caller's tokenizer
+ * (text.rs:210-217 stays on the Rust side). */
+typedef struct q3_request {
+    int32_t mode;
+    const uint32_t* text_ids;     int32_t n_text;
+    const uint32_t* instruct_ids; int32_t n_instruct;  /* voice design: ChatML-framed instruct */
+    uint32_t speaker_id;          /* Speaker::token_id (talker.rs:145-157) */
+    uint32_t language_id;         /* Language::token_id (talker.rs:94-107) */
+    const float* xvector;         /* [hidden] speaker embedding (voice clone) or NULL */
+    q3_options opts;
+} q3_request;
+
+/* SynthesisTiming (lib.rs:138-147) */
+typedef struct q3_timing {
+    double prefill_ms, generation_ms, decode_ms;
+    int32_t generation_frames;
+} q3_timing;
+
+typedef struct q3_model q3_model;
+typedef struct q3_session q3_session;
+
+int         q3_abi_version(void);
+const char* q3_last_error(void);
+/* number of visible HIP devices, or -1 (replaces auto_device / parse_device, lib.rs:1854-1926) */
+int         q3_device_count(void);
+
+/* ---------------- model (Qwen3TTS::from_weights, lib.rs:267-368) ---------------- */
+/* device = HIP device index; device = -1 creates a manifest-only handle (tensor names/shapes, no GPU) */
+q3_status q3_model_create(const q3_config* cfg, int device, q3_model** out);
+void      q3_model_free(q3_model* m);
+/* Upload one checkpoint tensor under its safetensors name. `dtype` is the
+ * SOURCE dtype; talker/code-predictor matrices are stored bf16 in HBM (the checkpoint's native
+ * dtype, lib.rs:1394-1396), norms/biases and all decoder tensors f32 (lib.rs:344-353). */
+q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtype, const void* data_host, int64_t n);
+/* Names the model expects: i in [0, q3_model_n_tensors); returns name, element count, stored dtype */
+int       q3_model_n_tensors(const q3_model* m);
+q3_status q3_model_tensor_info(const q3_model* m, int i, const char** name, int64_t* n, int* stored_dtype);
+/* Weight arena for the one data-parallel collective (RCCL broadcast from rank 0): device pointer
+ * + size; after the broadcast non-root ranks call q3_model_mark_loaded then q3_model_finalize. */
+q3_status q3_model_arena(q3_model* m, void** dev_ptr, size_t* bytes);
+q3_status q3_model_mark_loaded(q3_model* m);
+/* Verify every tensor is present ("Missing weight: <name>"), derive codebooks
+ * (decoder_12hz.rs:189-225) and RoPE tables. */
+q3_status q3_model_finalize(q3_model* m);
+/* Deterministic synthetic tensor generator (SURVEY.md Appendix B rules; host side, no GPU):
+ * value_i = offset + scale * z_i, z ~ approx N(0,1) from a counter hash of (seed, name, i);
+ * dtype BF16 writes uint16 (round-to-nearest-even), F32 writes float. */
+q3_status q3_synth_fill(uint64_t seed, const char* name, int dtype, float scale, float offset,
+                        int64_t n, void* out_host);
+
+/* ---------------- session = one batch of utterances on one GPU ----------------
+ * Owns KV pages, RNG streams, penalty masks (the fields of StreamingSession, lib.rs:1484-1508).
+ * batch > 1 has no reference counterpart (reference batch = 1): every sequence behaves exactly
+ * as its own batch-1 run. */
+q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out);
+void      q3_session_free(q3_session* s);
+/* prefill_custom_voice / _voice_clone / _voice_design + run_prefill_layers (talker.rs:451-627,
+ * 823-841), build_trailing_text (lib.rs:508-519) and the first sampling decision
+ * (lib.rs:558-571). */
+q3_status q3_session_prefill(q3_session* s);
+/* generate_codes frame loop (lib.rs:580-652): run up to n_frames more frames for every live
+ * sequence; returns when they are done on the device. use_graph != 0 replays a captured
+ * hipGraph per frame. */
+q3_status q3_session_generate(q3_session* s, int n_frames, int use_graph);
+/* frames emitted so far for sequence b (stops at the frame whose semantic token is EOS,
+ * lib.rs:581-585) and whether it hit EOS / max_length */
+q3_status q3_session_frames(q3_session* s, int b, int* n_frames, int* done);
+/* gpu_frames_to_frame_codes (lib.rs:676-690): [n][16] u32, frame-major */
+q3_status q3_session_codes(q3_session* s, int b, uint32_t* codes_host, int cap_frames, int* n_frames);
+/* decode_codes over frames [f0, f1) of sequence b (lib.rs:881-890; streaming decodes each chunk
+ * context-free, lib.rs:1755-1758): writes (f1-f0)*1920 f32 samples */
+q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, float* pcm_host, size_t cap, size_t* n_samples);
+/* synthesize_with_timing (lib.rs:425-501) for the whole batch: prefill → generate → decode.
+ * pcm_host[b] receives up to cap[b] samples (NULL = skip copy-out); n_samples[b] is set. */
+q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_host, const size_t* cap, size_t* n_samples,
+                         q3_timing* timing);
+/* StreamingSession::next_chunk (lib.rs:1650-1759) for sequence 0 of a batch-1 session: generates
+ * up to chunk_frames frames, decodes them as an independent utterance; *done=1 with
+ * *n_samples=0 when finished. */
+q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_t cap, size_t* n_samples, int* done);
+
+/* ---------------- stage-level entry points (parity tests; the reference's
+ * tests/reference_validation.rs stages) ---------------- */
+enum {
+    Q3_GET_PREFILL_EMBEDS = 0,  /* [prefill_len][hidden] f32 */
+    Q3_GET_LAST_HIDDEN = 1,     /* [hidden] normed last hidden (talker.rs:729-735) */
+    Q3_GET_LOGITS = 2,          /* [codec_vocab] raw logits of the latest talker step */
+    Q3_GET_TRAILING = 3,        /* [T_tr][hidden] */
+    Q3_GET_PAD_EMBED = 4,       /* [hidden] */
+    Q3_GET_LOGITS_HIST = 5,     /* [frames+1][codec_vocab] (session created with debug capture) */
+    Q3_GET_CP_LOGITS = 6,       /* [15][cp_vocab] of the latest code-predictor run */
+    Q3_GET_TOKEN = 7,           /* u32 current semantic token */
+    Q3_GET_CP_LOGITS_HIST = 8   /* [frames][15][cp_vocab] (debug capture) */
+};
+q3_status q3_session_set_debug(q3_session* s, int capture_logits);
+q3_status q3_session_prefill_len(q3_session* s, int b, int* prefill_len, int* trailing_len);
+q3_status q3_session_get(q3_session* s, int what, int b, void* out_host, size_t bytes);
+/* generate_step_with_embed (talker.rs:716-736), teacher-forced: embeds_host [batch][hidden] */
+q3_status q3_talker_step(q3_session* s, const float* embeds_host, float* hidden_host, float* logits_host);
+/* generate_acoustic_codes (code_predictor.rs:320-416), teacher-forced: inputs [batch][hidden] */
+q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host, const float* sem_embed_host,
+                         uint32_t* codes15_host, float* cp_logits_host /*[batch][15][cp_vocab] or NULL*/);
+/* lib.rs:612-622 frame glue: sem + ((e0+e1)+..+e14) + text_add → [hidden] */
+q3_status q3_frame_embed(q3_model* m, uint32_t sem_token, const uint32_t* codes15, const float* text_add_host,
+                         float* out_host);
+/* apply_generation_penalties_gpu + sample (lib.rs:1271-1322; sampling.rs:140-319) on device for
+ * `rows` independent rows: logits_host [rows][vocab], seen_host [rows][vocab] u8 (may be NULL),
+ * u_host [rows] uniform draws (SamplingContext::rand_f32) → tokens_host [rows] */
+q3_status q3_sample(int device, const float* logits_host, const uint8_t* seen_host, const float* u_host,
+                    int rows, int vocab, const q3_options* opts, int token_count, uint32_t* tokens_host);
+/* PCG-XSH-RR stream of SamplingContext (sampling.rs:32-51, 84-94); host side */
+void      q3_rng_seed(uint64_t seed, uint64_t* state);
+float     q3_rng_next(uint64_t* state);
+/* FusedRmsNorm::forward_residual (fused_ops.rs:49-96; kernels/fused_residual_rmsnorm.cu:39-90):
+ * returns (rms_norm(x+res)*w, x+res); dtype F32 or BF16 (storage), f32 math */
+q3_status q3_fused_residual_rmsnorm(int device, int dtype, const void* x_host, const void* res_host,
+                                    const void* w_host, int rows, int cols, float eps,
+                                    void* normed_host, void* sum_host);
+/* y = x·Wᵀ (+b) with bf16 weights / f32 activations — the GEMV family used by every projection
+ * (candle Linear, transformer.rs:224-227): x [M][K] f32, w [N][K] bf16 */
+q3_status q3_linear(int device, const float* x_host, const uint16_t* w_bf16_host, const float* bias_host,
+                    int M, int N, int K, float* y_host);
+/* Qwen3TTS::decode_codes (lib.rs:881-890) / Decoder12Hz::decode (decoder_12hz.rs:411-505):
+ * frames [n][16] u32 → n*1920 f32 samples. taps (optional, [Q3_DEC_N] host pointers or NULL)
+ * receive stage outputs for the stage-by-stage validation the reference does in
+ * tests/reference_validation.rs:1755-2400. */
+enum { Q3_DEC_QUANT = 0, Q3_DEC_PRECONV = 1, Q3_DEC_PRETRANS = 2, Q3_DEC_UP0 = 3, Q3_DEC_UP1 = 4,
+       Q3_DEC_INIT = 5, Q3_DEC_BLK0 = 6, Q3_DEC_BLK1 = 7, Q3_DEC_BLK2 = 8, Q3_DEC_BLK3 = 9, Q3_DEC_N = 10 };
+q3_status q3_decode_codes(q3_model* m, const uint32_t* frames_host, int n_frames, float* pcm_host,
+                          float** taps_host);
+/* codes_to_tensor (lib.rs:1417-1431): [n][16] u32 → [16][n] i64 (host helper) */
+void      q3_codes_to_tensor(const uint32_t* frames, int n_frames, int64_t* out);
+
+/* ---------------- measurement hooks (bench.py) ---------------- */
+/* per-kernel-class accumulated GPU time since the last reset, measured with hipEvents on the
+ * session stream when profiling is enabled (q3_session_set_profile) */
+q3_status q3_session_set_profile(q3_session* s, int enable);
+/* accumulated since the last reset: GPU milliseconds, algorithmic weight bytes and launch count of
+ * the bf16 GEMV family (the dominant kernel) */
+q3_status q3_session_profile_read(q3_session* s, double* ms, double* bytes, long* launches, int reset);
+/* raw stream handle (hipStream_t) the session launches on */
+q3_status q3_session_stream(q3_session* s, void** stream);
+/* Algorithmic HBM bytes of one frame for this session's batch at KV length L */
+q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q3TTS_H */

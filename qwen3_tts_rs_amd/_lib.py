@@ -1,0 +1,103 @@
+"""ctypes binding of libq3tts.so (include/q3tts.h). The product has NO CPU fallback: if the HIP
+library is missing this module raises, and every compute entry point fails loudly without a GPU."""
+import ctypes
+import os
+
+from .config import CConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libq3tts.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the gfx950 HIP library is not built. Run "
+        "`python -c 'import __graft_entry__ as g; g.build()'` (or qwen3_tts_rs_amd/csrc/build.sh).")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+
+class COptions(ctypes.Structure):
+    _fields_ = [
+        ("temperature", ctypes.c_double), ("top_p", ctypes.c_double), ("repetition_penalty", ctypes.c_double),
+        ("seed", ctypes.c_uint64), ("max_length", ctypes.c_int32), ("top_k", ctypes.c_int32),
+        ("eos_token_id", ctypes.c_int32), ("chunk_frames", ctypes.c_int32), ("min_new_tokens", ctypes.c_int32),
+        ("has_seed", ctypes.c_int32),
+    ]
+
+
+class CRequest(ctypes.Structure):
+    _fields_ = [
+        ("mode", ctypes.c_int32),
+        ("text_ids", ctypes.POINTER(ctypes.c_uint32)), ("n_text", ctypes.c_int32),
+        ("instruct_ids", ctypes.POINTER(ctypes.c_uint32)), ("n_instruct", ctypes.c_int32),
+        ("speaker_id", ctypes.c_uint32), ("language_id", ctypes.c_uint32),
+        ("xvector", ctypes.POINTER(ctypes.c_float)),
+        ("opts", COptions),
+    ]
+
+
+class CTiming(ctypes.Structure):
+    _fields_ = [("prefill_ms", ctypes.c_double), ("generation_ms", ctypes.c_double), ("decode_ms", ctypes.c_double),
+                ("generation_frames", ctypes.c_int32)]
+
+
+c_void_p, c_int, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p
+P = ctypes.POINTER
+
+# every symbol include/q3tts.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "q3_abi_version": (c_int, []),
+    "q3_last_error": (c_char_p, []),
+    "q3_device_count": (c_int, []),
+    "q3_model_create": (c_int, [P(CConfig), c_int, P(c_void_p)]),
+    "q3_model_free": (None, [c_void_p]),
+    "q3_model_set_tensor": (c_int, [c_void_p, c_char_p, c_int, c_void_p, ctypes.c_int64]),
+    "q3_model_n_tensors": (c_int, [c_void_p]),
+    "q3_model_tensor_info": (c_int, [c_void_p, c_int, P(c_char_p), P(ctypes.c_int64), P(c_int)]),
+    "q3_model_arena": (c_int, [c_void_p, P(c_void_p), P(ctypes.c_size_t)]),
+    "q3_model_mark_loaded": (c_int, [c_void_p]),
+    "q3_model_finalize": (c_int, [c_void_p]),
+    "q3_synth_fill": (c_int, [ctypes.c_uint64, c_char_p, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int64, c_void_p]),
+    "q3_session_create": (c_int, [c_void_p, P(CRequest), c_int, P(c_void_p)]),
+    "q3_session_free": (None, [c_void_p]),
+    "q3_session_prefill": (c_int, [c_void_p]),
+    "q3_session_generate": (c_int, [c_void_p, c_int, c_int]),
+    "q3_session_frames": (c_int, [c_void_p, c_int, P(c_int), P(c_int)]),
+    "q3_session_codes": (c_int, [c_void_p, c_int, c_void_p, c_int, P(c_int)]),
+    "q3_session_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_size_t, P(ctypes.c_size_t)]),
+    "q3_session_run": (c_int, [c_void_p, c_int, P(c_void_p), P(ctypes.c_size_t), P(ctypes.c_size_t), P(CTiming)]),
+    "q3_session_next_chunk": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, P(ctypes.c_size_t), P(c_int)]),
+    "q3_session_set_debug": (c_int, [c_void_p, c_int]),
+    "q3_session_prefill_len": (c_int, [c_void_p, c_int, P(c_int), P(c_int)]),
+    "q3_session_get": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_size_t]),
+    "q3_talker_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "q3_cp_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "q3_frame_embed": (c_int, [c_void_p, ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
+    "q3_sample": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, P(COptions), c_int, c_void_p]),
+    "q3_rng_seed": (None, [ctypes.c_uint64, P(ctypes.c_uint64)]),
+    "q3_rng_next": (ctypes.c_float, [P(ctypes.c_uint64)]),
+    "q3_fused_residual_rmsnorm": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_float, c_void_p, c_void_p]),
+    "q3_linear": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "q3_decode_codes": (c_int, [c_void_p, c_void_p, c_int, c_void_p, P(c_void_p)]),
+    "q3_codes_to_tensor": (None, [c_void_p, c_int, c_void_p]),
+    "q3_session_set_profile": (c_int, [c_void_p, c_int]),
+    "q3_session_profile_read": (c_int, [c_void_p, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_long), c_int]),
+    "q3_session_stream": (c_int, [c_void_p, P(c_void_p)]),
+    "q3_session_frame_bytes": (c_int, [c_void_p, c_int, P(ctypes.c_double), P(ctypes.c_double)]),
+}
+
+for _name, (_res, _args) in SYMBOLS.items():
+    _f = getattr(lib, _name)      # AttributeError here = header/library mismatch
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class Q3Error(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"q3 status {status}: {msg}")
+        self.status = status
+
+
+def check(status):
+    if status != 0:
+        raise Q3Error(status, lib.q3_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,470 @@
+"""Python mirror of the reference's public API over the C ABI (include/q3tts.h).
+
+Names, argument meaning and error behaviour follow the reference crate's re-exports
+(src/lib.rs:107-117): `Qwen3TTS`, `SynthesisOptions`, `SynthesisTiming`, `StreamingSession`,
+`AudioBuffer`, `Speaker`, `Language`, `CODEC_EOS_TOKEN_ID`, `SAMPLES_PER_FRAME`. Differences:
+text arrives as token ids (the tokenizer, src/tokenizer/text.rs, is outside the hot path) and the
+synthesis calls accept a LIST of utterances, which run as one batch on the GPU (the reference is
+batch 1; each sequence behaves exactly like its own batch-1 run).
+"""
+import ctypes
+import enum
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, COptions, CRequest, CTiming
+from .config import Q3Config
+from . import synth
+
+CODEC_EOS_TOKEN_ID = 2150      # lib.rs:1466
+SAMPLES_PER_FRAME = 1920       # lib.rs:1469
+
+
+class Language(enum.Enum):     # talker.rs:59-108
+    Chinese = 2055
+    English = 2050
+    Japanese = 2058
+    Korean = 2064
+    German = 2053
+    French = 2061
+    Russian = 2069
+    Portuguese = 2071
+    Spanish = 2054
+    Italian = 2070
+
+    def token_id(self) -> int:
+        return self.value
+
+    @staticmethod
+    def from_str(s: str) -> "Language":
+        table = {"english": "English", "en": "English", "chinese": "Chinese", "zh": "Chinese", "japanese": "Japanese",
+                 "ja": "Japanese", "korean": "Korean", "ko": "Korean", "german": "German", "de": "German",
+                 "french": "French", "fr": "French", "russian": "Russian", "ru": "Russian", "portuguese": "Portuguese",
+                 "pt": "Portuguese", "spanish": "Spanish", "es": "Spanish", "italian": "Italian", "it": "Italian"}
+        k = s.lower()
+        if k not in table:
+            raise ValueError(f"Unknown language: {s}")
+        return Language[table[k]]
+
+
+class Speaker(enum.Enum):      # talker.rs:111-157
+    Serena = 3066
+    Vivian = 3065
+    UncleFu = 3010
+    Ryan = 3061
+    Aiden = 2861
+    OnoAnna = 2873
+    Sohee = 2864
+    Eric = 2875
+    Dylan = 2878
+
+    def token_id(self) -> int:
+        return self.value
+
+    def native_language(self) -> Language:
+        if self in (Speaker.Ryan, Speaker.Aiden):
+            return Language.English
+        if self is Speaker.OnoAnna:
+            return Language.Japanese
+        if self is Speaker.Sohee:
+            return Language.Korean
+        return Language.Chinese
+
+    @staticmethod
+    def from_str(s: str) -> "Speaker":
+        table = {"ryan": "Ryan", "serena": "Serena", "vivian": "Vivian", "aiden": "Aiden", "uncle_fu": "UncleFu",
+                 "unclefu": "UncleFu", "ono_anna": "OnoAnna", "onoanna": "OnoAnna", "sohee": "Sohee", "eric": "Eric",
+                 "dylan": "Dylan"}
+        k = s.lower()
+        if k not in table:
+            raise ValueError(f"Unknown speaker: {s}")
+        return Speaker[table[k]]
+
+
+@dataclass
+class SynthesisOptions:        # lib.rs:1786-1836
+    max_length: int = 2048
+    temperature: float = 0.9
+    top_k: int = 50
+    top_p: float = 0.9
+    repetition_penalty: float = 1.05
+    eos_token_id: Optional[int] = CODEC_EOS_TOKEN_ID
+    chunk_frames: int = 10
+    min_new_tokens: int = 2
+    seed: Optional[int] = None
+
+    def to_c(self) -> COptions:
+        o = COptions()
+        o.temperature = float(self.temperature); o.top_p = float(self.top_p)
+        o.repetition_penalty = float(self.repetition_penalty)
+        o.seed = 0 if self.seed is None else int(self.seed)
+        o.max_length = int(self.max_length); o.top_k = int(self.top_k)
+        o.eos_token_id = -1 if self.eos_token_id is None else int(self.eos_token_id)
+        o.chunk_frames = int(self.chunk_frames); o.min_new_tokens = int(self.min_new_tokens)
+        o.has_seed = 0 if self.seed is None else 1
+        return o
+
+
+@dataclass
+class SynthesisTiming:         # lib.rs:138-147
+    prefill_ms: float
+    generation_ms: float
+    generation_frames: int
+    decode_ms: float
+
+
+@dataclass
+class AudioBuffer:             # audio/io.rs:28-34
+    samples: np.ndarray
+    sample_rate: int = 24000
+
+    def __len__(self) -> int:
+        return int(self.samples.shape[0])
+
+    def duration(self) -> float:
+        return len(self) / float(self.sample_rate)
+
+
+@dataclass
+class Utterance:
+    """One request: token ids + conditioning (the argument lists of lib.rs:718-724 / 802-808)."""
+    text_ids: Sequence[int]
+    speaker: Speaker = Speaker.Ryan
+    language: Language = Language.English
+    instruct_ids: Optional[Sequence[int]] = None     # voice design
+    xvector: Optional[np.ndarray] = None             # voice clone (x-vector only)
+    seed: Optional[int] = None                       # overrides options.seed for this sequence
+
+    def mode(self) -> int:
+        if self.instruct_ids is not None:
+            return 2
+        if self.xvector is not None:
+            return 1
+        return 0
+
+
+class Session:
+    """A batch of utterances on one GPU (q3_session). Owns KV pages, RNG streams, penalty masks."""
+
+    def __init__(self, model: "Qwen3TTS", utts: Sequence[Utterance], options: SynthesisOptions, debug: bool = False):
+        self.model = model
+        self.B = len(utts)
+        self.options = options
+        self._keep = []
+        reqs = (CRequest * self.B)()
+        for i, u in enumerate(utts):
+            r = reqs[i]
+            r.mode = u.mode()
+            t = np.ascontiguousarray(u.text_ids, dtype=np.uint32); self._keep.append(t)
+            r.text_ids = t.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_text = len(t)
+            if u.instruct_ids is not None:
+                ins = np.ascontiguousarray(u.instruct_ids, dtype=np.uint32); self._keep.append(ins)
+                r.instruct_ids = ins.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_instruct = len(ins)
+            r.speaker_id = u.speaker.token_id(); r.language_id = u.language.token_id()
+            if u.xvector is not None:
+                xv = np.ascontiguousarray(u.xvector, dtype=np.float32); self._keep.append(xv)
+                r.xvector = xv.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            o = options.to_c()
+            if u.seed is not None:
+                o.seed = int(u.seed); o.has_seed = 1
+            r.opts = o
+        h = ctypes.c_void_p()
+        check(lib.q3_session_create(model._h, reqs, self.B, ctypes.byref(h)))
+        self._h = h
+        if debug:
+            check(lib.q3_session_set_debug(self._h, 1))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.q3_session_free(self._h); self._h = None
+
+    __del__ = close
+
+    def prefill(self):
+        check(lib.q3_session_prefill(self._h))
+
+    def generate(self, n_frames: int, use_graph: bool = True):
+        check(lib.q3_session_generate(self._h, int(n_frames), 1 if use_graph else 0))
+
+    def frames(self, b: int = 0) -> Tuple[int, bool]:
+        n = ctypes.c_int(); d = ctypes.c_int()
+        check(lib.q3_session_frames(self._h, b, ctypes.byref(n), ctypes.byref(d)))
+        return n.value, bool(d.value)
+
+    def codes(self, b: int = 0) -> np.ndarray:
+        n, _ = self.frames(b)
+        out = np.zeros((max(n, 1), 16), dtype=np.uint32)
+        got = ctypes.c_int()
+        check(lib.q3_session_codes(self._h, b, out.ctypes.data_as(ctypes.c_void_p), out.shape[0], ctypes.byref(got)))
+        return out[:got.value]
+
+    def decode(self, b: int = 0, f0: int = 0, f1: Optional[int] = None) -> np.ndarray:
+        n, _ = self.frames(b)
+        f1 = n if f1 is None else f1
+        spf = self.model.config.samples_per_frame
+        out = np.zeros(max((f1 - f0) * spf, 1), dtype=np.float32)
+        got = ctypes.c_size_t()
+        check(lib.q3_session_decode(self._h, b, f0, f1, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(got)))
+        return out[:got.value]
+
+    def run(self, use_graph: bool = True) -> Tuple[List[AudioBuffer], SynthesisTiming]:
+        """synthesize_with_timing (lib.rs:425-501) for the batch."""
+        spf = self.model.config.samples_per_frame
+        cap = self.options.max_length * spf
+        bufs = [np.zeros(cap, dtype=np.float32) for _ in range(self.B)]
+        ptrs = (ctypes.c_void_p * self.B)(*[b.ctypes.data_as(ctypes.c_void_p) for b in bufs])
+        caps = (ctypes.c_size_t * self.B)(*([cap] * self.B))
+        ns = (ctypes.c_size_t * self.B)()
+        t = CTiming()
+        check(lib.q3_session_run(self._h, 1 if use_graph else 0, ptrs, caps, ns, ctypes.byref(t)))
+        audio = [AudioBuffer(bufs[i][:ns[i]].copy()) for i in range(self.B)]
+        return audio, SynthesisTiming(t.prefill_ms, t.generation_ms, t.generation_frames, t.decode_ms)
+
+    def run_timing_only(self, use_graph: bool = True) -> SynthesisTiming:
+        ns = (ctypes.c_size_t * self.B)()
+        t = CTiming()
+        check(lib.q3_session_run(self._h, 1 if use_graph else 0, None, None, ns, ctypes.byref(t)))
+        return SynthesisTiming(t.prefill_ms, t.generation_ms, t.generation_frames, t.decode_ms)
+
+    # ---- stage taps (parity tests) ----
+    def prefill_len(self, b: int = 0) -> Tuple[int, int]:
+        p = ctypes.c_int(); t = ctypes.c_int()
+        check(lib.q3_session_prefill_len(self._h, b, ctypes.byref(p), ctypes.byref(t)))
+        return p.value, t.value
+
+    def get(self, what: int, shape, b: int = 0, dtype=np.float32) -> np.ndarray:
+        out = np.zeros(shape, dtype=dtype)
+        check(lib.q3_session_get(self._h, what, b, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        return out
+
+    def talker_step(self, embeds: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        cfg = self.model.config
+        e = np.ascontiguousarray(embeds, dtype=np.float32).reshape(self.B, cfg.hidden)
+        hid = np.zeros((self.B, cfg.hidden), dtype=np.float32); lg = np.zeros((self.B, cfg.codec_vocab), dtype=np.float32)
+        check(lib.q3_talker_step(self._h, e.ctypes.data_as(ctypes.c_void_p), hid.ctypes.data_as(ctypes.c_void_p),
+                                 lg.ctypes.data_as(ctypes.c_void_p)))
+        return hid, lg
+
+    def cp_generate(self, last_hidden: np.ndarray, sem_embed: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        cfg = self.model.config
+        lh = np.ascontiguousarray(last_hidden, dtype=np.float32).reshape(self.B, cfg.hidden)
+        se = np.ascontiguousarray(sem_embed, dtype=np.float32).reshape(self.B, cfg.hidden)
+        codes = np.zeros((self.B, 15), dtype=np.uint32); lg = np.zeros((self.B, 15, cfg.cp_vocab), dtype=np.float32)
+        check(lib.q3_cp_generate(self._h, lh.ctypes.data_as(ctypes.c_void_p), se.ctypes.data_as(ctypes.c_void_p),
+                                 codes.ctypes.data_as(ctypes.c_void_p), lg.ctypes.data_as(ctypes.c_void_p)))
+        return codes, lg
+
+    def set_profile(self, on: bool):
+        check(lib.q3_session_set_profile(self._h, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> Tuple[float, float, int]:
+        ms = ctypes.c_double(); by = ctypes.c_double(); n = ctypes.c_long()
+        check(lib.q3_session_profile_read(self._h, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n), 1 if reset else 0))
+        return ms.value, by.value, n.value
+
+    def frame_bytes(self, kv_len: int) -> Tuple[float, float]:
+        w = ctypes.c_double(); k = ctypes.c_double()
+        check(lib.q3_session_frame_bytes(self._h, kv_len, ctypes.byref(w), ctypes.byref(k)))
+        return w.value, k.value
+
+
+class StreamingSession:
+    """StreamingSession (lib.rs:1484-1782): iterate to receive AudioBuffer chunks of up to
+    chunk_frames*1920 samples; each chunk is decoded as an independent utterance (lib.rs:1755-1758)."""
+
+    def __init__(self, model: "Qwen3TTS", utt: Utterance, options: SynthesisOptions):
+        self._s = Session(model, [utt], options)
+        self._done = False
+        self._spf = model.config.samples_per_frame
+        self._chunk = options.chunk_frames
+
+    def next_chunk(self) -> Optional[AudioBuffer]:
+        if self._done:
+            return None
+        buf = np.zeros(self._chunk * self._spf, dtype=np.float32)
+        n = ctypes.c_size_t(); d = ctypes.c_int()
+        check(lib.q3_session_next_chunk(self._s._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(n), ctypes.byref(d)))
+        if d.value:
+            self._done = True
+        if n.value == 0:
+            return None
+        return AudioBuffer(buf[:n.value].copy())
+
+    def frames_generated(self) -> int:
+        return self._s.frames(0)[0]
+
+    def is_done(self) -> bool:
+        return self._done
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> AudioBuffer:
+        c = self.next_chunk()
+        if c is None:
+            raise StopIteration
+        return c
+
+
+class Qwen3TTS:
+    """Qwen3TTS facade (lib.rs:154-173). Construct with `from_tensors` (name → array, the
+    from_weights path, lib.rs:267) or `from_synthetic`."""
+
+    def __init__(self, config: Q3Config, device: int = 0):
+        self.config = config
+        self.device_index = device
+        h = ctypes.c_void_p()
+        c = config.to_c()
+        check(lib.q3_model_create(ctypes.byref(c), device, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.q3_model_free(self._h); self._h = None
+
+    __del__ = close
+
+    def set_tensor(self, name: str, arr: np.ndarray, dtype: int):
+        a = np.ascontiguousarray(arr)
+        check(lib.q3_model_set_tensor(self._h, name.encode(), dtype, a.ctypes.data_as(ctypes.c_void_p), a.size))
+
+    def finalize(self):
+        check(lib.q3_model_finalize(self._h))
+
+    @classmethod
+    def from_synthetic(cls, config: Q3Config, device: int = 0, seed: int = synth.DEFAULT_SEED, sink=None) -> "Qwen3TTS":
+        """`sink(name, array, dtype)` (optional) also receives every tensor — used by tests to feed the
+        CPU oracle the identical checkpoint."""
+        m = cls(config, device)
+        for name, arr, dt in synth.synthetic_checkpoint(config, m._h, seed):
+            m.set_tensor(name, arr, dt)
+            if sink is not None:
+                sink(name, arr, dt)
+        m.finalize()
+        return m
+
+    @classmethod
+    def from_tensors(cls, config: Q3Config, tensors, device: int = 0) -> "Qwen3TTS":
+        m = cls(config, device)
+        for name, (arr, dt) in tensors.items():
+            m.set_tensor(name, arr, dt)
+        m.finalize()
+        return m
+
+    def arena(self) -> Tuple[int, int]:
+        p = ctypes.c_void_p(); n = ctypes.c_size_t()
+        check(lib.q3_model_arena(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def mark_loaded(self):
+        check(lib.q3_model_mark_loaded(self._h))
+
+    # ---- synthesis API (lib.rs:416-501, 718-870, 1070-1110) ----
+    def session(self, utts: Sequence[Utterance], options: Optional[SynthesisOptions] = None, debug: bool = False) -> Session:
+        return Session(self, utts, options or SynthesisOptions(), debug)
+
+    def synthesize(self, text_ids: Sequence[int], options: Optional[SynthesisOptions] = None) -> AudioBuffer:
+        return self.synthesize_with_voice(text_ids, Speaker.Ryan, Language.English, options)
+
+    def synthesize_with_voice(self, text_ids, speaker: Speaker, language: Language, options=None) -> AudioBuffer:
+        audio, _ = self.synthesize_with_timing(text_ids, speaker, language, options)
+        return audio
+
+    def synthesize_with_timing(self, text_ids, speaker: Speaker, language: Language, options=None):
+        s = self.session([Utterance(text_ids, speaker, language)], options)
+        try:
+            audio, timing = s.run()
+        finally:
+            s.close()
+        return audio[0], timing
+
+    def synthesize_voice_design(self, text_ids, instruct_ids, language: Language, options=None) -> AudioBuffer:
+        s = self.session([Utterance(text_ids, language=language, instruct_ids=instruct_ids)], options)
+        try:
+            audio, _ = s.run()
+        finally:
+            s.close()
+        return audio[0]
+
+    def synthesize_batch(self, utts: Sequence[Utterance], options=None):
+        s = self.session(utts, options)
+        try:
+            return s.run()
+        finally:
+            s.close()
+
+    def synthesize_streaming(self, text_ids, speaker: Speaker, language: Language, options=None) -> StreamingSession:
+        return StreamingSession(self, Utterance(text_ids, speaker, language), options or SynthesisOptions())
+
+    def decode_codes(self, codes: np.ndarray, taps=None) -> AudioBuffer:
+        """decode_codes (lib.rs:881-890): codes [n][16] u32."""
+        c = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, 16)
+        out = np.zeros(c.shape[0] * self.config.samples_per_frame, dtype=np.float32)
+        tp = None
+        if taps is not None:
+            tp = (ctypes.c_void_p * 10)(*[t.ctypes.data_as(ctypes.c_void_p) if t is not None else None for t in taps])
+        check(lib.q3_decode_codes(self._h, c.ctypes.data_as(ctypes.c_void_p), c.shape[0], out.ctypes.data_as(ctypes.c_void_p), tp))
+        return AudioBuffer(out)
+
+    def frame_embed(self, sem_token: int, codes15, text_add: np.ndarray) -> np.ndarray:
+        c = np.ascontiguousarray(codes15, dtype=np.uint32); t = np.ascontiguousarray(text_add, dtype=np.float32)
+        out = np.zeros(self.config.hidden, dtype=np.float32)
+        check(lib.q3_frame_embed(self._h, int(sem_token), c.ctypes.data_as(ctypes.c_void_p), t.ctypes.data_as(ctypes.c_void_p),
+                                 out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+
+def codes_to_tensor(codes: np.ndarray) -> np.ndarray:
+    """codes_to_tensor (lib.rs:1417-1431): [n][16] u32 → [1][16][n] i64."""
+    c = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, 16)
+    out = np.zeros((16, c.shape[0]), dtype=np.int64)
+    lib.q3_codes_to_tensor(c.ctypes.data_as(ctypes.c_void_p), c.shape[0], out.ctypes.data_as(ctypes.c_void_p))
+    return out.reshape(1, 16, c.shape[0])
+
+
+# ---- standalone ops (parity tests) ----
+def fused_residual_rmsnorm(x: np.ndarray, res: np.ndarray, w: np.ndarray, eps: float, device: int = 0):
+    """FusedRmsNorm::forward_residual (fused_ops.rs:49-96) on the GPU. f32 arrays, or uint16 = bf16 bits."""
+    rows, cols = x.shape
+    dt = 1 if x.dtype == np.uint16 else 0
+    x = np.ascontiguousarray(x); res = np.ascontiguousarray(res); w = np.ascontiguousarray(w)
+    normed = np.zeros_like(x); summ = np.zeros_like(x)
+    check(lib.q3_fused_residual_rmsnorm(device, dt, x.ctypes.data_as(ctypes.c_void_p), res.ctypes.data_as(ctypes.c_void_p),
+                                        w.ctypes.data_as(ctypes.c_void_p), rows, cols, eps,
+                                        normed.ctypes.data_as(ctypes.c_void_p), summ.ctypes.data_as(ctypes.c_void_p)))
+    return normed, summ
+
+
+def linear(x: np.ndarray, w_bf16: np.ndarray, bias: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
+    M, K = x.shape; N = w_bf16.shape[0]
+    x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w_bf16, dtype=np.uint16)
+    y = np.zeros((M, N), dtype=np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    check(lib.q3_linear(device, x.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p),
+                        None if b is None else b.ctypes.data_as(ctypes.c_void_p), M, N, K, y.ctypes.data_as(ctypes.c_void_p)))
+    return y
+
+
+def sample(logits: np.ndarray, u: np.ndarray, options: SynthesisOptions, seen: Optional[np.ndarray] = None,
+           token_count: int = -1, device: int = 0) -> np.ndarray:
+    """apply_generation_penalties + sample on the GPU (token_count < 0: plain `sample`, sampling.rs:140)."""
+    lg = np.ascontiguousarray(logits, dtype=np.float32); rows, vocab = lg.shape
+    uu = np.ascontiguousarray(u, dtype=np.float32)
+    out = np.zeros(rows, dtype=np.uint32)
+    o = options.to_c()
+    sn = None if seen is None else np.ascontiguousarray(seen, dtype=np.uint8)
+    check(lib.q3_sample(device, lg.ctypes.data_as(ctypes.c_void_p), None if sn is None else sn.ctypes.data_as(ctypes.c_void_p),
+                        uu.ctypes.data_as(ctypes.c_void_p), rows, vocab, ctypes.byref(o), token_count,
+                        out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def auto_device() -> int:
+    """auto_device (lib.rs:1854-1926): this build has exactly one backend — an MI355X. No CPU path."""
+    n = lib.q3_device_count()
+    if n <= 0:
+        raise RuntimeError("no HIP device visible: the MI355X-native build has no CPU fallback")
+    return 0

@@ -1,0 +1,1532 @@
+// q3_engine.hip — host side of libq3tts.so: weight arena, sessions (KV pages, RNG streams, penalty
+// masks), the per-frame launch sequence (optionally replayed as one hipGraph), the codec-decoder
+// pipeline and the C ABI declared in include/q3tts.h.
+//
+// Layer map of the reference this file replaces (paths relative to the reference repo):
+//   src/lib.rs:530-656 generate_codes, 425-501 synthesize_with_timing, 1484-1782 StreamingSession
+//   src/models/talker.rs:451-627 prefill builders, 716-736 generate_step_with_embed
+//   src/models/code_predictor.rs:320-416 generate_acoustic_codes
+//   src/models/codec/decoder_12hz.rs:411-505 decode
+#include "../../include/q3tts.h"
+#include "q3_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace q3;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static q3_status set_err(q3_status st, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return st;
+}
+#define HIPC(expr)                                                                                        \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return set_err(Q3_HIP_ERROR, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                                     \
+    } while (0)
+#define Q3C(expr)                         \
+    do {                                  \
+        q3_status s_ = (expr);            \
+        if (s_ != Q3_OK) return s_;       \
+    } while (0)
+
+extern "C" int q3_abi_version(void) { return Q3_ABI_VERSION; }
+extern "C" const char* q3_last_error(void) { return g_err; }
+extern "C" int q3_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+// token ids (talker.rs:30-55)
+enum { IM_START = 151644, ASSISTANT = 77091, NEWLINE = 198, TTS_PAD = 151671, TTS_BOS = 151672, TTS_EOS = 151673 };
+enum { CODEC_PAD = 2148, CODEC_BOS = 2149, CODEC_EOS = 2150, CODEC_THINK = 2154, CODEC_THINK_BOS = 2156, CODEC_THINK_EOS = 2157 };
+
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32_host(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// ------------------------------------------------------------------------------------------------
+// synthetic tensor generator (host)
+// ------------------------------------------------------------------------------------------------
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+static inline uint64_t fnv1a64(const char* s) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (; *s; ++s) { h ^= (unsigned char)*s; h *= 0x100000001b3ULL; }
+    return h;
+}
+extern "C" q3_status q3_synth_fill(uint64_t seed, const char* name, int dtype, float scale, float offset, int64_t n,
+                                   void* out_host) {
+    if (!name || !out_host || n < 0) return set_err(Q3_INVALID_ARG, "q3_synth_fill: bad argument");
+    const uint64_t key = splitmix64(seed ^ fnv1a64(name));
+    // Irwin-Hall(4) of 16-bit uniforms: exact integer sum, std = 65536/sqrt(3)
+    const float c = (float)((double)scale / (65536.0 / 1.7320508075688772));
+    float* of = (float*)out_host; uint16_t* ob = (uint16_t*)out_host;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t z = splitmix64(key + (uint64_t)i * 0x9E3779B97F4A7C15ULL);
+        const int s = (int)(z & 0xffff) + (int)((z >> 16) & 0xffff) + (int)((z >> 32) & 0xffff) + (int)((z >> 48) & 0xffff) - 131070;
+        const float v = offset + (float)s * c;
+        if (dtype == Q3_DTYPE_BF16) ob[i] = f32_to_bf16_host(v);
+        else of[i] = v;
+    }
+    return Q3_OK;
+}
+
+// PCG stream (sampling.rs:32-51, 84-94)
+extern "C" void q3_rng_seed(uint64_t seed, uint64_t* state) { *state = seed * 2685821657736338717ULL + 1442695040888963407ULL; }
+extern "C" float q3_rng_next(uint64_t* state) {
+    const uint64_t old = *state;
+    *state = old * 6364136223846793005ULL + 1442695040888963407ULL;
+    const uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+    const uint32_t out = (xs >> rot) | (xs << ((32 - rot) & 31));
+    return (float)out / (float)UINT32_MAX;
+}
+extern "C" void q3_codes_to_tensor(const uint32_t* frames, int n_frames, int64_t* out) {
+    for (int f = 0; f < n_frames; ++f)
+        for (int q = 0; q < 16; ++q) out[(size_t)q * n_frames + f] = (int64_t)frames[(size_t)f * 16 + q];
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+enum SlotKind { SK_PLAIN = 0, SK_TRANSCONV = 1 };
+struct Slot {
+    std::string name; int64_t n = 0; int stored = Q3_DTYPE_F32; size_t offset = 0; bool loaded = false;
+    int kind = SK_PLAIN; int tc_cin = 0, tc_cout = 0, tc_k = 0, tc_stride = 0;
+};
+struct LayerW {
+    const float *in_ln, *q_norm, *k_norm, *post_ln;
+    const uint16_t *qkv, *o, *gate, *up, *down;
+};
+struct DecLayerW { const float *in_ln, *q, *k, *v, *o, *attn_scale, *post_ln, *gate, *up, *down, *mlp_scale; };
+struct ResUnitW { const float *a1, *ib1, *c1w, *c1b, *a2, *ib2, *c2w, *c2b; };
+struct DecBlockW { const float *a, *ib, *tw, *tb; ResUnitW res[3]; int cin, cout, rate; };
+struct UpW { const float *tw, *tb, *dww, *dwb, *nw, *nb, *p1w, *p1b, *p2w, *p2b, *gamma; int ratio; };
+
+struct q3_model {
+    q3_config cfg{};
+    int device = 0;
+    std::vector<Slot> slots;
+    std::unordered_map<std::string, int> index;
+    char* arena = nullptr; size_t arena_bytes = 0;
+    bool finalized = false;
+    // derived device buffers
+    float *rope_cos = nullptr, *rope_sin = nullptr; int rope_len = 0;      // talker/CP (theta, hd 128)
+    float* derived = nullptr;                                              // codebooks + snake tables
+    const float* first_cb = nullptr; const float** rest_cbs_dev = nullptr; // device array of 15 pointers
+    const uint16_t** cp_embs_dev = nullptr;                                // device array of 15 pointers
+    // resolved pointers
+    const uint16_t *text_emb, *fc1w, *fc2w, *codec_emb, *codec_head, *mtp_w;
+    const float *fc1b, *fc2b, *norm, *mtp_b, *cp_norm;
+    std::vector<LayerW> tl, cl;
+    std::vector<const uint16_t*> cp_emb, cp_head;
+    const float *first_proj, *rest_proj, *pre_w, *pre_b, *inp_w, *inp_b, *outp_w, *outp_b, *dec_norm;
+    std::vector<DecLayerW> dl;
+    UpW up[2]; const float *init_w, *init_b; DecBlockW blk[4];
+    const float *fin_a, *fin_ib, *fin_w, *fin_b;
+};
+
+static void add_slot(q3_model* m, const std::string& name, int64_t n, int stored, bool align = true) {
+    Slot s; s.name = name; s.n = n; s.stored = stored;
+    size_t off = m->arena_bytes;
+    if (align) off = (off + 255) & ~(size_t)255;
+    s.offset = off;
+    m->arena_bytes = off + (size_t)n * (stored == Q3_DTYPE_BF16 ? 2 : 4);
+    m->index[name] = (int)m->slots.size();
+    m->slots.push_back(s);
+}
+static void add_layer_slots(q3_model* m, const std::string& p, int H, int I, int nh, int nkv, int hd) {
+    add_slot(m, p + ".input_layernorm.weight", H, Q3_DTYPE_F32);
+    // q,k,v rows are stored back to back so the fused QKV GEMV sees one [QD+2KD][H] matrix
+    add_slot(m, p + ".self_attn.q_proj.weight", (int64_t)nh * hd * H, Q3_DTYPE_BF16);
+    add_slot(m, p + ".self_attn.k_proj.weight", (int64_t)nkv * hd * H, Q3_DTYPE_BF16, false);
+    add_slot(m, p + ".self_attn.v_proj.weight", (int64_t)nkv * hd * H, Q3_DTYPE_BF16, false);
+    add_slot(m, p + ".self_attn.o_proj.weight", (int64_t)H * nh * hd, Q3_DTYPE_BF16);
+    add_slot(m, p + ".self_attn.q_norm.weight", hd, Q3_DTYPE_F32);
+    add_slot(m, p + ".self_attn.k_norm.weight", hd, Q3_DTYPE_F32);
+    add_slot(m, p + ".post_attention_layernorm.weight", H, Q3_DTYPE_F32);
+    add_slot(m, p + ".mlp.gate_proj.weight", (int64_t)I * H, Q3_DTYPE_BF16);
+    add_slot(m, p + ".mlp.up_proj.weight", (int64_t)I * H, Q3_DTYPE_BF16);
+    add_slot(m, p + ".mlp.down_proj.weight", (int64_t)H * I, Q3_DTYPE_BF16);
+}
+static std::string fmt(const char* f, ...) {
+    char b[256]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return b;
+}
+
+// tensor manifest: names/shapes of SURVEY.md Appendix B (talker.rs:380-405, code_predictor.rs:163-205,
+// decoder_12hz.rs:191-381)
+static void build_manifest(q3_model* m) {
+    const q3_config& c = m->cfg;
+    const int H = c.hidden, TD = c.text_dim, CH = c.cp_hidden;
+    add_slot(m, "talker.model.text_embedding.weight", (int64_t)c.text_vocab * TD, Q3_DTYPE_BF16);
+    add_slot(m, "talker.text_projection.linear_fc1.weight", (int64_t)TD * TD, Q3_DTYPE_BF16);
+    add_slot(m, "talker.text_projection.linear_fc1.bias", TD, Q3_DTYPE_F32);
+    add_slot(m, "talker.text_projection.linear_fc2.weight", (int64_t)H * TD, Q3_DTYPE_BF16);
+    add_slot(m, "talker.text_projection.linear_fc2.bias", H, Q3_DTYPE_F32);
+    add_slot(m, "talker.model.codec_embedding.weight", (int64_t)c.codec_vocab * H, Q3_DTYPE_BF16);
+    for (int i = 0; i < c.n_layers; ++i)
+        add_layer_slots(m, fmt("talker.model.layers.%d", i), H, c.inter, c.n_heads, c.n_kv_heads, c.head_dim);
+    add_slot(m, "talker.model.norm.weight", H, Q3_DTYPE_F32);
+    add_slot(m, "talker.codec_head.weight", (int64_t)c.codec_vocab * H, Q3_DTYPE_BF16);
+    if (H != CH) {
+        add_slot(m, "talker.code_predictor.small_to_mtp_projection.weight", (int64_t)CH * H, Q3_DTYPE_BF16);
+        add_slot(m, "talker.code_predictor.small_to_mtp_projection.bias", CH, Q3_DTYPE_F32);
+    }
+    for (int g = 0; g < c.n_groups - 1; ++g)
+        add_slot(m, fmt("talker.code_predictor.model.codec_embedding.%d.weight", g), (int64_t)c.cp_vocab * H, Q3_DTYPE_BF16);
+    for (int i = 0; i < c.cp_layers; ++i)
+        add_layer_slots(m, fmt("talker.code_predictor.model.layers.%d", i), CH, c.cp_inter, c.cp_heads, c.cp_kv_heads, c.head_dim);
+    add_slot(m, "talker.code_predictor.model.norm.weight", CH, Q3_DTYPE_F32);
+    for (int g = 0; g < c.n_groups - 1; ++g)
+        add_slot(m, fmt("talker.code_predictor.lm_head.%d.weight", g), (int64_t)c.cp_vocab * CH, Q3_DTYPE_BF16);
+    // decoder (all f32)
+    const int CB = c.dec_cb_size, CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden;
+    const int QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
+    auto F = [&](const std::string& n, int64_t cnt) { add_slot(m, n, cnt, Q3_DTYPE_F32); };
+    F("decoder.quantizer.rvq_first.vq.layers.0._codebook.embedding_sum", (int64_t)CB * CD);
+    F("decoder.quantizer.rvq_first.vq.layers.0._codebook.cluster_usage", CB);
+    for (int i = 0; i < 15; ++i) {
+        F(fmt("decoder.quantizer.rvq_rest.vq.layers.%d._codebook.embedding_sum", i), (int64_t)CB * CD);
+        F(fmt("decoder.quantizer.rvq_rest.vq.layers.%d._codebook.cluster_usage", i), CB);
+    }
+    F("decoder.quantizer.rvq_first.output_proj.weight", (int64_t)Q * CD);
+    F("decoder.quantizer.rvq_rest.output_proj.weight", (int64_t)Q * CD);
+    F("decoder.pre_conv.conv.weight", (int64_t)LAT * Q * 3);
+    F("decoder.pre_conv.conv.bias", LAT);
+    F("decoder.pre_transformer.input_proj.weight", (int64_t)DH * LAT);
+    F("decoder.pre_transformer.input_proj.bias", DH);
+    F("decoder.pre_transformer.output_proj.weight", (int64_t)LAT * DH);
+    F("decoder.pre_transformer.output_proj.bias", LAT);
+    F("decoder.pre_transformer.norm.weight", DH);
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string p = fmt("decoder.pre_transformer.layers.%d", i);
+        F(p + ".input_layernorm.weight", DH);
+        F(p + ".self_attn.q_proj.weight", (int64_t)QD * DH);
+        F(p + ".self_attn.k_proj.weight", (int64_t)QD * DH);
+        F(p + ".self_attn.v_proj.weight", (int64_t)QD * DH);
+        F(p + ".self_attn.o_proj.weight", (int64_t)DH * QD);
+        F(p + ".self_attn_layer_scale.scale", DH);
+        F(p + ".post_attention_layernorm.weight", DH);
+        F(p + ".mlp.gate_proj.weight", (int64_t)DI * DH);
+        F(p + ".mlp.up_proj.weight", (int64_t)DI * DH);
+        F(p + ".mlp.down_proj.weight", (int64_t)DH * DI);
+        F(p + ".mlp_layer_scale.scale", DH);
+    }
+    auto TC = [&](const std::string& n, int cin, int cout, int k, int stride) {
+        add_slot(m, n, (int64_t)cin * cout * k, Q3_DTYPE_F32);
+        Slot& s = m->slots.back(); s.kind = SK_TRANSCONV; s.tc_cin = cin; s.tc_cout = cout; s.tc_k = k; s.tc_stride = stride;
+    };
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = fmt("decoder.upsample.%d", i);
+        const int r = c.dec_up_ratios[i];
+        TC(p + ".0.conv.weight", LAT, LAT, r, r);
+        F(p + ".0.conv.bias", LAT);
+        F(p + ".1.dwconv.conv.weight", (int64_t)LAT * 7);
+        F(p + ".1.dwconv.conv.bias", LAT);
+        F(p + ".1.norm.weight", LAT);
+        F(p + ".1.norm.bias", LAT);
+        F(p + ".1.pwconv1.weight", (int64_t)4 * LAT * LAT);
+        F(p + ".1.pwconv1.bias", 4 * LAT);
+        F(p + ".1.pwconv2.weight", (int64_t)4 * LAT * LAT);
+        F(p + ".1.pwconv2.bias", LAT);
+        F(p + ".1.gamma", LAT);
+    }
+    const int D = c.dec_dim;
+    F("decoder.decoder.0.conv.weight", (int64_t)D * LAT * 7);
+    F("decoder.decoder.0.conv.bias", D);
+    int cin = D;
+    for (int b = 0; b < 4; ++b) {
+        const int r = c.dec_up_rates[b], cout = cin / 2;
+        const std::string p = fmt("decoder.decoder.%d.block", b + 1);
+        F(p + ".0.alpha", cin); F(p + ".0.beta", cin);
+        TC(p + ".1.conv.weight", cin, cout, 2 * r, r);
+        F(p + ".1.conv.bias", cout);
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = fmt("%s.%d", p.c_str(), u + 2);
+            F(q + ".act1.alpha", cout); F(q + ".act1.beta", cout);
+            F(q + ".conv1.conv.weight", (int64_t)cout * cout * 7); F(q + ".conv1.conv.bias", cout);
+            F(q + ".act2.alpha", cout); F(q + ".act2.beta", cout);
+            F(q + ".conv2.conv.weight", (int64_t)cout * cout); F(q + ".conv2.conv.bias", cout);
+        }
+        cin = cout;
+    }
+    F("decoder.decoder.5.alpha", cin); F("decoder.decoder.5.beta", cin);
+    F("decoder.decoder.6.conv.weight", (int64_t)cin * 7);
+    F("decoder.decoder.6.conv.bias", 1);
+}
+
+static q3_status check_config(const q3_config& c) {
+    if (c.head_dim != HEAD_DIM) return set_err(Q3_UNSUPPORTED, "head_dim %d unsupported (kernels are built for 128)", c.head_dim);
+    if (c.dec_head_dim != 64) return set_err(Q3_UNSUPPORTED, "decoder head_dim %d unsupported (64)", c.dec_head_dim);
+    if (c.hidden % 8 || c.inter % 8 || c.text_dim % 8 || c.cp_hidden % 8 || c.cp_inter % 8)
+        return set_err(Q3_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 8");
+    if (c.n_groups != 16) return set_err(Q3_UNSUPPORTED, "n_groups must be 16");
+    if (c.codec_vocab > 4096 || c.codec_vocab < 1024) return set_err(Q3_UNSUPPORTED, "codec_vocab must be in [1024, 4096]");
+    const int nrep = c.n_heads / (c.n_kv_heads ? c.n_kv_heads : 1), crep = c.cp_heads / (c.cp_kv_heads ? c.cp_kv_heads : 1);
+    if ((nrep != 1 && nrep != 2 && nrep != 4) || (crep != 1 && crep != 2 && crep != 4))
+        return set_err(Q3_UNSUPPORTED, "heads/kv_heads ratio must be 1, 2 or 4");
+    if (c.dec_cb_dim > 256) return set_err(Q3_UNSUPPORTED, "dec_cb_dim > 256");
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model** out) {
+    if (!cfg || !out) return set_err(Q3_INVALID_ARG, "q3_model_create: null argument");
+    Q3C(check_config(*cfg));
+    if (device == -1) {   // manifest-only handle (no GPU): names/shapes for tools and CPU tests
+        std::unique_ptr<q3_model> mm(new q3_model());
+        mm->cfg = *cfg; mm->device = -1;
+        build_manifest(mm.get());
+        *out = mm.release();
+        return Q3_OK;
+    }
+    int ndev = 0;
+    HIPC(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return set_err(Q3_INVALID_ARG, "device %d not available (%d visible)", device, ndev);
+    HIPC(hipSetDevice(device));
+    std::unique_ptr<q3_model> m(new q3_model());
+    m->cfg = *cfg; m->device = device;
+    build_manifest(m.get());
+    HIPC(hipMalloc((void**)&m->arena, m->arena_bytes));
+    HIPC(hipMemset(m->arena, 0, m->arena_bytes));
+    *out = m.release();
+    return Q3_OK;
+}
+
+extern "C" void q3_model_free(q3_model* m) {
+    if (!m) return;
+    if (m->device < 0) { delete m; return; }
+    hipSetDevice(m->device);
+    hipFree(m->arena); hipFree(m->rope_cos); hipFree(m->rope_sin); hipFree(m->derived);
+    hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev);
+    delete m;
+}
+
+extern "C" int q3_model_n_tensors(const q3_model* m) { return m ? (int)m->slots.size() : 0; }
+extern "C" q3_status q3_model_tensor_info(const q3_model* m, int i, const char** name, int64_t* n, int* stored_dtype) {
+    if (!m || i < 0 || i >= (int)m->slots.size()) return set_err(Q3_INVALID_ARG, "tensor index out of range");
+    if (name) *name = m->slots[i].name.c_str();
+    if (n) *n = m->slots[i].n;
+    if (stored_dtype) *stored_dtype = m->slots[i].stored;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtype, const void* data, int64_t n) {
+    if (!m || !name || !data) return set_err(Q3_INVALID_ARG, "q3_model_set_tensor: null argument");
+    auto it = m->index.find(name);
+    if (it == m->index.end()) return set_err(Q3_INVALID_ARG, "unknown tensor name: %s", name);
+    Slot& s = m->slots[it->second];
+    if (n != s.n) return set_err(Q3_INVALID_ARG, "tensor %s has %lld elements, expected %lld", name, (long long)n, (long long)s.n);
+    if (m->device < 0) return set_err(Q3_UNSUPPORTED, "manifest-only model handle (device -1) holds no weights");
+    HIPC(hipSetDevice(m->device));
+    const size_t bytes = (size_t)n * (s.stored == Q3_DTYPE_BF16 ? 2 : 4);
+    std::vector<char> tmp;
+    const void* src = data;
+    if (s.kind == SK_TRANSCONV) {
+        // [cin][cout][k] → per-phase causal-conv weights [stride][cout][cin][taps]
+        std::vector<float> w((size_t)n);
+        if (dtype == Q3_DTYPE_F32) memcpy(w.data(), data, (size_t)n * 4);
+        else for (int64_t i = 0; i < n; ++i) w[(size_t)i] = bf16_to_f32_host(((const uint16_t*)data)[i]);
+        const int cin = s.tc_cin, cout = s.tc_cout, k = s.tc_k, st = s.tc_stride, taps = k / st;
+        tmp.resize(bytes);
+        float* o = (float*)tmp.data();
+        for (int ph = 0; ph < st; ++ph)
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int tp = 0; tp < taps; ++tp) {
+                        // tap tp multiplies x[j - (taps-1-tp)]  ⇒  kernel index ph + (taps-1-tp)*stride
+                        const int kk = ph + (taps - 1 - tp) * st;
+                        o[(((size_t)ph * cout + co) * cin + ci) * taps + tp] = w[((size_t)ci * cout + co) * k + kk];
+                    }
+        src = tmp.data();
+    } else if (s.stored == Q3_DTYPE_BF16 && dtype == Q3_DTYPE_F32) {
+        tmp.resize(bytes);
+        uint16_t* o = (uint16_t*)tmp.data(); const float* f = (const float*)data;
+        for (int64_t i = 0; i < n; ++i) o[i] = f32_to_bf16_host(f[i]);
+        src = tmp.data();
+    } else if (s.stored == Q3_DTYPE_F32 && dtype == Q3_DTYPE_BF16) {
+        tmp.resize(bytes);
+        float* o = (float*)tmp.data(); const uint16_t* h = (const uint16_t*)data;
+        for (int64_t i = 0; i < n; ++i) o[i] = bf16_to_f32_host(h[i]);
+        src = tmp.data();
+    } else if (dtype != Q3_DTYPE_F32 && dtype != Q3_DTYPE_BF16) {
+        return set_err(Q3_INVALID_ARG, "unsupported source dtype %d", dtype);
+    }
+    HIPC(hipMemcpy(m->arena + s.offset, src, bytes, hipMemcpyHostToDevice));
+    s.loaded = true;
+    m->finalized = false;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_model_arena(q3_model* m, void** dev_ptr, size_t* bytes) {
+    if (!m) return set_err(Q3_INVALID_ARG, "null model");
+    if (dev_ptr) *dev_ptr = m->arena;
+    if (bytes) *bytes = m->arena_bytes;
+    return Q3_OK;
+}
+extern "C" q3_status q3_model_mark_loaded(q3_model* m) {
+    if (!m) return set_err(Q3_INVALID_ARG, "null model");
+    for (auto& s : m->slots) s.loaded = true;
+    return Q3_OK;
+}
+
+template <typename T>
+static const T* P(const q3_model* m, const std::string& name) {
+    auto it = m->index.find(name);
+    if (it == m->index.end()) return nullptr;
+    return (const T*)(m->arena + m->slots[it->second].offset);
+}
+static void resolve_layer(const q3_model* m, LayerW& L, const std::string& p) {
+    L.in_ln = P<float>(m, p + ".input_layernorm.weight");
+    L.qkv = P<uint16_t>(m, p + ".self_attn.q_proj.weight");
+    L.o = P<uint16_t>(m, p + ".self_attn.o_proj.weight");
+    L.q_norm = P<float>(m, p + ".self_attn.q_norm.weight");
+    L.k_norm = P<float>(m, p + ".self_attn.k_norm.weight");
+    L.post_ln = P<float>(m, p + ".post_attention_layernorm.weight");
+    L.gate = P<uint16_t>(m, p + ".mlp.gate_proj.weight");
+    L.up = P<uint16_t>(m, p + ".mlp.up_proj.weight");
+    L.down = P<uint16_t>(m, p + ".mlp.down_proj.weight");
+}
+
+extern "C" q3_status q3_model_finalize(q3_model* m) {
+    if (!m) return set_err(Q3_INVALID_ARG, "null model");
+    if (m->device < 0) return set_err(Q3_UNSUPPORTED, "manifest-only model handle (device -1) cannot be finalized");
+    for (auto& s : m->slots)
+        if (!s.loaded) return set_err(Q3_MISSING_WEIGHT, "Missing weight: %s", s.name.c_str());
+    HIPC(hipSetDevice(m->device));
+    const q3_config& c = m->cfg;
+    m->text_emb = P<uint16_t>(m, "talker.model.text_embedding.weight");
+    m->fc1w = P<uint16_t>(m, "talker.text_projection.linear_fc1.weight");
+    m->fc1b = P<float>(m, "talker.text_projection.linear_fc1.bias");
+    m->fc2w = P<uint16_t>(m, "talker.text_projection.linear_fc2.weight");
+    m->fc2b = P<float>(m, "talker.text_projection.linear_fc2.bias");
+    m->codec_emb = P<uint16_t>(m, "talker.model.codec_embedding.weight");
+    m->norm = P<float>(m, "talker.model.norm.weight");
+    m->codec_head = P<uint16_t>(m, "talker.codec_head.weight");
+    m->mtp_w = P<uint16_t>(m, "talker.code_predictor.small_to_mtp_projection.weight");
+    m->mtp_b = P<float>(m, "talker.code_predictor.small_to_mtp_projection.bias");
+    m->cp_norm = P<float>(m, "talker.code_predictor.model.norm.weight");
+    m->tl.resize(c.n_layers); m->cl.resize(c.cp_layers);
+    for (int i = 0; i < c.n_layers; ++i) resolve_layer(m, m->tl[i], fmt("talker.model.layers.%d", i));
+    for (int i = 0; i < c.cp_layers; ++i) resolve_layer(m, m->cl[i], fmt("talker.code_predictor.model.layers.%d", i));
+    m->cp_emb.resize(15); m->cp_head.resize(15);
+    for (int g = 0; g < 15; ++g) {
+        m->cp_emb[g] = P<uint16_t>(m, fmt("talker.code_predictor.model.codec_embedding.%d.weight", g));
+        m->cp_head[g] = P<uint16_t>(m, fmt("talker.code_predictor.lm_head.%d.weight", g));
+    }
+    if (!m->cp_embs_dev) HIPC(hipMalloc((void**)&m->cp_embs_dev, 15 * sizeof(void*)));
+    HIPC(hipMemcpy((void*)m->cp_embs_dev, m->cp_emb.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
+
+    // RoPE tables on the host with libm (bit-identical to the CPU oracle): transformer.rs:78-92, 133-175
+    if (!m->rope_cos) {
+        m->rope_len = 8192;
+        std::vector<float> cs((size_t)m->rope_len * 64), sn((size_t)m->rope_len * 64);
+        for (int i = 0; i < 64; ++i) {
+            const float inv = 1.0f / powf(c.rope_theta, (float)(2 * i) / (float)HEAD_DIM);
+            for (int p = 0; p < m->rope_len; ++p) {
+                const float f = (float)p * inv;
+                cs[(size_t)p * 64 + i] = cosf(f); sn[(size_t)p * 64 + i] = sinf(f);
+            }
+        }
+        HIPC(hipMalloc((void**)&m->rope_cos, cs.size() * 4));
+        HIPC(hipMalloc((void**)&m->rope_sin, sn.size() * 4));
+        HIPC(hipMemcpy(m->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(m->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    }
+
+    // decoder pointers + derived tensors (normalised codebooks, snake tables)
+    const int CB = c.dec_cb_size, CD = c.dec_cb_dim;
+    size_t n_snake = 0;
+    { int cin = c.dec_dim; for (int b = 0; b < 4; ++b) { n_snake += cin; cin /= 2; n_snake += (size_t)cin * 6; } n_snake += cin; }
+    const size_t derived_floats = (size_t)16 * CB * CD + 2 * n_snake;
+    if (!m->derived) HIPC(hipMalloc((void**)&m->derived, derived_floats * 4));
+    float* cursor = m->derived;
+    std::vector<const float*> rest(15);
+    auto CBOOK = [&](const std::string& p) -> const float* {
+        float* dst = cursor; cursor += (size_t)CB * CD;
+        launch_norm_codebook(P<float>(m, p + "._codebook.embedding_sum"), P<float>(m, p + "._codebook.cluster_usage"), dst, CB, CD, 0);
+        return dst;
+    };
+    m->first_cb = CBOOK("decoder.quantizer.rvq_first.vq.layers.0");
+    for (int i = 0; i < 15; ++i) rest[i] = CBOOK(fmt("decoder.quantizer.rvq_rest.vq.layers.%d", i));
+    if (!m->rest_cbs_dev) HIPC(hipMalloc((void**)&m->rest_cbs_dev, 15 * sizeof(void*)));
+    HIPC(hipMemcpy((void*)m->rest_cbs_dev, rest.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
+    auto SNAKE = [&](const std::string& pa, const std::string& pb, int C, const float*& a, const float*& ib) {
+        float* da = cursor; cursor += C; float* di = cursor; cursor += C;
+        launch_snake_tables(P<float>(m, pa), P<float>(m, pb), da, di, C, 0);
+        a = da; ib = di;
+    };
+    m->first_proj = P<float>(m, "decoder.quantizer.rvq_first.output_proj.weight");
+    m->rest_proj = P<float>(m, "decoder.quantizer.rvq_rest.output_proj.weight");
+    m->pre_w = P<float>(m, "decoder.pre_conv.conv.weight"); m->pre_b = P<float>(m, "decoder.pre_conv.conv.bias");
+    m->inp_w = P<float>(m, "decoder.pre_transformer.input_proj.weight"); m->inp_b = P<float>(m, "decoder.pre_transformer.input_proj.bias");
+    m->outp_w = P<float>(m, "decoder.pre_transformer.output_proj.weight"); m->outp_b = P<float>(m, "decoder.pre_transformer.output_proj.bias");
+    m->dec_norm = P<float>(m, "decoder.pre_transformer.norm.weight");
+    m->dl.resize(c.dec_layers);
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string p = fmt("decoder.pre_transformer.layers.%d", i);
+        DecLayerW& L = m->dl[i];
+        L.in_ln = P<float>(m, p + ".input_layernorm.weight");
+        L.q = P<float>(m, p + ".self_attn.q_proj.weight"); L.k = P<float>(m, p + ".self_attn.k_proj.weight");
+        L.v = P<float>(m, p + ".self_attn.v_proj.weight"); L.o = P<float>(m, p + ".self_attn.o_proj.weight");
+        L.attn_scale = P<float>(m, p + ".self_attn_layer_scale.scale");
+        L.post_ln = P<float>(m, p + ".post_attention_layernorm.weight");
+        L.gate = P<float>(m, p + ".mlp.gate_proj.weight"); L.up = P<float>(m, p + ".mlp.up_proj.weight");
+        L.down = P<float>(m, p + ".mlp.down_proj.weight"); L.mlp_scale = P<float>(m, p + ".mlp_layer_scale.scale");
+    }
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = fmt("decoder.upsample.%d", i);
+        UpW& U = m->up[i]; U.ratio = c.dec_up_ratios[i];
+        U.tw = P<float>(m, p + ".0.conv.weight"); U.tb = P<float>(m, p + ".0.conv.bias");
+        U.dww = P<float>(m, p + ".1.dwconv.conv.weight"); U.dwb = P<float>(m, p + ".1.dwconv.conv.bias");
+        U.nw = P<float>(m, p + ".1.norm.weight"); U.nb = P<float>(m, p + ".1.norm.bias");
+        U.p1w = P<float>(m, p + ".1.pwconv1.weight"); U.p1b = P<float>(m, p + ".1.pwconv1.bias");
+        U.p2w = P<float>(m, p + ".1.pwconv2.weight"); U.p2b = P<float>(m, p + ".1.pwconv2.bias");
+        U.gamma = P<float>(m, p + ".1.gamma");
+    }
+    m->init_w = P<float>(m, "decoder.decoder.0.conv.weight"); m->init_b = P<float>(m, "decoder.decoder.0.conv.bias");
+    int cin = c.dec_dim;
+    for (int b = 0; b < 4; ++b) {
+        DecBlockW& B = m->blk[b];
+        const std::string p = fmt("decoder.decoder.%d.block", b + 1);
+        B.cin = cin; B.cout = cin / 2; B.rate = c.dec_up_rates[b];
+        SNAKE(p + ".0.alpha", p + ".0.beta", cin, B.a, B.ib);
+        B.tw = P<float>(m, p + ".1.conv.weight"); B.tb = P<float>(m, p + ".1.conv.bias");
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = fmt("%s.%d", p.c_str(), u + 2);
+            ResUnitW& R = B.res[u];
+            SNAKE(q + ".act1.alpha", q + ".act1.beta", B.cout, R.a1, R.ib1);
+            R.c1w = P<float>(m, q + ".conv1.conv.weight"); R.c1b = P<float>(m, q + ".conv1.conv.bias");
+            SNAKE(q + ".act2.alpha", q + ".act2.beta", B.cout, R.a2, R.ib2);
+            R.c2w = P<float>(m, q + ".conv2.conv.weight"); R.c2b = P<float>(m, q + ".conv2.conv.bias");
+        }
+        cin = B.cout;
+    }
+    SNAKE("decoder.decoder.5.alpha", "decoder.decoder.5.beta", cin, m->fin_a, m->fin_ib);
+    m->fin_w = P<float>(m, "decoder.decoder.6.conv.weight"); m->fin_b = P<float>(m, "decoder.decoder.6.conv.bias");
+    HIPC(hipGetLastError());
+    HIPC(hipDeviceSynchronize());
+    m->finalized = true;
+    return Q3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device buffer helper
+// ------------------------------------------------------------------------------------------------
+struct DevPool {
+    std::vector<void*> ptrs;
+    template <typename T> hipError_t alloc(T** p, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        if (e != hipSuccess) return e;
+        ptrs.push_back(q); *p = (T*)q;
+        return hipMemset(q, 0, (count ? count : 1) * sizeof(T));
+    }
+    ~DevPool() { for (void* p : ptrs) hipFree(p); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// codec decoder pipeline
+// ------------------------------------------------------------------------------------------------
+struct CodecWS {
+    int cap_frames = 0;
+    float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr, *bufE = nullptr;
+    float *cs = nullptr, *sn = nullptr;
+    uint32_t* frames = nullptr; float* pcm = nullptr;
+    void release() {
+        hipFree(bufA); hipFree(bufB); hipFree(bufC); hipFree(bufD); hipFree(bufE); hipFree(cs); hipFree(sn); hipFree(frames); hipFree(pcm);
+        bufA = bufB = bufC = bufD = bufE = cs = sn = pcm = nullptr; frames = nullptr; cap_frames = 0;
+    }
+};
+
+static q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T) {
+    if (T <= ws.cap_frames) return Q3_OK;
+    ws.release();
+    const q3_config& c = m->cfg;
+    int up = 1; for (int i = 0; i < 2; ++i) up *= c.dec_up_ratios[i];
+    // largest [C][L] activation per frame
+    size_t per = (size_t)4 * c.dec_latent * up;                 // ConvNeXt hidden 4*LAT × (T*up)
+    { size_t L = up; int C = c.dec_dim; per = per > (size_t)C * L ? per : (size_t)C * L;
+      for (int b = 0; b < 4; ++b) { L *= c.dec_up_rates[b]; C /= 2; if ((size_t)C * L > per) per = (size_t)C * L; } }
+    const size_t n = per * (size_t)T;
+    HIPC(hipMalloc((void**)&ws.bufA, n * 4)); HIPC(hipMalloc((void**)&ws.bufB, n * 4)); HIPC(hipMalloc((void**)&ws.bufC, n * 4));
+    const size_t small = (size_t)T * (size_t)(c.dec_heads * c.dec_head_dim > c.dec_latent ? c.dec_heads * c.dec_head_dim : c.dec_latent);
+    HIPC(hipMalloc((void**)&ws.bufD, small * 4)); HIPC(hipMalloc((void**)&ws.bufE, small * 4));
+    HIPC(hipMalloc((void**)&ws.cs, (size_t)T * 32 * 4)); HIPC(hipMalloc((void**)&ws.sn, (size_t)T * 32 * 4));
+    HIPC(hipMalloc((void**)&ws.frames, (size_t)T * 16 * 4));
+    size_t total_up = up; for (int b = 0; b < 4; ++b) total_up *= c.dec_up_rates[b];
+    HIPC(hipMalloc((void**)&ws.pcm, (size_t)T * total_up * 4));
+    // RoPE table of the pre-transformer (decoder_12hz.rs:541-553), host libm
+    std::vector<float> cs((size_t)T * 32), sn((size_t)T * 32);
+    for (int i = 0; i < 32; ++i) {
+        const float inv = 1.0f / powf(c.dec_theta, (float)(2 * i) / (float)c.dec_head_dim);
+        for (int t = 0; t < T; ++t) { const float f = (float)t * inv; cs[(size_t)t * 32 + i] = cosf(f); sn[(size_t)t * 32 + i] = sinf(f); }
+    }
+    HIPC(hipMemcpy(ws.cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ws.sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    ws.cap_frames = T;
+    return Q3_OK;
+}
+
+static int samples_per_frame(const q3_config& c) {
+    int u = 1; for (int i = 0; i < 2; ++i) u *= c.dec_up_ratios[i]; for (int i = 0; i < 4; ++i) u *= c.dec_up_rates[i];
+    return u;
+}
+
+static hipError_t conv1(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L, hipStream_t st,
+                        const float* resid = nullptr, const float* scale = nullptr, int act = 0,
+                        const float* sa = nullptr, const float* sib = nullptr) {
+    ConvArgs a; a.x = x; a.w = w; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = 1; a.dil = 1;
+    a.resid = resid; a.scale = scale; a.act = act; a.snake_a = sa; a.snake_b = sib;
+    return launch_conv1d(a, st);
+}
+static hipError_t convk(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L, int k, int dil,
+                        hipStream_t st, const float* sa = nullptr, const float* sib = nullptr, int act = 0) {
+    ConvArgs a; a.x = x; a.w = w; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = k; a.dil = dil;
+    a.snake_a = sa; a.snake_b = sib; a.act = act;
+    return launch_conv1d(a, st);
+}
+
+// frames already on device in ws.frames; result in ws.pcm ([T*spf]). taps: host pointers or nullptr.
+static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStream_t st, float** taps) {
+    const q3_config& c = m->cfg;
+    const int CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden, QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
+    auto TAP = [&](int id, const float* dev, size_t n) -> q3_status {
+        if (taps && taps[id]) { HIPC(hipStreamSynchronize(st)); HIPC(hipMemcpy(taps[id], dev, n * 4, hipMemcpyDeviceToHost)); }
+        return Q3_OK;
+    };
+    float *A = ws.bufA, *B = ws.bufB, *C = ws.bufC, *D = ws.bufD, *E = ws.bufE;
+    // D1 quantiser: E1 = A[0..256T), E2 = A[256T..512T) → quantized in B [Q][T]
+    float* e1 = A; float* e2 = A + (size_t)CD * T;
+    HIPC(launch_rvq_embed(ws.frames, T, m->first_cb, m->rest_cbs_dev, e1, e2, CD, c.dec_cb_size, st));
+    HIPC(conv1(e1, m->first_proj, nullptr, B, CD, Q, T, st));
+    HIPC(conv1(e2, m->rest_proj, nullptr, B, CD, Q, T, st, B));
+    Q3C(TAP(Q3_DEC_QUANT, B, (size_t)Q * T));
+    // D2 pre_conv → C [LAT][T]
+    HIPC(convk(B, m->pre_w, m->pre_b, C, Q, LAT, T, 3, 1, st));
+    Q3C(TAP(Q3_DEC_PRECONV, C, (size_t)LAT * T));
+    // D3 pre-transformer. hidden Hd = D [DH][T]
+    float* Hd = D;
+    HIPC(conv1(C, m->inp_w, m->inp_b, Hd, LAT, DH, T, st));
+    float* Nn = E;                                   // [DH][T]
+    float* q = A; float* k = A + (size_t)QD * T; float* v = A + (size_t)2 * QD * T; float* ao = A + (size_t)3 * QD * T;
+    float* g = B; float* u = B + (size_t)DI * T;
+    const float scale = (float)pow((double)c.dec_head_dim, -0.5);
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const DecLayerW& L = m->dl[l];
+        HIPC(launch_rmsnorm_c(Hd, L.in_ln, Nn, DH, T, c.dec_eps, st));
+        HIPC(conv1(Nn, L.q, nullptr, q, DH, QD, T, st));
+        HIPC(conv1(Nn, L.k, nullptr, k, DH, QD, T, st));
+        HIPC(conv1(Nn, L.v, nullptr, v, DH, QD, T, st));
+        HIPC(launch_rope_c(q, k, ws.cs, ws.sn, c.dec_heads, c.dec_head_dim, T, st));
+        HIPC(launch_attn_c(q, k, v, ao, c.dec_heads, c.dec_head_dim, T, scale, st));
+        HIPC(conv1(ao, L.o, nullptr, Hd, QD, DH, T, st, Hd, L.attn_scale));
+        HIPC(launch_rmsnorm_c(Hd, L.post_ln, Nn, DH, T, c.dec_eps, st));
+        HIPC(conv1(Nn, L.gate, nullptr, g, DH, DI, T, st));
+        HIPC(conv1(Nn, L.up, nullptr, u, DH, DI, T, st));
+        HIPC(launch_silu_mul(g, u, g, (int64_t)DI * T, st));
+        HIPC(conv1(g, L.down, nullptr, Hd, DI, DH, T, st, Hd, L.mlp_scale));
+    }
+    HIPC(launch_rmsnorm_c(Hd, m->dec_norm, Nn, DH, T, c.dec_eps, st));
+    HIPC(conv1(Nn, m->outp_w, m->outp_b, C, DH, LAT, T, st));      // C [LAT][T]
+    Q3C(TAP(Q3_DEC_PRETRANS, C, (size_t)LAT * T));
+    // D4 upsample stages: cur in C
+    float* cur = C; float* o1 = A; float* o2 = B;
+    int L = T;
+    for (int i = 0; i < 2; ++i) {
+        const UpW& U = m->up[i];
+        float* upo = (cur == C) ? A : C;            // transconv output [LAT][L*r]
+        HIPC(launch_transconv1d_taps(cur, U.tw, U.tb, upo, LAT, LAT, L, U.ratio, 1, nullptr, nullptr, st));
+        L *= U.ratio;
+        // dwconv → LN → pw1+GELU → pw2·gamma + residual (in place into upo)
+        float* dw = (upo == A) ? C : A;             // [LAT][L]
+        HIPC(launch_dwconv7(upo, U.dww, U.dwb, dw, LAT, L, st));
+        float* ln = dw + (size_t)LAT * L;           // second half of that buffer
+        HIPC(launch_layernorm_c(dw, U.nw, U.nb, ln, LAT, L, 1e-6f, st));
+        HIPC(conv1(ln, U.p1w, U.p1b, B, LAT, 4 * LAT, L, st, nullptr, nullptr, 1));
+        HIPC(conv1(B, U.p2w, U.p2b, upo, 4 * LAT, LAT, L, st, upo, U.gamma));
+        cur = upo;
+        Q3C(TAP(Q3_DEC_UP0 + i, cur, (size_t)LAT * L));
+    }
+    (void)o1; (void)o2;
+    // D5 decoder.0: → x in (other buffer)
+    int Cc = c.dec_dim;
+    float* x = (cur == A) ? B : A;
+    HIPC(convk(cur, m->init_w, m->init_b, x, LAT, Cc, L, 7, 1, st));
+    Q3C(TAP(Q3_DEC_INIT, x, (size_t)Cc * L));
+    // D6 decoder blocks
+    static const int dils[3] = {1, 3, 9};
+    for (int b = 0; b < 4; ++b) {
+        const DecBlockW& Bk = m->blk[b];
+        float* y = (x == A) ? B : A;
+        HIPC(launch_transconv1d_taps(x, Bk.tw, Bk.tb, y, Bk.cin, Bk.cout, L, Bk.rate, 2, Bk.a, Bk.ib, st));
+        L *= Bk.rate; Cc = Bk.cout;
+        float* t2 = C;
+        for (int uu = 0; uu < 3; ++uu) {
+            const ResUnitW& R = Bk.res[uu];
+            HIPC(convk(y, R.c1w, R.c1b, t2, Cc, Cc, L, 7, dils[uu], st, R.a1, R.ib1));
+            HIPC(conv1(t2, R.c2w, R.c2b, y, Cc, Cc, L, st, y, nullptr, 0, R.a2, R.ib2));
+        }
+        x = y;
+        Q3C(TAP(Q3_DEC_BLK0 + b, x, (size_t)Cc * L));
+    }
+    // D9 final snake + conv + clamp
+    HIPC(convk(x, m->fin_w, m->fin_b, ws.pcm, Cc, 1, L, 7, 1, st, m->fin_a, m->fin_ib, 2));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_decode_codes(q3_model* m, const uint32_t* frames_host, int n_frames, float* pcm_host, float** taps_host) {
+    if (!m || !m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
+    if (n_frames < 0 || (n_frames > 0 && (!frames_host || !pcm_host))) return set_err(Q3_INVALID_ARG, "q3_decode_codes: bad argument");
+    if (n_frames == 0) return Q3_OK;
+    for (int f = 0; f < n_frames; ++f)
+        for (int g = 1; g < 16; ++g)
+            if (frames_host[(size_t)f * 16 + g] >= (uint32_t)m->cfg.dec_cb_size)
+                return set_err(Q3_INVALID_ARG, "code %u out of range for codebook %d (frame %d)", frames_host[(size_t)f * 16 + g], g, f);
+    HIPC(hipSetDevice(m->device));
+    CodecWS ws;
+    q3_status st = codec_reserve(m, ws, n_frames);
+    if (st == Q3_OK) {
+        hipError_t e = hipMemcpy(ws.frames, frames_host, (size_t)n_frames * 16 * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "hipMemcpy frames: %s", hipGetErrorString(e));
+    }
+    if (st == Q3_OK) st = codec_decode_dev(m, ws, n_frames, 0, taps_host);
+    if (st == Q3_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(pcm_host, ws.pcm, (size_t)n_frames * samples_per_frame(m->cfg) * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "decode: %s", hipGetErrorString(e));
+    }
+    ws.release();
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// session
+// ------------------------------------------------------------------------------------------------
+struct LmBuf { float *X, *SUM, *QKV, *Q, *ATT, *ACT, *PART; };
+struct LmDims { int H, I, nh, nkv, layers; float eps; };
+
+struct SeqInfo {
+    q3_request req; std::vector<uint32_t> text, instruct; std::vector<float> xvec;
+    int prefill_len = 0, trailing_len = 0, row_base = 0, n_rows = 0, trail_base = 0, pad_row = 0;
+    int n_frames = 0; bool done = false;
+};
+
+struct ProfAcc { double ms = 0; double bytes = 0; long launches = 0; };
+
+struct q3_session {
+    q3_model* m = nullptr; int B = 0;
+    hipStream_t stream = nullptr;
+    DevPool pool;
+    std::vector<SeqInfo> seq;
+    q3_options opts{};
+    int max_frames = 0, max_seq = 0, prefill_len = 0, n_splits = 1;
+    LmBuf tb{}, cb{};
+    float *LASTH = nullptr, *LOGITS = nullptr, *CP_IN = nullptr, *CP_LOGITS = nullptr;
+    float *kcache = nullptr, *vcache = nullptr, *ckcache = nullptr, *cvcache = nullptr;
+    size_t kv_layer_stride = 0, ckv_layer_stride = 0;
+    float *rows = nullptr, *embeds = nullptr, *xvec = nullptr; int n_rows_total = 0;
+    int *trail_base = nullptr, *trail_len = nullptr, *pad_row = nullptr;
+    uint32_t* tok = nullptr; uint8_t* seen = nullptr; int *frame_idx = nullptr, *pos = nullptr, *token_count = nullptr;
+    float* U = nullptr; uint32_t* codes = nullptr;
+    float* logits_hist = nullptr; float* cp_logits_hist = nullptr; bool debug = false;
+    bool prefilled = false; int frames_run = 0;
+    hipGraphExec_t graph_exec = nullptr; hipGraph_t graph = nullptr;
+    CodecWS cws;
+    std::vector<uint32_t> codes_host; bool codes_host_valid = false;
+    int stream_pos = 0;    // streaming: frames already decoded
+    bool profile = false; ProfAcc prof_linear;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
+};
+
+static hipError_t run_linear(q3_session* s, const LinArgs& a) {
+    if (!s->profile) return launch_linear(a, s->stream);
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0); if (e != hipSuccess) return e;
+    e = hipEventCreate(&e1); if (e != hipSuccess) return e;
+    hipEventRecord(e0, s->stream);
+    e = launch_linear(a, s->stream);
+    hipEventRecord(e1, s->stream);
+    s->prof_events.push_back({e0, e1});
+    s->prof_event_bytes.push_back((double)a.N * a.K * 2.0 * (a.epi == EPI_SWIGLU ? 2.0 : 1.0));
+    return e;
+}
+
+// one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
+static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf& b, float* kc, float* vc, int max_seq,
+                          const int* pos_dev, int pos_static, int n_splits) {
+    const q3_model* m = s->m;
+    const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, B = s->B;
+    LinArgs a;
+    a.W = w.qkv; a.N = QD + 2 * KD; a.K = d.H; a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
+    a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE;
+    HIPC(run_linear(s, a));
+    AttnArgs t{};
+    t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
+    t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
+    t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
+    t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits;
+    HIPC(launch_qknorm_rope_kv(t, s->stream));
+    HIPC(launch_attn_decode(t, s->stream));
+    HIPC(launch_attn_merge(t, s->stream));
+    LinArgs o;
+    o.W = w.o; o.N = d.H; o.K = QD; o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID;
+    HIPC(run_linear(s, o));
+    LinArgs g;
+    g.W = w.gate; g.W2 = w.up; g.N = d.I; g.K = d.H; g.x = b.SUM; g.ldx = d.H; g.norm_w = w.post_ln; g.eps = d.eps;
+    g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU;
+    HIPC(run_linear(s, g));
+    LinArgs dn;
+    dn.W = w.down; dn.N = d.H; dn.K = d.I; dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID;
+    HIPC(run_linear(s, dn));
+    return Q3_OK;
+}
+
+static LmDims talker_dims(const q3_config& c) { return LmDims{c.hidden, c.inter, c.n_heads, c.n_kv_heads, c.n_layers, c.rms_eps}; }
+static LmDims cp_dims(const q3_config& c) { return LmDims{c.cp_hidden, c.cp_inter, c.cp_heads, c.cp_kv_heads, c.cp_layers, c.rms_eps}; }
+
+// talker layers on the contents of tb.X at position pos (device array or static); with_head: final
+// norm → LASTH and codec_head → LOGITS (talker.rs:716-736)
+static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, bool with_head) {
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    const LmDims d = talker_dims(c);
+    for (int i = 0; i < c.n_layers; ++i)
+        Q3C(lm_layer(s, d, m->tl[i], s->tb, s->kcache + (size_t)i * s->kv_layer_stride, s->vcache + (size_t)i * s->kv_layer_stride,
+                     s->max_seq, pos_dev, pos_static, s->n_splits));
+    if (with_head) {
+        HIPC(launch_rmsnorm(s->tb.X, c.hidden, m->norm, s->LASTH, c.hidden, s->B, c.hidden, c.rms_eps, s->stream));
+        LinArgs h;
+        h.W = m->codec_head; h.N = c.codec_vocab; h.K = c.hidden; h.x = s->LASTH; h.ldx = c.hidden; h.y = s->LOGITS; h.ldy = c.codec_vocab;
+        h.M = s->B; h.epi = EPI_NONE;
+        HIPC(run_linear(s, h));
+    }
+    return Q3_OK;
+}
+
+// generate_acoustic_codes (code_predictor.rs:320-416) as 16 single-token passes: pass 0 = talker
+// hidden (pos 0), pass 1 = semantic embedding (pos 1) → lm_head[0]; pass p = embedding of code p-2
+// (pos p) → lm_head[p-1]. (The reference runs passes 0 and 1 as one 2-token causal prefill; for
+// causal attention that is the same computation.) Codes 0..13 are recorded by the next pass's
+// gather, code 14 by frame_embed / the caller.
+static q3_status cp_run(q3_session* s) {
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    const LmDims d = cp_dims(c);
+    const int H = c.hidden, CH = c.cp_hidden, V = c.cp_vocab, B = s->B;
+    const int n_pass = c.n_groups;   // 16
+    for (int p = 0; p < n_pass; ++p) {
+        CpGatherArgs g{};
+        g.pass = p; g.last_hidden = s->LASTH; g.H = H; g.codec_emb = m->codec_emb; g.tok = s->tok;
+        g.cp_emb = p >= 2 ? m->cp_emb[p - 2] : nullptr;
+        g.cp_logits = p >= 2 ? s->CP_LOGITS + (size_t)(p - 2) * B * V : nullptr;
+        g.cp_vocab = V; g.codes = s->codes; g.frame_idx = s->frame_idx; g.max_frames = s->max_frames; g.B = B;
+        if (m->mtp_w) { g.out = s->CP_IN; g.ld_out = H; } else { g.out = s->cb.X; g.ld_out = CH; }
+        HIPC(launch_cp_gather(g, s->stream));
+        if (m->mtp_w) {
+            LinArgs a;
+            a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
+            HIPC(run_linear(s, a));
+        }
+        for (int i = 0; i < c.cp_layers; ++i)
+            Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,
+                         n_pass + 1, nullptr, p, 1));
+        if (p >= 1) {
+            LinArgs h;
+            h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
+            h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
+            HIPC(run_linear(s, h));
+        }
+    }
+    return Q3_OK;
+}
+
+static void fill_sample_args(q3_session* s, SampleArgs& a) {
+    const q3_options& o = s->opts; const q3_config& c = s->m->cfg;
+    memset(&a, 0, sizeof a);
+    a.logits = s->LOGITS; a.ld = c.codec_vocab; a.seen = s->seen; a.u = s->U; a.u_stride = s->max_frames + 1;
+    a.draw_idx = s->token_count; a.tok = s->tok; a.token_count = s->token_count; a.frame_idx = s->frame_idx; a.pos = s->pos;
+    a.vocab = c.codec_vocab; a.B = s->B;
+    a.apply_temp = (o.temperature != 1.0 && o.temperature > 0.0) ? 1 : 0;
+    a.inv_temp = (float)(1.0 / o.temperature);
+    a.greedy = o.temperature < 0.01 ? 1 : 0;
+    a.top_k = o.top_k; a.use_top_p = (o.top_p < 1.0 && o.top_p > 0.0) ? 1 : 0; a.top_p = (float)o.top_p;
+    a.use_rep = (o.repetition_penalty != 1.0 && !(fabs(o.repetition_penalty - 1.0) < 1e-9)) ? 1 : 0;
+    a.rep_pen = (float)o.repetition_penalty; a.rep_inv = 1.0f / (float)o.repetition_penalty;
+    a.eos_id = o.eos_token_id; a.min_new_tokens = o.min_new_tokens; a.codec_eos = CODEC_EOS; a.use_suppress = 1;
+    if (s->debug && s->logits_hist) { a.logits_hist = s->logits_hist; a.hist_stride_b = (s->max_frames + 1) * c.codec_vocab; a.hist_cap = s->max_frames + 1; }
+}
+
+// one frame of generate_codes (lib.rs:580-652)
+static q3_status frame_launch(q3_session* s) {
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    Q3C(cp_run(s));
+    FrameEmbedArgs f{};
+    f.codec_emb = m->codec_emb; f.cp_embs = m->cp_embs_dev; f.tok = s->tok;
+    f.cp_logits_last = s->CP_LOGITS + (size_t)14 * s->B * c.cp_vocab; f.cp_vocab = c.cp_vocab;
+    f.codes = s->codes; f.frame_idx = s->frame_idx; f.max_frames = s->max_frames;
+    f.text_rows = s->rows; f.trail_base = s->trail_base; f.trail_len = s->trail_len; f.pad_row = s->pad_row;
+    f.out = s->tb.X; f.H = c.hidden; f.B = s->B; f.n_acoustic = c.n_groups - 1;
+    HIPC(launch_frame_embed(f, s->stream));
+    if (s->debug && s->cp_logits_hist) {
+        // capture is host-indexed: only valid outside graph replay (debug sessions never use graphs)
+        HIPC(hipMemcpyAsync(s->cp_logits_hist + (size_t)s->frames_run * 15 * s->B * c.cp_vocab, s->CP_LOGITS,
+                            (size_t)15 * s->B * c.cp_vocab * 4, hipMemcpyDeviceToDevice, s->stream));
+    }
+    Q3C(talker_step(s, s->pos, 0, true));
+    SampleArgs a; fill_sample_args(s, a); a.advance = 1;
+    HIPC(launch_sample(a, s->stream));
+    return Q3_OK;
+}
+
+static bool opts_equal_sampling(const q3_options& a, const q3_options& b) {
+    return a.temperature == b.temperature && a.top_p == b.top_p && a.repetition_penalty == b.repetition_penalty &&
+           a.max_length == b.max_length && a.top_k == b.top_k && a.eos_token_id == b.eos_token_id &&
+           a.min_new_tokens == b.min_new_tokens && a.chunk_frames == b.chunk_frames;
+}
+
+extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out) {
+    if (!m || !reqs || !out) return set_err(Q3_INVALID_ARG, "q3_session_create: null argument");
+    if (!m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
+    if (batch < 1 || batch > 8) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..8 per GPU)", batch);
+    HIPC(hipSetDevice(m->device));
+    const q3_config& c = m->cfg;
+    std::unique_ptr<q3_session> s(new q3_session());
+    s->m = m; s->B = batch; s->opts = reqs[0].opts;
+    if (s->opts.max_length < 1) return set_err(Q3_INVALID_ARG, "max_length must be >= 1");
+    s->seq.resize(batch);
+    int rows = 0;
+    for (int b = 0; b < batch; ++b) {
+        const q3_request& r = reqs[b];
+        if (!opts_equal_sampling(r.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "all requests of a batch must share sampling options (seed may differ)");
+        if (r.mode < 0 || r.mode > 2) return set_err(Q3_INVALID_ARG, "bad mode %d", r.mode);
+        if (r.n_text < 0 || r.n_instruct < 0 || (r.n_text > 0 && !r.text_ids) || (r.n_instruct > 0 && !r.instruct_ids))
+            return set_err(Q3_INVALID_ARG, "bad token id arrays");
+        if (r.mode == Q3_MODE_VOICE_CLONE && !r.xvector) return set_err(Q3_INVALID_ARG, "voice clone needs an x-vector");
+        SeqInfo& q = s->seq[b];
+        q.req = r;
+        q.text.assign(r.text_ids, r.text_ids + r.n_text);
+        for (uint32_t id : q.text) if (id >= (uint32_t)c.text_vocab) return set_err(Q3_INVALID_ARG, "text id %u out of range", id);
+        if (r.mode == Q3_MODE_VOICE_DESIGN) q.instruct.assign(r.instruct_ids, r.instruct_ids + r.n_instruct);
+        for (uint32_t id : q.instruct) if (id >= (uint32_t)c.text_vocab) return set_err(Q3_INVALID_ARG, "instruct id %u out of range", id);
+        if (r.language_id >= (uint32_t)c.codec_vocab || (r.mode == Q3_MODE_CUSTOM_VOICE && r.speaker_id >= (uint32_t)c.codec_vocab))
+            return set_err(Q3_INVALID_ARG, "speaker/language id out of range");
+        if (r.xvector) q.xvec.assign(r.xvector, r.xvector + c.hidden);
+        const int n_ins = (int)q.instruct.size();
+        const int overlay = r.mode == Q3_MODE_VOICE_DESIGN ? 5 : 6;
+        q.prefill_len = n_ins + 3 + overlay + (r.n_text > 0 ? 1 : 0);
+        q.trailing_len = (r.n_text > 1 ? r.n_text - 1 : 0) + 1;
+        q.row_base = rows;
+        q.n_rows = n_ins + 5 + r.n_text + 1;     // instruct, role×3, pad, bos, text…, eos
+        rows += q.n_rows;
+        if (q.prefill_len != s->seq[0].prefill_len)
+            return set_err(Q3_UNSUPPORTED, "all sequences of a batch must have the same prefill length (%d vs %d)", q.prefill_len, s->seq[0].prefill_len);
+    }
+    s->prefill_len = s->seq[0].prefill_len;
+    s->n_rows_total = rows;
+    s->max_frames = s->opts.max_length;
+    // KV sized for what the path needs (prefill + frames), not the reference's max_new_tokens+256 (lib.rs:450)
+    s->max_seq = s->prefill_len + s->max_frames + 1;
+    if (s->max_seq > m->rope_len) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds the RoPE table (%d)", s->max_seq, m->rope_len);
+    { int ns = 256 / (batch * c.n_kv_heads); if (ns < 1) ns = 1; if (ns > MAX_SPLITS) ns = MAX_SPLITS; s->n_splits = ns; }
+    HIPC(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const int B = batch, H = c.hidden, CH = c.cp_hidden;
+    auto alloc_lm = [&](LmBuf& b, const LmDims& d, int nsplit) -> hipError_t {
+        const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM;
+        hipError_t e;
+        if ((e = s->pool.alloc(&b.X, (size_t)B * d.H)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.SUM, (size_t)B * d.H)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.QKV, (size_t)B * (QD + 2 * KD))) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.Q, (size_t)B * QD)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.ATT, (size_t)B * QD)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.ACT, (size_t)B * d.I)) != hipSuccess) return e;
+        return s->pool.alloc(&b.PART, (size_t)B * d.nh * nsplit * PART_STRIDE);
+    };
+    HIPC(alloc_lm(s->tb, talker_dims(c), s->n_splits));
+    HIPC(alloc_lm(s->cb, cp_dims(c), 1));
+    HIPC(s->pool.alloc(&s->LASTH, (size_t)B * H));
+    HIPC(s->pool.alloc(&s->LOGITS, (size_t)B * c.codec_vocab));
+    HIPC(s->pool.alloc(&s->CP_IN, (size_t)B * H));
+    HIPC(s->pool.alloc(&s->CP_LOGITS, (size_t)15 * B * c.cp_vocab));
+    s->kv_layer_stride = (size_t)B * c.n_kv_heads * s->max_seq * HEAD_DIM;
+    HIPC(s->pool.alloc(&s->kcache, s->kv_layer_stride * c.n_layers));
+    HIPC(s->pool.alloc(&s->vcache, s->kv_layer_stride * c.n_layers));
+    s->ckv_layer_stride = (size_t)B * c.cp_kv_heads * (c.n_groups + 1) * HEAD_DIM;
+    HIPC(s->pool.alloc(&s->ckcache, s->ckv_layer_stride * c.cp_layers));
+    HIPC(s->pool.alloc(&s->cvcache, s->ckv_layer_stride * c.cp_layers));
+    HIPC(s->pool.alloc(&s->rows, (size_t)rows * H));
+    HIPC(s->pool.alloc(&s->embeds, (size_t)B * s->prefill_len * H));
+    HIPC(s->pool.alloc(&s->xvec, (size_t)B * H));
+    HIPC(s->pool.alloc(&s->trail_base, B)); HIPC(s->pool.alloc(&s->trail_len, B)); HIPC(s->pool.alloc(&s->pad_row, B));
+    HIPC(s->pool.alloc(&s->tok, B)); HIPC(s->pool.alloc(&s->seen, (size_t)B * c.codec_vocab));
+    HIPC(s->pool.alloc(&s->frame_idx, B)); HIPC(s->pool.alloc(&s->pos, B)); HIPC(s->pool.alloc(&s->token_count, B));
+    HIPC(s->pool.alloc(&s->U, (size_t)B * (s->max_frames + 1)));
+    HIPC(s->pool.alloc(&s->codes, (size_t)B * s->max_frames * 16));
+    // RNG: one PCG stream per sequence, one draw per sampled token
+    std::vector<float> U((size_t)B * (s->max_frames + 1));
+    for (int b = 0; b < B; ++b) {
+        uint64_t st;
+        const q3_options& o = reqs[b].opts;
+        uint64_t seed = o.seed;
+        if (!o.has_seed) seed = (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count() + 0x9E37ULL * b;
+        q3_rng_seed(seed, &st);
+        for (int i = 0; i <= s->max_frames; ++i) U[(size_t)b * (s->max_frames + 1) + i] = q3_rng_next(&st);
+    }
+    HIPC(hipMemcpy(s->U, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+    *out = s.release();
+    return Q3_OK;
+}
+
+extern "C" void q3_session_free(q3_session* s) {
+    if (!s) return;
+    hipSetDevice(s->m->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) hipGraphDestroy(s->graph);
+    for (auto& p : s->prof_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    s->cws.release();
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" q3_status q3_session_set_debug(q3_session* s, int capture) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (s->prefilled) return set_err(Q3_INVALID_ARG, "set_debug must be called before prefill");
+    s->debug = capture != 0;
+    if (s->debug && !s->logits_hist) {
+        const q3_config& c = s->m->cfg;
+        HIPC(hipSetDevice(s->m->device));
+        HIPC(s->pool.alloc(&s->logits_hist, (size_t)s->B * (s->max_frames + 1) * c.codec_vocab));
+        HIPC(s->pool.alloc(&s->cp_logits_hist, (size_t)s->max_frames * 15 * s->B * c.cp_vocab));
+    }
+    return Q3_OK;
+}
+extern "C" q3_status q3_session_set_profile(q3_session* s, int enable) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    s->profile = enable != 0;
+    return Q3_OK;
+}
+extern "C" q3_status q3_session_stream(q3_session* s, void** stream) {
+    if (!s || !stream) return set_err(Q3_INVALID_ARG, "null argument");
+    *stream = (void*)s->stream;
+    return Q3_OK;
+}
+extern "C" q3_status q3_session_prefill_len(q3_session* s, int b, int* prefill_len, int* trailing_len) {
+    if (!s || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad sequence index");
+    if (prefill_len) *prefill_len = s->seq[b].prefill_len;
+    if (trailing_len) *trailing_len = s->seq[b].trailing_len;
+    return Q3_OK;
+}
+
+// text projection (talker.rs:316-320) of `n` gathered rows: fc2(silu(fc1(e)+b1))+b2, 8 rows a time
+static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, float* out_rows) {
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    const int TD = c.text_dim, H = c.hidden;
+    float *e = nullptr, *h = nullptr;
+    HIPC(hipMalloc((void**)&e, (size_t)n * TD * 4)); HIPC(hipMalloc((void**)&h, (size_t)n * TD * 4));
+    q3_status st = Q3_OK;
+    hipError_t er = launch_gather_rows_bf16(m->text_emb, ids_dev, e, n, TD, s->stream);
+    for (int r0 = 0; r0 < n && er == hipSuccess; r0 += 8) {
+        const int M = (n - r0) < 8 ? (n - r0) : 8;
+        LinArgs a;
+        a.W = m->fc1w; a.N = TD; a.K = TD; a.x = e + (size_t)r0 * TD; a.ldx = TD; a.bias = m->fc1b; a.y = h + (size_t)r0 * TD; a.ldy = TD; a.M = M; a.epi = EPI_SILU;
+        er = launch_linear(a, s->stream);
+        if (er != hipSuccess) break;
+        LinArgs b2;
+        b2.W = m->fc2w; b2.N = H; b2.K = TD; b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE;
+        er = launch_linear(b2, s->stream);
+    }
+    if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
+    if (er != hipSuccess) st = set_err(Q3_HIP_ERROR, "text projection: %s", hipGetErrorString(er));
+    hipFree(e); hipFree(h);
+    return st;
+}
+
+extern "C" q3_status q3_session_prefill(q3_session* s) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (s->prefilled) return set_err(Q3_INVALID_ARG, "session already prefilled");
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    HIPC(hipSetDevice(m->device));
+    const int B = s->B, H = c.hidden, S = s->prefill_len;
+    // 1. ids to project, per sequence: [instruct…, IM_START, ASSISTANT, NEWLINE, TTS_PAD, TTS_BOS, text…, TTS_EOS]
+    std::vector<uint32_t> ids; ids.reserve(s->n_rows_total);
+    std::vector<int> text_row((size_t)B * S, -1), codec_id((size_t)B * S, -1);
+    std::vector<int> trail_base(B), trail_len(B), pad_row(B);
+    std::vector<float> xv((size_t)B * H, 0.0f);
+    for (int b = 0; b < B; ++b) {
+        SeqInfo& q = s->seq[b];
+        const int n_ins = (int)q.instruct.size(), n_text = (int)q.text.size(), base = q.row_base;
+        for (uint32_t id : q.instruct) ids.push_back(id);
+        ids.push_back(IM_START); ids.push_back(ASSISTANT); ids.push_back(NEWLINE); ids.push_back(TTS_PAD); ids.push_back(TTS_BOS);
+        for (uint32_t id : q.text) ids.push_back(id);
+        ids.push_back(TTS_EOS);
+        const int r_role = base + n_ins, r_pad = r_role + 3, r_bos = r_pad + 1, r_text = r_bos + 1, r_eos = r_text + n_text;
+        q.pad_row = r_pad;
+        q.trail_base = n_text > 1 ? r_text + 1 : r_eos;          // build_trailing_text (lib.rs:508-519)
+        trail_base[b] = q.trail_base; trail_len[b] = q.trailing_len; pad_row[b] = q.pad_row;
+        // prefill positions (talker.rs:451-491 / 511-564 / 585-627)
+        int* tr = &text_row[(size_t)b * S]; int* ci = &codec_id[(size_t)b * S];
+        int p = 0;
+        for (int i = 0; i < n_ins; ++i) tr[p++] = base + i;
+        for (int i = 0; i < 3; ++i) tr[p++] = r_role + i;
+        const bool vd = q.req.mode == Q3_MODE_VOICE_DESIGN;
+        int codec[7]; int nc;
+        if (vd) { int t[6] = {CODEC_THINK, CODEC_THINK_BOS, (int)q.req.language_id, CODEC_THINK_EOS, CODEC_PAD, CODEC_BOS}; memcpy(codec, t, sizeof t); nc = 6; }
+        else { int t[7] = {CODEC_THINK, CODEC_THINK_BOS, (int)q.req.language_id, CODEC_THINK_EOS, (int)q.req.speaker_id, CODEC_PAD, CODEC_BOS}; memcpy(codec, t, sizeof t); nc = 7; }
+        const int overlay = nc - 1;
+        for (int i = 0; i < overlay; ++i) {
+            tr[p] = (i == overlay - 1) ? r_bos : r_pad;
+            ci[p] = (q.req.mode == Q3_MODE_VOICE_CLONE && i == 4) ? -2 : codec[i];
+            ++p;
+        }
+        if (n_text > 0) { tr[p] = r_text; ci[p] = codec[nc - 1]; ++p; }
+        if (!q.xvec.empty()) memcpy(&xv[(size_t)b * H], q.xvec.data(), (size_t)H * 4);
+    }
+    uint32_t* ids_dev = nullptr; int *tr_dev = nullptr, *ci_dev = nullptr;
+    HIPC(hipMalloc((void**)&ids_dev, ids.size() * 4));
+    HIPC(hipMalloc((void**)&tr_dev, text_row.size() * 4)); HIPC(hipMalloc((void**)&ci_dev, codec_id.size() * 4));
+    HIPC(hipMemcpy(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(tr_dev, text_row.data(), text_row.size() * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ci_dev, codec_id.data(), codec_id.size() * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(s->xvec, xv.data(), xv.size() * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(s->trail_base, trail_base.data(), B * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(s->trail_len, trail_len.data(), B * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(s->pad_row, pad_row.data(), B * 4, hipMemcpyHostToDevice));
+    q3_status st = text_project(s, ids_dev, (int)ids.size(), s->rows);
+    if (st == Q3_OK) {
+        hipError_t e = hipSuccess;
+        for (int b = 0; b < B && e == hipSuccess; ++b)
+            e = launch_assemble_rows(s->rows, tr_dev + (size_t)b * S, m->codec_emb, ci_dev + (size_t)b * S, s->xvec + (size_t)b * H,
+                                     s->embeds + (size_t)b * S * H, S, H, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "prefill assembly: %s", hipGetErrorString(e));
+    }
+    hipFree(ids_dev); hipFree(tr_dev); hipFree(ci_dev);
+    Q3C(st);
+    // 2. run_prefill_layers (talker.rs:823-841): causal attention ⇒ token-by-token decode steps
+    for (int t = 0; t < S; ++t) {
+        HIPC(launch_copy_rows(s->embeds + (size_t)t * H, S * H, s->tb.X, H, B, H, s->stream));
+        Q3C(talker_step(s, nullptr, t, t == S - 1));
+    }
+    // 3. first sampling decision (lib.rs:558-571)
+    std::vector<int> posv(B, S), zero(B, 0);
+    HIPC(hipMemcpyAsync(s->pos, posv.data(), B * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->frame_idx, zero.data(), B * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->token_count, zero.data(), B * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipStreamSynchronize(s->stream));
+    SampleArgs a; fill_sample_args(s, a); a.advance = 0;
+    HIPC(launch_sample(a, s->stream));
+    HIPC(hipStreamSynchronize(s->stream));
+    s->prefilled = true; s->frames_run = 0; s->codes_host_valid = false;
+    return Q3_OK;
+}
+
+static q3_status refresh_codes(q3_session* s) {
+    if (s->codes_host_valid) return Q3_OK;
+    HIPC(hipStreamSynchronize(s->stream));
+    s->codes_host.resize((size_t)s->B * s->max_frames * 16);
+    if (s->frames_run > 0)
+        for (int b = 0; b < s->B; ++b)
+            HIPC(hipMemcpy(&s->codes_host[(size_t)b * s->max_frames * 16], s->codes + (size_t)b * s->max_frames * 16,
+                           (size_t)s->frames_run * 16 * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> tok(s->B);
+    HIPC(hipMemcpy(tok.data(), s->tok, s->B * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < s->B; ++b) {
+        SeqInfo& q = s->seq[b];
+        int n = s->frames_run; bool done = false;
+        if (s->opts.eos_token_id >= 0) {
+            for (int f = 0; f < s->frames_run; ++f)
+                if ((int)s->codes_host[((size_t)b * s->max_frames + f) * 16] == s->opts.eos_token_id) { n = f; done = true; break; }
+            if (!done && (int)tok[b] == s->opts.eos_token_id) done = true;     // EOS sampled for the next frame
+        }
+        if (n >= s->max_frames) done = true;
+        q.n_frames = n; q.done = done;
+    }
+    s->codes_host_valid = true;
+    return Q3_OK;
+}
+
+static bool all_done(q3_session* s) { for (auto& q : s->seq) if (!q.done) return false; return true; }
+
+extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_graph) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
+    HIPC(hipSetDevice(s->m->device));
+    if (s->debug || s->profile) use_graph = 0;
+    int todo = n_frames;
+    if (s->frames_run + todo > s->max_frames) todo = s->max_frames - s->frames_run;
+    if (todo <= 0) return Q3_OK;
+    if (use_graph && !s->graph_exec) {
+        HIPC(hipStreamSynchronize(s->stream));
+        HIPC(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        q3_status st = frame_launch(s);
+        hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
+        Q3C(st);
+        if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        HIPC(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
+    }
+    const bool eos_on = s->opts.eos_token_id >= 0;
+    const int check_every = 32;
+    while (todo > 0) {
+        const int burst = eos_on ? (todo < check_every ? todo : check_every) : todo;
+        for (int i = 0; i < burst; ++i) {
+            if (use_graph) HIPC(hipGraphLaunch(s->graph_exec, s->stream));
+            else Q3C(frame_launch(s));
+            s->frames_run += 1;
+        }
+        todo -= burst;
+        s->codes_host_valid = false;
+        if (eos_on) { Q3C(refresh_codes(s)); if (all_done(s)) break; }
+    }
+    HIPC(hipStreamSynchronize(s->stream));
+    if (s->profile && !s->prof_events.empty()) {
+        for (size_t i = 0; i < s->prof_events.size(); ++i) {
+            float ms = 0; hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second);
+            s->prof_linear.ms += ms; s->prof_linear.bytes += s->prof_event_bytes[i]; s->prof_linear.launches += 1;
+            hipEventDestroy(s->prof_events[i].first); hipEventDestroy(s->prof_events[i].second);
+        }
+        s->prof_events.clear(); s->prof_event_bytes.clear();
+    }
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_frames(q3_session* s, int b, int* n_frames, int* done) {
+    if (!s || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad sequence index");
+    HIPC(hipSetDevice(s->m->device));
+    Q3C(refresh_codes(s));
+    if (n_frames) *n_frames = s->seq[b].n_frames;
+    if (done) *done = s->seq[b].done ? 1 : 0;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_codes(q3_session* s, int b, uint32_t* codes_host, int cap_frames, int* n_frames) {
+    if (!s || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad sequence index");
+    HIPC(hipSetDevice(s->m->device));
+    Q3C(refresh_codes(s));
+    const int n = s->seq[b].n_frames;
+    if (n_frames) *n_frames = n;
+    if (codes_host) {
+        if (cap_frames < n) return set_err(Q3_INVALID_ARG, "codes buffer too small (%d < %d frames)", cap_frames, n);
+        memcpy(codes_host, &s->codes_host[(size_t)b * s->max_frames * 16], (size_t)n * 16 * 4);
+    }
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, float* pcm_host, size_t cap, size_t* n_samples) {
+    if (!s || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad sequence index");
+    HIPC(hipSetDevice(s->m->device));
+    Q3C(refresh_codes(s));
+    if (f0 < 0 || f1 < f0 || f1 > s->seq[b].n_frames) return set_err(Q3_INVALID_ARG, "bad frame range [%d,%d) of %d", f0, f1, s->seq[b].n_frames);
+    const int T = f1 - f0, spf = samples_per_frame(s->m->cfg);
+    if (n_samples) *n_samples = (size_t)T * spf;
+    if (T == 0) return Q3_OK;
+    Q3C(codec_reserve(s->m, s->cws, T));
+    HIPC(hipMemcpyAsync(s->cws.frames, s->codes + ((size_t)b * s->max_frames + f0) * 16, (size_t)T * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
+    Q3C(codec_decode_dev(s->m, s->cws, T, s->stream, nullptr));
+    HIPC(hipStreamSynchronize(s->stream));
+    if (pcm_host) {
+        if (cap < (size_t)T * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+        HIPC(hipMemcpy(pcm_host, s->cws.pcm, (size_t)T * spf * 4, hipMemcpyDeviceToHost));
+    }
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_host, const size_t* cap, size_t* n_samples, q3_timing* timing) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
+    Q3C(q3_session_prefill(s));
+    const auto t1 = clk::now();
+    Q3C(q3_session_generate(s, s->max_frames, use_graph));
+    Q3C(refresh_codes(s));
+    const auto t2 = clk::now();
+    int total = 0;
+    for (int b = 0; b < s->B; ++b) {
+        size_t n = 0;
+        Q3C(q3_session_decode(s, b, 0, s->seq[b].n_frames, pcm_host ? pcm_host[b] : nullptr, cap ? cap[b] : 0, &n));
+        if (n_samples) n_samples[b] = n;
+        total += s->seq[b].n_frames;
+    }
+    const auto t3 = clk::now();
+    if (timing) { timing->prefill_ms = ms(t0, t1); timing->generation_ms = ms(t1, t2); timing->decode_ms = ms(t2, t3); timing->generation_frames = total; }
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_t cap, size_t* n_samples, int* done) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (s->B != 1) return set_err(Q3_UNSUPPORTED, "streaming sessions are batch 1 (StreamingSession, lib.rs:1484)");
+    if (!s->prefilled) Q3C(q3_session_prefill(s));
+    Q3C(refresh_codes(s));
+    SeqInfo& q = s->seq[0];
+    const int chunk = s->opts.chunk_frames > 0 ? s->opts.chunk_frames : 10;
+    // generate until chunk_frames frames are buffered or the sequence ends (lib.rs:1663-1748)
+    while (!q.done && q.n_frames - s->stream_pos < chunk && s->frames_run < s->max_frames) {
+        int need = chunk - (q.n_frames - s->stream_pos);
+        Q3C(q3_session_generate(s, need, 1));
+        Q3C(refresh_codes(s));
+    }
+    int avail = q.n_frames - s->stream_pos;
+    if (avail > chunk) avail = chunk;
+    if (avail <= 0) { if (n_samples) *n_samples = 0; if (done) *done = 1; return Q3_OK; }
+    Q3C(q3_session_decode(s, 0, s->stream_pos, s->stream_pos + avail, pcm_host, cap, n_samples));
+    s->stream_pos += avail;
+    if (done) *done = (q.done && s->stream_pos >= q.n_frames) ? 1 : 0;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_get(q3_session* s, int what, int b, void* out, size_t bytes) {
+    if (!s || !out || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad argument");
+    const q3_config& c = s->m->cfg;
+    HIPC(hipSetDevice(s->m->device));
+    HIPC(hipStreamSynchronize(s->stream));
+    const void* src = nullptr; size_t need = 0;
+    switch (what) {
+        case Q3_GET_PREFILL_EMBEDS: src = s->embeds + (size_t)b * s->prefill_len * c.hidden; need = (size_t)s->prefill_len * c.hidden * 4; break;
+        case Q3_GET_LAST_HIDDEN: src = s->LASTH + (size_t)b * c.hidden; need = (size_t)c.hidden * 4; break;
+        case Q3_GET_LOGITS: src = s->LOGITS + (size_t)b * c.codec_vocab; need = (size_t)c.codec_vocab * 4; break;
+        case Q3_GET_TRAILING: src = s->rows + (size_t)s->seq[b].trail_base * c.hidden; need = (size_t)s->seq[b].trailing_len * c.hidden * 4; break;
+        case Q3_GET_PAD_EMBED: src = s->rows + (size_t)s->seq[b].pad_row * c.hidden; need = (size_t)c.hidden * 4; break;
+        case Q3_GET_LOGITS_HIST:
+            if (!s->logits_hist) return set_err(Q3_INVALID_ARG, "session has no debug capture");
+            src = s->logits_hist + (size_t)b * (s->max_frames + 1) * c.codec_vocab; need = (size_t)(s->frames_run + 1) * c.codec_vocab * 4; break;
+        case Q3_GET_TOKEN: src = s->tok + b; need = 4; break;
+        case Q3_GET_CP_LOGITS: {
+            // [15][B][V] on device → [15][V] for sequence b
+            need = (size_t)15 * c.cp_vocab * 4;
+            if (bytes < need) return set_err(Q3_INVALID_ARG, "buffer too small");
+            for (int g = 0; g < 15; ++g)
+                HIPC(hipMemcpy((char*)out + (size_t)g * c.cp_vocab * 4, s->CP_LOGITS + ((size_t)g * s->B + b) * c.cp_vocab, (size_t)c.cp_vocab * 4, hipMemcpyDeviceToHost));
+            return Q3_OK;
+        }
+        case Q3_GET_CP_LOGITS_HIST: {
+            if (!s->cp_logits_hist) return set_err(Q3_INVALID_ARG, "session has no debug capture");
+            need = (size_t)s->frames_run * 15 * c.cp_vocab * 4;
+            if (bytes < need) return set_err(Q3_INVALID_ARG, "buffer too small");
+            for (int f = 0; f < s->frames_run; ++f)
+                for (int g = 0; g < 15; ++g)
+                    HIPC(hipMemcpy((char*)out + ((size_t)f * 15 + g) * c.cp_vocab * 4,
+                                   s->cp_logits_hist + (((size_t)f * 15 + g) * s->B + b) * c.cp_vocab, (size_t)c.cp_vocab * 4, hipMemcpyDeviceToHost));
+            return Q3_OK;
+        }
+        default: return set_err(Q3_INVALID_ARG, "unknown item %d", what);
+    }
+    if (bytes < need) return set_err(Q3_INVALID_ARG, "buffer too small (%zu < %zu)", bytes, need);
+    HIPC(hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_talker_step(q3_session* s, const float* embeds_host, float* hidden_host, float* logits_host) {
+    if (!s || !embeds_host) return set_err(Q3_INVALID_ARG, "null argument");
+    if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
+    const q3_config& c = s->m->cfg;
+    HIPC(hipSetDevice(s->m->device));
+    HIPC(hipMemcpyAsync(s->tb.X, embeds_host, (size_t)s->B * c.hidden * 4, hipMemcpyHostToDevice, s->stream));
+    Q3C(talker_step(s, s->pos, 0, true));
+    // advance positions by one (host-driven teacher forcing)
+    std::vector<int> posv(s->B);
+    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(hipMemcpy(posv.data(), s->pos, s->B * 4, hipMemcpyDeviceToHost));
+    for (int& p : posv) { p += 1; if (p >= s->max_seq) return set_err(Q3_KV_OVERFLOW, "KV cache full (%d)", s->max_seq); }
+    HIPC(hipMemcpy(s->pos, posv.data(), s->B * 4, hipMemcpyHostToDevice));
+    if (hidden_host) HIPC(hipMemcpy(hidden_host, s->LASTH, (size_t)s->B * c.hidden * 4, hipMemcpyDeviceToHost));
+    if (logits_host) HIPC(hipMemcpy(logits_host, s->LOGITS, (size_t)s->B * c.codec_vocab * 4, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host, const float* sem_embed_host,
+                                    uint32_t* codes15_host, float* cp_logits_host) {
+    if (!s || !last_hidden_host || !codes15_host) return set_err(Q3_INVALID_ARG, "null argument");
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    HIPC(hipSetDevice(m->device));
+    // the semantic embedding is looked up from tok on device; teacher forcing passes it as an embedding
+    // row, so run pass 1 from an explicit buffer: temporarily stage it through CP_IN/cb.X.
+    const int B = s->B, H = c.hidden, CH = c.cp_hidden, V = c.cp_vocab;
+    HIPC(hipMemcpyAsync(s->LASTH, last_hidden_host, (size_t)B * H * 4, hipMemcpyHostToDevice, s->stream));
+    const LmDims d = cp_dims(c);
+    float* sem_dev = nullptr;
+    if (sem_embed_host) { HIPC(hipMalloc((void**)&sem_dev, (size_t)B * H * 4)); HIPC(hipMemcpy(sem_dev, sem_embed_host, (size_t)B * H * 4, hipMemcpyHostToDevice)); }
+    q3_status st = Q3_OK;
+    auto run = [&]() -> q3_status {
+        for (int p = 0; p < c.n_groups; ++p) {
+            CpGatherArgs g{};
+            g.pass = p; g.last_hidden = s->LASTH; g.H = H; g.codec_emb = m->codec_emb; g.tok = s->tok;
+            g.cp_emb = p >= 2 ? m->cp_emb[p - 2] : nullptr;
+            g.cp_logits = p >= 2 ? s->CP_LOGITS + (size_t)(p - 2) * B * V : nullptr;
+            g.cp_vocab = V; g.codes = s->codes; g.frame_idx = s->frame_idx; g.max_frames = s->max_frames; g.B = B;
+            float* dst = m->mtp_w ? s->CP_IN : s->cb.X; const int ld = m->mtp_w ? H : CH;
+            g.out = dst; g.ld_out = ld;
+            if (p == 1 && sem_dev) HIPC(launch_copy_rows(sem_dev, H, dst, ld, B, H, s->stream));
+            else HIPC(launch_cp_gather(g, s->stream));
+            if (m->mtp_w) {
+                LinArgs a;
+                a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
+                HIPC(launch_linear(a, s->stream));
+            }
+            for (int i = 0; i < c.cp_layers; ++i)
+                Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,
+                             c.n_groups + 1, nullptr, p, 1));
+            if (p >= 1) {
+                LinArgs h;
+                h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
+                h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
+                HIPC(launch_linear(h, s->stream));
+            }
+        }
+        HIPC(hipStreamSynchronize(s->stream));
+        return Q3_OK;
+    };
+    st = run();
+    if (sem_dev) hipFree(sem_dev);
+    Q3C(st);
+    std::vector<float> lg((size_t)15 * B * V);
+    HIPC(hipMemcpy(lg.data(), s->CP_LOGITS, lg.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+        for (int g = 0; g < 15; ++g) {
+            const float* row = &lg[((size_t)g * B + b) * V];
+            int best = 0; for (int i = 1; i < V; ++i) if (row[i] > row[best]) best = i;
+            codes15_host[(size_t)b * 15 + g] = (uint32_t)best;
+            if (cp_logits_host) memcpy(cp_logits_host + ((size_t)b * 15 + g) * V, row, (size_t)V * 4);
+        }
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_frame_embed(q3_model* m, uint32_t sem_token, const uint32_t* codes15, const float* text_add_host, float* out_host) {
+    if (!m || !m->finalized || !codes15 || !text_add_host || !out_host) return set_err(Q3_INVALID_ARG, "bad argument");
+    const q3_config& c = m->cfg;
+    HIPC(hipSetDevice(m->device));
+    const int H = c.hidden, V = c.cp_vocab;
+    if (sem_token >= (uint32_t)c.codec_vocab) return set_err(Q3_INVALID_ARG, "semantic token out of range");
+    DevPool pool;
+    float *rows, *logits, *out; uint32_t *tok, *codes; int *zero, *one;
+    HIPC(pool.alloc(&rows, (size_t)H)); HIPC(pool.alloc(&logits, (size_t)V)); HIPC(pool.alloc(&out, (size_t)H));
+    HIPC(pool.alloc(&tok, 1)); HIPC(pool.alloc(&codes, 16)); HIPC(pool.alloc(&zero, 1)); HIPC(pool.alloc(&one, 1));
+    // codes 0..13 pre-written; code 14 enters through a one-hot logits row
+    uint32_t frame[16] = {0};
+    for (int g = 0; g < 14; ++g) { if (codes15[g] >= (uint32_t)V) return set_err(Q3_INVALID_ARG, "code out of range"); frame[1 + g] = codes15[g]; }
+    if (codes15[14] >= (uint32_t)V) return set_err(Q3_INVALID_ARG, "code out of range");
+    std::vector<float> lg((size_t)V, 0.0f); lg[codes15[14]] = 1.0f;
+    const int h_one = 1;
+    HIPC(hipMemcpy(rows, text_add_host, (size_t)H * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(logits, lg.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(tok, &sem_token, 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(codes, frame, 64, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(one, &h_one, 4, hipMemcpyHostToDevice));
+    FrameEmbedArgs f{};
+    f.codec_emb = m->codec_emb; f.cp_embs = m->cp_embs_dev; f.tok = tok; f.cp_logits_last = logits; f.cp_vocab = V;
+    f.codes = codes; f.frame_idx = zero; f.max_frames = 1; f.text_rows = rows; f.trail_base = zero; f.trail_len = one; f.pad_row = zero;
+    f.out = out; f.H = H; f.B = 1; f.n_acoustic = 15;
+    HIPC(launch_frame_embed(f, 0));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(out_host, out, (size_t)H * 4, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_sample(int device, const float* logits_host, const uint8_t* seen_host, const float* u_host, int rows, int vocab,
+                               const q3_options* o, int token_count, uint32_t* tokens_host) {
+    if (!logits_host || !u_host || !o || !tokens_host || rows < 1) return set_err(Q3_INVALID_ARG, "bad argument");
+    if (vocab < 2 || vocab > 4096) return set_err(Q3_UNSUPPORTED, "vocab %d unsupported by the device sampler (2..4096)", vocab);
+    HIPC(hipSetDevice(device));
+    DevPool pool;
+    float *lg, *u; uint8_t* seen = nullptr; uint32_t* tok;
+    HIPC(pool.alloc(&lg, (size_t)rows * vocab)); HIPC(pool.alloc(&u, (size_t)rows)); HIPC(pool.alloc(&tok, (size_t)rows));
+    HIPC(hipMemcpy(lg, logits_host, (size_t)rows * vocab * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(u, u_host, (size_t)rows * 4, hipMemcpyHostToDevice));
+    if (seen_host) { HIPC(pool.alloc(&seen, (size_t)rows * vocab)); HIPC(hipMemcpy(seen, seen_host, (size_t)rows * vocab, hipMemcpyHostToDevice)); }
+    SampleArgs a; memset(&a, 0, sizeof a);
+    a.logits = lg; a.ld = vocab; a.seen = seen; a.u = u; a.u_stride = 1; a.tok = tok; a.token_count_static = token_count < 0 ? 0 : token_count;
+    a.vocab = vocab; a.B = rows;
+    a.apply_temp = (o->temperature != 1.0 && o->temperature > 0.0) ? 1 : 0;
+    a.inv_temp = (float)(1.0 / o->temperature);
+    a.greedy = o->temperature < 0.01 ? 1 : 0;
+    a.top_k = o->top_k; a.use_top_p = (o->top_p < 1.0 && o->top_p > 0.0) ? 1 : 0; a.top_p = (float)o->top_p;
+    const bool pen = token_count >= 0;     // token_count < 0: plain `sample` without the penalty pipeline
+    a.use_rep = (pen && seen && o->repetition_penalty != 1.0 && !(fabs(o->repetition_penalty - 1.0) < 1e-9)) ? 1 : 0;
+    a.rep_pen = (float)o->repetition_penalty; a.rep_inv = 1.0f / (float)o->repetition_penalty;
+    a.eos_id = pen ? o->eos_token_id : -1; a.min_new_tokens = pen ? o->min_new_tokens : 0; a.codec_eos = CODEC_EOS; a.use_suppress = pen ? 1 : 0;
+    HIPC(launch_sample(a, 0));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(tokens_host, tok, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_fused_residual_rmsnorm(int device, int dtype, const void* x_host, const void* res_host, const void* w_host,
+                                               int rows, int cols, float eps, void* normed_host, void* sum_host) {
+    if (!x_host || !res_host || !w_host || !normed_host || !sum_host || rows < 1 || cols < 1) return set_err(Q3_INVALID_ARG, "bad argument");
+    if (dtype != Q3_DTYPE_F32 && dtype != Q3_DTYPE_BF16) return set_err(Q3_UNSUPPORTED, "dtype %d unsupported", dtype);
+    HIPC(hipSetDevice(device));
+    const size_t es = dtype == Q3_DTYPE_F32 ? 4 : 2, n = (size_t)rows * cols;
+    DevPool pool;
+    char *x, *r, *w, *nm, *sm;
+    HIPC(pool.alloc(&x, n * es)); HIPC(pool.alloc(&r, n * es)); HIPC(pool.alloc(&w, (size_t)cols * es)); HIPC(pool.alloc(&nm, n * es)); HIPC(pool.alloc(&sm, n * es));
+    HIPC(hipMemcpy(x, x_host, n * es, hipMemcpyHostToDevice)); HIPC(hipMemcpy(r, res_host, n * es, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(w, w_host, (size_t)cols * es, hipMemcpyHostToDevice));
+    if (dtype == Q3_DTYPE_F32) HIPC(launch_fused_residual_rmsnorm_f32((float*)x, (float*)r, (float*)w, (float*)nm, (float*)sm, rows, cols, eps, 0));
+    else HIPC(launch_fused_residual_rmsnorm_bf16((uint16_t*)x, (uint16_t*)r, (uint16_t*)w, (uint16_t*)nm, (uint16_t*)sm, rows, cols, eps, 0));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(normed_host, nm, n * es, hipMemcpyDeviceToHost)); HIPC(hipMemcpy(sum_host, sm, n * es, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* w_host, const float* bias_host, int M, int N, int K, float* y_host) {
+    if (!x_host || !w_host || !y_host || M < 1 || N < 1 || K < 8 || K % 8) return set_err(Q3_INVALID_ARG, "bad argument (K must be a multiple of 8)");
+    HIPC(hipSetDevice(device));
+    DevPool pool;
+    float *x, *y, *b = nullptr; uint16_t* w;
+    HIPC(pool.alloc(&x, (size_t)M * K)); HIPC(pool.alloc(&y, (size_t)M * N)); HIPC(pool.alloc(&w, (size_t)N * K));
+    HIPC(hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(w, w_host, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    if (bias_host) { HIPC(pool.alloc(&b, (size_t)N)); HIPC(hipMemcpy(b, bias_host, (size_t)N * 4, hipMemcpyHostToDevice)); }
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        LinArgs a;
+        a.W = w; a.N = N; a.K = K; a.x = x + (size_t)m0 * K; a.ldx = K; a.bias = b; a.y = y + (size_t)m0 * N; a.ldy = N; a.M = (M - m0) < 8 ? (M - m0) : 8; a.epi = EPI_NONE;
+        HIPC(launch_linear(a, 0));
+    }
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(y_host, y, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    const q3_config& c = s->m->cfg;
+    auto layer_params = [](int H, int I, int nh, int nkv) { return (double)H * (nh + 2 * nkv) * HEAD_DIM + (double)H * nh * HEAD_DIM + 3.0 * (double)H * I; };
+    const double talker = c.n_layers * layer_params(c.hidden, c.inter, c.n_heads, c.n_kv_heads) + (double)c.codec_vocab * c.hidden;
+    const double cp_pass = c.cp_layers * layer_params(c.cp_hidden, c.cp_inter, c.cp_heads, c.cp_kv_heads) + (double)c.cp_vocab * c.cp_hidden +
+                           (c.hidden != c.cp_hidden ? (double)c.cp_hidden * c.hidden : 0.0);
+    if (weight_bytes) *weight_bytes = 2.0 * (talker + 15.0 * cp_pass);          // bf16; SURVEY §8(d)
+    if (kv_bytes) {
+        const double kv_tok = 2.0 * c.n_kv_heads * HEAD_DIM * 4.0 * c.n_layers;   // f32 KV in this build
+        const double cp_tok = 2.0 * c.cp_kv_heads * HEAD_DIM * 4.0 * c.cp_layers;
+        *kv_bytes = s->B * (kv_tok * kv_len + cp_tok * 135.0);
+    }
+    return Q3_OK;
+}
+
+// profiling read-out: accumulated GPU milliseconds / algorithmic bytes / launches of the bf16 GEMV family
+extern "C" q3_status q3_session_profile_read(q3_session* s, double* ms, double* bytes, long* launches, int reset) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (ms) *ms = s->prof_linear.ms; if (bytes) *bytes = s->prof_linear.bytes; if (launches) *launches = s->prof_linear.launches;
+    if (reset) s->prof_linear = ProfAcc();
+    return Q3_OK;
+}

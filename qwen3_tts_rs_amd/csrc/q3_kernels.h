@@ -1,0 +1,136 @@
+// q3_kernels.h — host-side launchers of the gfx950 kernels (q3_kernels_lm.hip,
+// q3_kernels_codec.hip). Everything takes an explicit hipStream_t; no allocation, no sync — all
+// launchers are hipGraph-capturable.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace q3 {
+
+constexpr int HEAD_DIM = 128;        // talker / code-predictor head dim (kernels are specialised)
+constexpr int MAX_SPLITS = 16;       // KV splits of the decode attention
+constexpr int PART_STRIDE = HEAD_DIM + 2;   // partial record: acc[128], m, l
+
+// ---- bf16-weight skinny GEMM ("GEMV family"): y[m][n] = sum_k x[m][k] * W[n][k] ----
+enum LinEpi { EPI_NONE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_SWIGLU = 3 };
+struct LinArgs {
+    const uint16_t* W = nullptr;    // [N][K] bf16
+    const uint16_t* W2 = nullptr;   // second matrix (SwiGLU "up")
+    const float* x = nullptr; int ldx = 0;        // [M][ldx]
+    const float* norm_w = nullptr; float eps = 0; // fused input RMSNorm if norm_w != nullptr
+    const float* bias = nullptr;                  // [N] or nullptr
+    const float* resid = nullptr; int ldr = 0;    // EPI_RESID: y = resid + acc
+    float* y = nullptr; int ldy = 0;
+    int M = 1, N = 0, K = 0;
+    int epi = EPI_NONE;
+};
+hipError_t launch_linear(const LinArgs& a, hipStream_t st);
+
+// standalone analogue of kernels/fused_residual_rmsnorm.cu: (normed, sum) for [rows][cols]
+hipError_t launch_fused_residual_rmsnorm_f32(const float* x, const float* res, const float* w, float* normed,
+                                             float* sum, int rows, int cols, float eps, hipStream_t st);
+hipError_t launch_fused_residual_rmsnorm_bf16(const uint16_t* x, const uint16_t* res, const uint16_t* w,
+                                              uint16_t* normed, uint16_t* sum, int rows, int cols, float eps,
+                                              hipStream_t st);
+// y = rms_norm(x) * w   (rows = batch)
+hipError_t launch_rmsnorm(const float* x, int ldx, const float* w, float* y, int ldy, int rows, int cols, float eps,
+                          hipStream_t st);
+
+// ---- attention decode ----
+struct AttnArgs {
+    const float* qkv; int ld_qkv;           // [B][nh*128 + 2*nkv*128] raw projections
+    const float* q_norm_w; const float* k_norm_w; float eps;
+    const float* rope_cos; const float* rope_sin;   // [max_pos][64]
+    const int* pos_dev; int pos_static;     // position of the new token: pos_dev[b] if non-null
+    float* kcache; float* vcache;           // [B][nkv][max_seq][128]
+    int max_seq;
+    float* qbuf;                            // [B][nh][128] normed+roped q
+    float* part;                            // [B][nh][n_splits][PART_STRIDE]
+    float* out; int ld_out;                 // [B][nh*128]
+    int B, nh, nkv, n_splits;
+};
+hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
+hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
+hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st);
+
+// ---- frame glue ----
+// gather rows: out[r][0..dim) = f32(table_bf16[ids[r]][0..dim))
+hipError_t launch_gather_rows_bf16(const uint16_t* table, const uint32_t* ids, float* out, int n_rows, int dim,
+                                   hipStream_t st);
+// prefill assembly: out[i] = (text_row[i] >= 0 ? rows[text_row[i]] : 0) + (codec_id[i] >= 0 ? codec_emb[codec_id[i]]
+//                   : codec_id[i] == -2 ? xvec : 0)
+hipError_t launch_assemble_rows(const float* rows, const int* text_row, const uint16_t* codec_emb, const int* codec_id,
+                                const float* xvec, float* out, int n, int H, hipStream_t st);
+hipError_t launch_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t st);
+
+struct CpGatherArgs {
+    int pass;                        // 0..15
+    const float* last_hidden; int H; // [B][H] (pass 0)
+    const uint16_t* codec_emb;       // talker codec embedding [codec_vocab][H] (pass 1)
+    const uint32_t* tok;             // [B] current semantic token
+    const uint16_t* cp_emb;          // table of group pass-2 (pass >= 2): [cp_vocab][H]
+    const float* cp_logits;          // [B][cp_vocab] logits of the previous pass (pass >= 2)
+    int cp_vocab;
+    uint32_t* codes;                 // [B][max_frames][16]
+    const int* frame_idx;            // [B]
+    int max_frames;
+    float* out; int ld_out;          // [B][H]
+    int B;
+};
+hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st);
+
+struct FrameEmbedArgs {
+    const uint16_t* codec_emb; const uint16_t* const* cp_embs;   // device array of 15 table pointers
+    const uint32_t* tok; const float* cp_logits_last; int cp_vocab;  // final pass logits → code 14
+    uint32_t* codes; const int* frame_idx; int max_frames;
+    const float* text_rows; const int* trail_base; const int* trail_len; const int* pad_row;   // per-seq
+    float* out; int H; int B; int n_acoustic;
+};
+hipError_t launch_frame_embed(const FrameEmbedArgs& a, hipStream_t st);
+
+struct SampleArgs {
+    const float* logits; int ld;     // [B][vocab]
+    uint8_t* seen;                   // [B][vocab] or nullptr
+    const float* u; int u_stride;    // u[b*u_stride + (draw_idx ? draw_idx[b] : 0)]
+    const int* draw_idx;
+    uint32_t* tok;                   // [B] out
+    int* token_count;                // [B] device counters (incremented) or nullptr
+    int token_count_static;
+    int* frame_idx; int* pos;        // advanced by one after sampling when advance != 0
+    int advance;
+    float* logits_hist; int hist_stride_b; int hist_cap;  // optional capture [B][cap][vocab] at index token_count
+    int vocab, B;
+    float inv_temp; int apply_temp; int greedy;
+    int top_k; float top_p; int use_top_p;
+    float rep_pen, rep_inv; int use_rep;
+    int eos_id; int min_new_tokens; int codec_eos; int use_suppress;
+};
+hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
+
+// ---- codec decoder (f32, [C][L] layout) ----
+struct ConvArgs {
+    const float* x; const float* w; const float* b; float* y;
+    int cin, cout, L, k, dil;
+    const float* snake_a = nullptr; const float* snake_b = nullptr;   // SnakeBeta applied to x on load
+    const float* resid = nullptr;    // y += resid
+    const float* scale = nullptr;    // y = resid + scale[c] * conv   (layer scale / gamma), needs resid
+    int act = 0;                     // 1 = GELU(erf), 2 = clamp(-1,1)
+};
+hipError_t launch_conv1d(const ConvArgs& a, hipStream_t st);
+// polyphase transposed conv: wp = per-phase causal-conv weights [stride][cout][cin][taps]
+hipError_t launch_transconv1d_taps(const float* x, const float* wp, const float* b, float* y, int cin, int cout, int L,
+                                   int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st);
+hipError_t launch_snake_tables(const float* alpha, const float* beta, float* a, float* ib, int C, hipStream_t st);
+hipError_t launch_dwconv7(const float* x, const float* w, const float* b, float* y, int C, int L, hipStream_t st);
+hipError_t launch_layernorm_c(const float* x, const float* w, const float* b, float* y, int C, int L, float eps,
+                              hipStream_t st);
+hipError_t launch_rmsnorm_c(const float* x, const float* w, float* y, int C, int L, float eps, hipStream_t st);
+hipError_t launch_rope_c(float* q, float* k, const float* cs, const float* sn, int nh, int hd, int L, hipStream_t st);
+hipError_t launch_attn_c(const float* q, const float* k, const float* v, float* o, int nh, int hd, int L, float scale,
+                         hipStream_t st);
+hipError_t launch_silu_mul(const float* g, const float* u, float* y, int64_t n, hipStream_t st);
+hipError_t launch_rvq_embed(const uint32_t* frames, int n_frames, const float* first_cb, const float* const* rest_cbs,
+                            float* first_out, float* rest_out, int cb_dim, int cb_size, hipStream_t st);
+hipError_t launch_norm_codebook(const float* esum, const float* usage, float* out, int rows, int dim, hipStream_t st);
+
+}  // namespace q3

@@ -1,0 +1,337 @@
+// q3_kernels_codec.hip — gfx950 kernels of the 12 Hz codec decoder / vocoder (always F32, like the
+// reference: lib.rs:344-353). All activations are [C][L] row-major (time contiguous), so every conv
+// and every "linear" (a K=1 conv) shares one LDS-tiled kernel with the input tile + left halo
+// dil*(k-1) staged once per input-channel chunk; SnakeBeta is fused into the tile load, bias /
+// GELU / layer-scale / residual / clamp into the store.
+//
+// Reference anchors: decoder_12hz.rs:411-505 (decode), 536-691 (pre-transformer), causal_conv.rs:94-103,
+// causal_trans_conv.rs:88-100, convnext_block.rs:110-141, decoder_block.rs:81-92/240-247,
+// snake_beta.rs:58-77.
+#include "q3_kernels.h"
+
+#include <math.h>
+
+namespace q3 {
+
+__device__ __forceinline__ float snake_f(float x, float a, float ib) {
+    const float s = sinf(x * a);
+    return x + (s * s) * ib;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic causal conv1d:  y[co][t*ostride + ooff] = epi( b[co] + Σ_ci Σ_kk w[co][ci][kk] · f(x[ci][t-(k-1-kk)·dil]) )
+// Block tile: 32 output channels × 128 time steps, 256 threads, 4×4 outputs per thread;
+// input channels in chunks of 16 through LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int CV_CO = 32, CV_T = 128, CV_CI = 16, CV_MAXK = 7, CV_MAXHALO = 54;
+
+struct ConvDev {
+    const float* x; const float* w; const float* b; float* y;
+    int cin, cout, L, k, dil;
+    const float* snake_a; const float* snake_ib;
+    const float* resid; const float* scale;
+    int act;
+    int ostride, ooff, oL;        // output indexing (transposed conv phases write strided)
+    size_t w_phase_stride;        // weight offset per blockIdx.z
+    int ooff_phase;               // output offset added per blockIdx.z
+};
+
+__global__ __launch_bounds__(256) void k_conv1d(ConvDev a) {
+    __shared__ float xs[CV_CI][CV_T + CV_MAXHALO + 2];
+    __shared__ __attribute__((aligned(16))) float ws[CV_CI][CV_MAXK][CV_CO];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int t0 = blockIdx.x * CV_T, co0 = blockIdx.y * CV_CO;
+    const float* w = a.w + (size_t)blockIdx.z * a.w_phase_stride;
+    const int ooff = a.ooff + (int)blockIdx.z * a.ooff_phase;
+    const int halo = (a.k - 1) * a.dil;
+    const int W = CV_T + halo;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+
+    for (int ci0 = 0; ci0 < a.cin; ci0 += CV_CI) {
+        __syncthreads();
+        // stage x tile (with SnakeBeta applied) — coalesced along t
+        for (int e = tid; e < CV_CI * W; e += 256) {
+            const int ci = e / W, tt = e - ci * W;
+            const int c = ci0 + ci, t = t0 - halo + tt;
+            float v = 0.0f;
+            if (c < a.cin && t >= 0 && t < a.L) {
+                v = a.x[(size_t)c * a.L + t];
+                if (a.snake_a) v = snake_f(v, a.snake_a[c], a.snake_ib[c]);
+            }
+            xs[ci][tt] = v;
+        }
+        // stage weights [ci][kk][co]
+        for (int e = tid; e < CV_CI * a.k * CV_CO; e += 256) {
+            const int co = e % CV_CO, r = e / CV_CO, kk = r % a.k, ci = r / a.k;
+            const int c = ci0 + ci, o = co0 + co;
+            ws[ci][kk][co] = (c < a.cin && o < a.cout) ? w[((size_t)o * a.cin + c) * a.k + kk] : 0.0f;
+        }
+        __syncthreads();
+        const int nci = (a.cin - ci0) < CV_CI ? (a.cin - ci0) : CV_CI;
+        for (int ci = 0; ci < nci; ++ci) {
+            for (int kk = 0; kk < a.k; ++kk) {
+                const float4 wv = *reinterpret_cast<const float4*>(&ws[ci][kk][ty * 4]);
+                const int xo = tx + kk * a.dil;
+                float xv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[j] = xs[ci][xo + 32 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0][j] = fmaf(wv.x, xv[j], acc[0][j]);
+                    acc[1][j] = fmaf(wv.y, xv[j], acc[1][j]);
+                    acc[2][j] = fmaf(wv.z, xv[j], acc[2][j]);
+                    acc[3][j] = fmaf(wv.w, xv[j], acc[3][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = co0 + ty * 4 + i;
+        if (o >= a.cout) continue;
+        const float bias = a.b ? a.b[o] : 0.0f;
+        const float sc = a.scale ? a.scale[o] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + tx + 32 * j;
+            if (t >= a.L) continue;
+            float v = acc[i][j] + bias;
+            if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (a.scale) v = v * sc;
+            const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
+            if (a.resid) v = a.resid[oi] + v;
+            if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
+            a.y[oi] = v;
+        }
+    }
+}
+
+// single-output-channel conv (final 96→1, k=7): one thread per time step
+__global__ __launch_bounds__(256) void k_conv_out1(ConvDev a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.L) return;
+    float acc = 0.0f;
+    for (int c = 0; c < a.cin; ++c) {
+        const float sa = a.snake_a ? a.snake_a[c] : 0.0f, sib = a.snake_a ? a.snake_ib[c] : 0.0f;
+        for (int kk = 0; kk < a.k; ++kk) {
+            const int ts = t - (a.k - 1 - kk) * a.dil;
+            if (ts < 0) continue;
+            float v = a.x[(size_t)c * a.L + ts];
+            if (a.snake_a) v = snake_f(v, sa, sib);
+            acc = fmaf(a.w[(size_t)c * a.k + kk], v, acc);
+        }
+    }
+    float v = acc + (a.b ? a.b[0] : 0.0f);
+    if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
+    a.y[t] = v;
+}
+
+hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
+    if (c.k > CV_MAXK || (c.k - 1) * c.dil > CV_MAXHALO || c.L <= 0) return hipErrorInvalidValue;
+    ConvDev a{};
+    a.x = c.x; a.w = c.w; a.b = c.b; a.y = c.y; a.cin = c.cin; a.cout = c.cout; a.L = c.L; a.k = c.k; a.dil = c.dil;
+    a.snake_a = c.snake_a; a.snake_ib = c.snake_b; a.resid = c.resid; a.scale = c.scale; a.act = c.act;
+    a.ostride = 1; a.ooff = 0; a.oL = c.L; a.w_phase_stride = 0; a.ooff_phase = 0;
+    if (c.cout == 1) {
+        hipLaunchKernelGGL(k_conv_out1, dim3((c.L + 255) / 256), dim3(256), 0, st, a);
+    } else {
+        dim3 grid((c.L + CV_T - 1) / CV_T, (c.cout + CV_CO - 1) / CV_CO, 1);
+        hipLaunchKernelGGL(k_conv1d, grid, dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+// Transposed conv, polyphase form. Host code pre-arranges the weight [cin][cout][k] into per-phase
+// causal-conv weights wp[ph][cout][cin][taps] (taps = k/stride: tap 0 ↔ x[j-1] (w[.][.][ph+s]),
+// last tap ↔ x[j] (w[.][.][ph])), so phase ph is a k=taps causal conv whose outputs land at
+// t = j*stride + ph; the right-trim k - s of causal_trans_conv.rs:79 is implicit (length L*stride).
+hipError_t launch_transconv1d_taps(const float* x, const float* wp, const float* b, float* y, int cin, int cout, int L,
+                                   int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st) {
+    ConvDev a{};
+    a.x = x; a.w = wp; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = taps; a.dil = 1;
+    a.snake_a = snake_a; a.snake_ib = snake_ib; a.resid = nullptr; a.scale = nullptr; a.act = 0;
+    a.ostride = stride; a.ooff = 0; a.oL = L * stride;
+    a.w_phase_stride = (size_t)cout * cin * taps; a.ooff_phase = 1;
+    dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO, stride);
+    hipLaunchKernelGGL(k_conv1d, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// depthwise causal conv k=7 (ConvNeXt, convnext_block.rs:116)
+__global__ __launch_bounds__(256) void k_dwconv7(const float* x, const float* w, const float* b, float* y, int L) {
+    const int c = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const float* xr = x + (size_t)c * L;
+    float acc = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) {
+        const int ts = t - 6 + kk;
+        if (ts >= 0) acc = fmaf(w[c * 7 + kk], xr[ts], acc);
+    }
+    y[(size_t)c * L + t] = acc + b[c];
+}
+hipError_t launch_dwconv7(const float* x, const float* w, const float* b, float* y, int C, int L, hipStream_t st) {
+    hipLaunchKernelGGL(k_dwconv7, dim3((L + 255) / 256, C), dim3(256), 0, st, x, w, b, y, L);
+    return hipGetLastError();
+}
+
+// channel-wise norms for [C][L] tensors: block = 32 time steps × 8 channel groups
+template <bool LAYERNORM>
+__global__ __launch_bounds__(256) void k_norm_c(const float* x, const float* w, const float* b, float* y, int C, int L,
+                                                float eps) {
+    __shared__ float s1[8][32], s2[8][32];
+    const int tx = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tx;
+    float a = 0.0f, q = 0.0f;
+    if (t < L)
+        for (int c = cg; c < C; c += 8) { const float v = x[(size_t)c * L + t]; a += v; q += v * v; }
+    s1[cg][tx] = a; s2[cg][tx] = q;
+    __syncthreads();
+    float sum = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { sum += s1[g][tx]; sq += s2[g][tx]; }
+    if (t >= L) return;
+    if (LAYERNORM) {
+        const float mean = sum / (float)C, var = sq / (float)C - mean * mean;
+        const float inv = 1.0f / sqrtf(var + eps);
+        for (int c = cg; c < C; c += 8) y[(size_t)c * L + t] = (x[(size_t)c * L + t] - mean) * inv * w[c] + b[c];
+    } else {
+        const float den = sqrtf(sq / (float)C + eps);
+        for (int c = cg; c < C; c += 8) y[(size_t)c * L + t] = x[(size_t)c * L + t] / den * w[c];
+    }
+}
+hipError_t launch_layernorm_c(const float* x, const float* w, const float* b, float* y, int C, int L, float eps,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(k_norm_c<true>, dim3((L + 31) / 32), dim3(256), 0, st, x, w, b, y, C, L, eps);
+    return hipGetLastError();
+}
+hipError_t launch_rmsnorm_c(const float* x, const float* w, float* y, int C, int L, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(k_norm_c<false>, dim3((L + 31) / 32), dim3(256), 0, st, x, w, (const float*)nullptr, y, C, L, eps);
+    return hipGetLastError();
+}
+
+// rotate-half RoPE on q and k in [nh*hd][L] layout (decoder_12hz.rs:682-691)
+__global__ __launch_bounds__(256) void k_rope_c(float* q, float* k, const float* cs, const float* sn, int hd, int L) {
+    const int half = hd / 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int hi = blockIdx.y;                 // h*half + i
+    if (t >= L) return;
+    const int h = hi / half, i = hi % half;
+    const float c = cs[(size_t)t * half + i], s = sn[(size_t)t * half + i];
+    float* p = blockIdx.z == 0 ? q : k;
+    const size_t i1 = ((size_t)h * hd + i) * L + t, i2 = ((size_t)h * hd + i + half) * L + t;
+    const float x1 = p[i1], x2 = p[i2];
+    p[i1] = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, s));
+    p[i2] = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+}
+hipError_t launch_rope_c(float* q, float* k, const float* cs, const float* sn, int nh, int hd, int L, hipStream_t st) {
+    hipLaunchKernelGGL(k_rope_c, dim3((L + 255) / 256, nh * hd / 2, 2), dim3(256), 0, st, q, k, cs, sn, hd, L);
+    return hipGetLastError();
+}
+
+// causal MHA over [nh*hd][L] tensors, hd == 64: one wave per (query i, head h); lane = key index
+// inside a 64-key chunk for QKᵀ/softmax, lane = output dim for the accumulator.
+__global__ __launch_bounds__(64) void k_attn_c(const float* q, const float* k, const float* v, float* o, int L,
+                                               float scale) {
+    const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const size_t hb = (size_t)h * 64 * L;
+    const float qd = q[hb + (size_t)lane * L + i];      // lane d holds q[d]
+    float m = -INFINITY, l = 0.0f, acc = 0.0f;          // acc: lane d holds out[d]
+    for (int j0 = 0; j0 <= i; j0 += 64) {
+        const int j = j0 + lane;
+        const bool ok = j <= i;
+        float s = 0.0f;
+        for (int d = 0; d < 64; ++d) {
+            const float qv = __shfl(qd, d);
+            const float kv = ok ? k[hb + (size_t)d * L + j] : 0.0f;
+            s = fmaf(qv, kv, s);
+        }
+        s = ok ? s * scale : -INFINITY;
+        float cm = s;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cm = fmaxf(cm, __shfl_xor(cm, off));
+        const float mn = fmaxf(m, cm);
+        const float corr = expf(m - mn);
+        const float p = ok ? expf(s - mn) : 0.0f;
+        float ps = p;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ps += __shfl_xor(ps, off);
+        l = l * corr + ps;
+        acc *= corr;
+        for (int d = 0; d < 64; ++d) {
+            float c = ok ? p * v[hb + (size_t)d * L + j] : 0.0f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+            if (lane == d) acc += c;
+        }
+        m = mn;
+    }
+    o[hb + (size_t)lane * L + i] = acc / l;
+}
+hipError_t launch_attn_c(const float* q, const float* k, const float* v, float* o, int nh, int hd, int L, float scale,
+                         hipStream_t st) {
+    if (hd != 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_attn_c, dim3(L, nh), dim3(64), 0, st, q, k, v, o, L, scale);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_silu_mul(const float* g, const float* u, float* y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float v = g[i]; y[i] = (v / (1.0f + expf(-v))) * u[i]; }
+}
+hipError_t launch_silu_mul(const float* g, const float* u, float* y, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_silu_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, u, y, n);
+    return hipGetLastError();
+}
+
+// split-RVQ lookup (decoder_12hz.rs:420-446): first_out[d][t] = first_cb[code0 % cb_size][d],
+// rest_out[d][t] = ((0 + cb_0[c1][d]) + cb_1[c2][d]) + … (15 tables, in order)
+__global__ __launch_bounds__(256) void k_rvq_embed(const uint32_t* frames, int n_frames, const float* first_cb,
+                                                   const float* const* rest_cbs, float* first_out, float* rest_out,
+                                                   int cb_dim, int cb_size) {
+    const int t = blockIdx.x, d = threadIdx.x;
+    if (d >= cb_dim) return;
+    const uint32_t* f = frames + (size_t)t * 16;
+    first_out[(size_t)d * n_frames + t] = first_cb[(size_t)(f[0] % (uint32_t)cb_size) * cb_dim + d];
+    float acc = 0.0f;
+    for (int i = 0; i < 15; ++i) {
+        uint32_t c = f[1 + i];
+        if (c >= (uint32_t)cb_size) c = cb_size - 1;      // host validates; clamp keeps the read in-bounds
+        acc = __fadd_rn(acc, rest_cbs[i][(size_t)c * cb_dim + d]);
+    }
+    rest_out[(size_t)d * n_frames + t] = acc;
+}
+hipError_t launch_rvq_embed(const uint32_t* frames, int n_frames, const float* first_cb, const float* const* rest_cbs,
+                            float* first_out, float* rest_out, int cb_dim, int cb_size, hipStream_t st) {
+    if (cb_dim > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_rvq_embed, dim3(n_frames), dim3(256), 0, st, frames, n_frames, first_cb, rest_cbs, first_out,
+                       rest_out, cb_dim, cb_size);
+    return hipGetLastError();
+}
+
+// codebook = embedding_sum / clamp(cluster_usage, 1e-7) (decoder_12hz.rs:199-225)
+__global__ __launch_bounds__(256) void k_norm_codebook(const float* esum, const float* usage, float* out, int dim) {
+    const int r = blockIdx.x;
+    const float u = fmaxf(usage[r], 1e-7f);
+    for (int d = threadIdx.x; d < dim; d += 256) out[(size_t)r * dim + d] = esum[(size_t)r * dim + d] / u;
+}
+hipError_t launch_norm_codebook(const float* esum, const float* usage, float* out, int rows, int dim, hipStream_t st) {
+    hipLaunchKernelGGL(k_norm_codebook, dim3(rows), dim3(256), 0, st, esum, usage, out, dim);
+    return hipGetLastError();
+}
+
+// snake tables: a = exp(alpha), ib = 1/(exp(beta)+1e-9) (snake_beta.rs:63-73), computed once at load
+__global__ __launch_bounds__(256) void k_snake_tables(const float* alpha, const float* beta, float* a, float* ib, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) { a[c] = expf(alpha[c]); ib[c] = 1.0f / (expf(beta[c]) + 1e-9f); }
+}
+hipError_t launch_snake_tables(const float* alpha, const float* beta, float* a, float* ib, int C, hipStream_t st) {
+    hipLaunchKernelGGL(k_snake_tables, dim3((C + 255) / 256), dim3(256), 0, st, alpha, beta, a, ib, C);
+    return hipGetLastError();
+}
+
+}  // namespace q3

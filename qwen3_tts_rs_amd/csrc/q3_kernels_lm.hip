@@ -1,0 +1,708 @@
+// q3_kernels_lm.hip — gfx950 (CDNA4, wave64) kernels for the autoregressive half of the hot path:
+// talker decode step, 15-step code predictor, frame glue and the on-device sampler.
+//
+// Numerics contract: weights are bf16 in HBM exactly as the checkpoint stores them,
+// every activation / accumulation / KV entry is f32, and the op order of the reference's candle-CPU
+// path is kept (x / sqrt(mean+eps) * w, rotate-half RoPE with separately rounded products, softmax
+// as exp(x-max)/sum, left-to-right embedding sums). Only the summation ORDER inside dot products
+// and block reductions differs from the CPU oracle.
+//
+// Reference anchors: transformer.rs:247-467 (DecoderLayer/Attention/MLP), fused_ops.rs:49-96 +
+// kernels/fused_residual_rmsnorm.cu:39-90, kv_cache.rs:290-347, code_predictor.rs:320-416,
+// lib.rs:612-622, 1271-1322, generation/sampling.rs:140-319.
+#include "q3_kernels.h"
+
+#include <math.h>
+
+namespace q3 {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float half_wave_sum(float v) {   // over aligned groups of 32 lanes
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// block-wide sum for 256-thread blocks; `red` needs 4 floats
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// argmax with first-max tie rule (candle argmax returns the first extremum)
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ int block_argmax_first(const float* vals, int n, float* red_v, int* red_i) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        float v = vals[j];
+        if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; }   // NaN never wins
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    bv = red_v[0]; bi = red_i[0];
+    for (int w = 1; w < nw; ++w) argmax_combine(bv, bi, red_v[w], red_i[w]);
+    if (bi == 0x7fffffff) bi = 0;
+    return bi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16-weight skinny GEMM. One wave produces R output rows for all M activations rows; the weight
+// row is streamed once from HBM with 16-byte loads (8 bf16 per lane, 1 KiB per wave-instruction),
+// x lives in LDS as f32 in a two-plane layout so that both ds_read_b128 of a lane are
+// conflict-free: for the 512-wide k-block j, lane l reads plane A at j*512 + 4l (k = 8l..8l+3) and
+// plane B at j*512 + 256 + 4l (k = 8l+4..8l+7).
+// Optional fused input RMSNorm (x / sqrt(mean(x²)+eps) * w — the candle CPU form) and epilogues:
+// +bias, residual add, SiLU, SwiGLU (two weight streams, one x).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xs_index(int k) {   // k multiple of 4
+    return (k & ~511) + ((k & 4) ? 256 : 0) + ((k & 511) >> 3) * 4;
+}
+
+__device__ __forceinline__ float dot8(const uint4& w, const float4& a, const float4& b, float acc) {
+    acc = fmaf(bf16_lo(w.x), a.x, acc); acc = fmaf(bf16_hi(w.x), a.y, acc);
+    acc = fmaf(bf16_lo(w.y), a.z, acc); acc = fmaf(bf16_hi(w.y), a.w, acc);
+    acc = fmaf(bf16_lo(w.z), b.x, acc); acc = fmaf(bf16_hi(w.z), b.y, acc);
+    acc = fmaf(bf16_lo(w.w), b.z, acc); acc = fmaf(bf16_hi(w.w), b.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+template <int M> struct LinKC { static constexpr int value = (M >= 8) ? 1024 : 2048; };
+
+template <int M, int R, bool RMS, int EPI>
+__global__ __launch_bounds__(256) void k_linear(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KC = LinKC<M>::value;
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, N = a.N;
+    const int kc_cap = ((K < KC ? K : KC) + 511) & ~511;   // LDS floats per m-row
+    float* xs = smem;                                      // [M][kc_cap]
+    float* red = smem + M * kc_cap;                        // [M][4]
+
+    float den[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) den[m] = 1.0f;
+    if constexpr (RMS) {
+        float ss[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) ss[m] = 0.0f;
+        for (int k = tid * 4; k < K; k += 1024) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)(m < a.M ? m : 0) * a.ldx + k);
+                ss[m] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) ss[m] = wave_sum(ss[m]);
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) red[m * 4 + wave] = ss[m];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float tot = (red[m * 4 + 0] + red[m * 4 + 1]) + (red[m * 4 + 2] + red[m * 4 + 3]);
+            den[m] = sqrtf(tot / (float)K + a.eps);
+        }
+    }
+
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    const uint16_t* wrow[NW][R];
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        valid[r] = (row0 + r) < N;
+        const size_t off = (size_t)(valid[r] ? row0 + r : 0) * K;
+        wrow[0][r] = a.W + off;
+        if constexpr (NW == 2) wrow[1][r] = a.W2 + off;
+    }
+
+    float acc[NW][M][R];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[w][m][r] = 0.0f;
+
+    for (int kc0 = 0; kc0 < K; kc0 += KC) {
+        const int kc = (K - kc0) < KC ? (K - kc0) : KC;
+        __syncthreads();   // previous chunk fully consumed (and `red` reads done)
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            for (int k = tid * 4; k < kc; k += 1024) {
+                float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)(m < a.M ? m : 0) * a.ldx + kc0 + k);
+                if constexpr (RMS) {
+                    const float4 nw = *reinterpret_cast<const float4*>(a.norm_w + kc0 + k);
+                    v.x = v.x / den[m] * nw.x; v.y = v.y / den[m] * nw.y;
+                    v.z = v.z / den[m] * nw.z; v.w = v.w / den[m] * nw.w;
+                }
+                *reinterpret_cast<float4*>(xs + m * kc_cap + xs_index(k)) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int k0 = lane * 8; k0 < kc; k0 += 512) {
+            uint4 wv[NW][R];
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    wv[w][r] = *reinterpret_cast<const uint4*>(wrow[w][r] + kc0 + k0);
+            const int xo = (k0 & ~511) + lane * 4;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float4 xa = *reinterpret_cast<const float4*>(xs + m * kc_cap + xo);
+                const float4 xb = *reinterpret_cast<const float4*>(xs + m * kc_cap + xo + 256);
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[w][m][r] = dot8(wv[w][r], xa, xb, acc[w][m][r]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[w][m][r] = wave_sum(acc[w][m][r]);
+
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!valid[r]) continue;
+            const int n = row0 + r;
+            const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                if (m >= a.M) continue;
+                float v = acc[0][m][r];
+                if (a.bias) v = v + bias;
+                if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n] + v;
+                if constexpr (EPI == EPI_SILU) v = silu_f(v);
+                if constexpr (EPI == EPI_SWIGLU) v = silu_f(v) * acc[NW - 1][m][r];
+                a.y[(size_t)m * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+template <int M, int R, bool RMS, int EPI>
+static hipError_t launch_linear_t(const LinArgs& a, hipStream_t st) {
+    constexpr int KC = LinKC<M>::value;
+    const int kc_cap = ((a.K < KC ? a.K : KC) + 511) & ~511;
+    const size_t lds = (size_t)(M * kc_cap + M * 4) * sizeof(float);
+    const int blocks = (a.N + 4 * R - 1) / (4 * R);
+    hipLaunchKernelGGL((k_linear<M, R, RMS, EPI>), dim3(blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int M, int R>
+static hipError_t launch_linear_mr(const LinArgs& a, hipStream_t st) {
+    const bool rms = a.norm_w != nullptr;
+    switch (a.epi) {
+        case EPI_NONE:
+            return rms ? launch_linear_t<M, R, true, EPI_NONE>(a, st) : launch_linear_t<M, R, false, EPI_NONE>(a, st);
+        case EPI_RESID:
+            if (rms) return hipErrorInvalidValue;
+            return launch_linear_t<M, R, false, EPI_RESID>(a, st);
+        case EPI_SILU:
+            if (rms) return hipErrorInvalidValue;
+            return launch_linear_t<M, R, false, EPI_SILU>(a, st);
+        case EPI_SWIGLU:
+            return rms ? launch_linear_t<M, R, true, EPI_SWIGLU>(a, st) : launch_linear_t<M, R, false, EPI_SWIGLU>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_linear(const LinArgs& a, hipStream_t st) {
+    if (a.K % 8 != 0 || a.ldx % 4 != 0 || a.M < 1 || a.M > 8 || a.N < 1) return hipErrorInvalidValue;
+    // rows per wave: 2 when that still leaves >= 512 workgroups (2 per CU), else 1
+    const bool r2 = (a.N / 8) >= 512;
+    const int Mp = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
+    switch (Mp) {
+        case 1: return r2 ? launch_linear_mr<1, 2>(a, st) : launch_linear_mr<1, 1>(a, st);
+        case 2: return r2 ? launch_linear_mr<2, 2>(a, st) : launch_linear_mr<2, 1>(a, st);
+        case 4: return r2 ? launch_linear_mr<4, 2>(a, st) : launch_linear_mr<4, 1>(a, st);
+        default: return r2 ? launch_linear_mr<8, 2>(a, st) : launch_linear_mr<8, 1>(a, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm family (one 256-thread block per row)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rmsnorm(const float* x, int ldx, const float* w, float* y, int ldy, int cols,
+                                                 float eps) {
+    __shared__ float red[4];
+    const float* xr = x + (size_t)blockIdx.x * ldx;
+    float* yr = y + (size_t)blockIdx.x * ldy;
+    float ss = 0.0f;
+    for (int c = threadIdx.x; c < cols; c += 256) { const float v = xr[c]; ss += v * v; }
+    ss = block_sum_256(ss, red);
+    const float den = sqrtf(ss / (float)cols + eps);
+    for (int c = threadIdx.x; c < cols; c += 256) yr[c] = xr[c] / den * w[c];
+}
+
+hipError_t launch_rmsnorm(const float* x, int ldx, const float* w, float* y, int ldy, int rows, int cols, float eps,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(k_rmsnorm, dim3(rows), dim3(256), 0, st, x, ldx, w, y, ldy, cols, eps);
+    return hipGetLastError();
+}
+
+// The reference's only hand-written kernel, re-done for wave64: pass 1 s = x + r (stored, rounded to
+// T), Σ s² accumulated from the unrounded f32; wave shuffle + LDS cross-wave reduce; pass 2 re-reads
+// the rounded s. Output = (normed, sum). f32 math: s / sqrt(mean+eps) * w (CPU form, fused_ops.rs:59-67).
+template <typename T> struct IO;
+template <> struct IO<float> {
+    static __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
+    static __device__ __forceinline__ void st(float* p, size_t i, float v) { p[i] = v; }
+};
+template <> struct IO<uint16_t> {
+    static __device__ __forceinline__ float ld(const uint16_t* p, size_t i) { return bf16_to_f32(p[i]); }
+    static __device__ __forceinline__ void st(uint16_t* p, size_t i, float v) { p[i] = f32_to_bf16(v); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fused_residual_rmsnorm(const T* x, const T* res, const T* w, T* normed, T* sum,
+                                                                int cols, float eps) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * cols;
+    float ss = 0.0f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float s = IO<T>::ld(x, base + c) + IO<T>::ld(res, base + c);
+        IO<T>::st(sum, base + c, s);
+        ss += s * s;
+    }
+    ss = block_sum_256(ss, red);   // also orders the `sum` stores of this block before pass 2 re-reads
+    const float den = sqrtf(ss / (float)cols + eps);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float s = IO<T>::ld(sum, base + c);
+        IO<T>::st(normed, base + c, s / den * IO<T>::ld(w, c));
+    }
+}
+
+hipError_t launch_fused_residual_rmsnorm_f32(const float* x, const float* res, const float* w, float* normed,
+                                             float* sum, int rows, int cols, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(k_fused_residual_rmsnorm<float>, dim3(rows), dim3(256), 0, st, x, res, w, normed, sum, cols, eps);
+    return hipGetLastError();
+}
+hipError_t launch_fused_residual_rmsnorm_bf16(const uint16_t* x, const uint16_t* res, const uint16_t* w,
+                                              uint16_t* normed, uint16_t* sum, int rows, int cols, float eps,
+                                              hipStream_t st) {
+    hipLaunchKernelGGL(k_fused_residual_rmsnorm<uint16_t>, dim3(rows), dim3(256), 0, st, x, res, w, normed, sum, cols,
+                       eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// q/k per-head RMSNorm + rotate-half RoPE + in-place KV append (transformer.rs:263-284,
+// kv_cache.rs:290-347). grid (nh + nkv, B), one wave per head; lane i owns the pair (i, i+64).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_qknorm_rope_kv(AttnArgs a) {
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
+    const int pos = a.pos_dev ? a.pos_dev[b] : a.pos_static;
+    const bool is_q = h < a.nh;
+    const float* src = a.qkv + (size_t)b * a.ld_qkv + (is_q ? h * HEAD_DIM : QD + (h - a.nh) * HEAD_DIM);
+    float x1 = src[lane], x2 = src[lane + 64];
+    const float ss = wave_sum(x1 * x1 + x2 * x2);
+    const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
+    const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
+    x1 = x1 / den * nw[lane];
+    x2 = x2 / den * nw[lane + 64];
+    const float c = a.rope_cos[(size_t)pos * 64 + lane], s = a.rope_sin[(size_t)pos * 64 + lane];
+    const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, s));
+    const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+    if (is_q) {
+        float* q = a.qbuf + ((size_t)b * a.nh + h) * HEAD_DIM;
+        q[lane] = o1; q[lane + 64] = o2;
+    } else {
+        const int kvh = h - a.nh;
+        const size_t slot = (((size_t)b * a.nkv + kvh) * a.max_seq + pos) * HEAD_DIM;
+        a.kcache[slot + lane] = o1; a.kcache[slot + lane + 64] = o2;
+        const float* vs = a.qkv + (size_t)b * a.ld_qkv + QD + KD + kvh * HEAD_DIM;
+        a.vcache[slot + lane] = vs[lane]; a.vcache[slot + lane + 64] = vs[lane + 64];
+    }
+}
+
+hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_qknorm_rope_kv, dim3(a.nh + a.nkv, a.B), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GQA decode attention, split over the KV sequence. grid (n_splits, nkv, B), 256 threads = 8 groups
+// of 32 lanes; a group owns one cached position at a time (lane = 4 dims, float4 K/V loads: 512 B
+// per position, coalesced) and serves all NREP query heads of its KV head from one K/V load.
+// Online softmax per group, groups merged through LDS, one partial record per (head, split).
+// ------------------------------------------------------------------------------------------------
+template <int NREP>
+__global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
+    __shared__ float sm_m[NREP][8], sm_l[NREP][8];
+    __shared__ __attribute__((aligned(16))) float sm_acc[NREP][8][HEAD_DIM];
+    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, grp = tid >> 5, li = tid & 31;
+    const int pos = a.pos_dev ? a.pos_dev[b] : a.pos_static;
+    const int len = pos + 1;
+    const int chunk = (len + a.n_splits - 1) / a.n_splits;
+    const int start = split * chunk;
+    const int end = (start + chunk) < len ? (start + chunk) : len;
+    const float scale = 0.08838834764831845f;   // (1/sqrt(128)) as f32 (affine(scale,0) in candle)
+
+    float4 q[NREP];
+#pragma unroll
+    for (int r = 0; r < NREP; ++r)
+        q[r] = *reinterpret_cast<const float4*>(a.qbuf + ((size_t)b * a.nh + kvh * NREP + r) * HEAD_DIM + li * 4);
+    float m[NREP], l[NREP];
+    float4 acc[NREP];
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+    const size_t base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM + li * 4;
+    for (int p = start + grp; p < end; p += 8) {
+        const float4 kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
+        const float4 vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            float s = q[r].x * kk.x + q[r].y * kk.y + q[r].z * kk.z + q[r].w * kk.w;
+            s = half_wave_sum(s) * scale;
+            const float mn = fmaxf(m[r], s);
+            const float corr = expf(m[r] - mn);
+            const float pe = expf(s - mn);
+            l[r] = l[r] * corr + pe;
+            acc[r].x = acc[r].x * corr + pe * vv.x; acc[r].y = acc[r].y * corr + pe * vv.y;
+            acc[r].z = acc[r].z * corr + pe * vv.z; acc[r].w = acc[r].w * corr + pe * vv.w;
+            m[r] = mn;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+        if (li == 0) { sm_m[r][grp] = m[r]; sm_l[r][grp] = l[r]; }
+        *reinterpret_cast<float4*>(&sm_acc[r][grp][li * 4]) = acc[r];
+    }
+    __syncthreads();
+    for (int t = tid; t < NREP * HEAD_DIM; t += 256) {
+        const int r = t / HEAD_DIM, d = t % HEAD_DIM;
+        float M = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) M = fmaxf(M, sm_m[r][g]);
+        float L = 0.0f, A = 0.0f;
+        if (M != -INFINITY) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float wgt = sm_m[r][g] == -INFINITY ? 0.0f : expf(sm_m[r][g] - M);
+                L += sm_l[r][g] * wgt;
+                A += sm_acc[r][g][d] * wgt;
+            }
+        }
+        float* rec = a.part + (((size_t)b * a.nh + kvh * NREP + r) * a.n_splits + split) * PART_STRIDE;
+        rec[d] = A;
+        if (d == 0) { rec[HEAD_DIM] = M; rec[HEAD_DIM + 1] = L; }
+    }
+}
+
+hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
+    const int nrep = a.nh / a.nkv;
+    dim3 grid(a.n_splits, a.nkv, a.B);
+    if (nrep == 1) hipLaunchKernelGGL(k_attn_decode<1>, grid, dim3(256), 0, st, a);
+    else if (nrep == 2) hipLaunchKernelGGL(k_attn_decode<2>, grid, dim3(256), 0, st, a);
+    else if (nrep == 4) hipLaunchKernelGGL(k_attn_decode<4>, grid, dim3(256), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// merge the split partials: out[b][h*128+d] = Σ_s A_s[d] e^{m_s-M} / Σ_s l_s e^{m_s-M}
+__global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float* rec = a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE;
+    float M = -INFINITY;
+    for (int s = 0; s < a.n_splits; ++s) M = fmaxf(M, rec[s * PART_STRIDE + HEAD_DIM]);
+    float L = 0.0f, A = 0.0f;
+    for (int s = 0; s < a.n_splits; ++s) {
+        const float ms = rec[s * PART_STRIDE + HEAD_DIM];
+        const float wgt = ms == -INFINITY ? 0.0f : expf(ms - M);
+        L += rec[s * PART_STRIDE + HEAD_DIM + 1] * wgt;
+        A += rec[s * PART_STRIDE + d] * wgt;
+    }
+    a.out[(size_t)b * a.ld_out + h * HEAD_DIM + d] = A / L;
+}
+
+hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_attn_merge, dim3(a.nh, a.B), dim3(128), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// gathers / frame glue
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_rows_bf16(const uint16_t* table, const uint32_t* ids, float* out, int dim) {
+    const size_t r = blockIdx.x;
+    const uint16_t* src = table + (size_t)ids[r] * dim;
+    for (int c = threadIdx.x; c < dim; c += 256) out[r * dim + c] = bf16_to_f32(src[c]);
+}
+hipError_t launch_gather_rows_bf16(const uint16_t* table, const uint32_t* ids, float* out, int n_rows, int dim,
+                                   hipStream_t st) {
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_rows_bf16, dim3(n_rows), dim3(256), 0, st, table, ids, out, dim);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_assemble_rows(const float* rows, const int* text_row, const uint16_t* codec_emb,
+                                                       const int* codec_id, const float* xvec, float* out, int H) {
+    const size_t i = blockIdx.x;
+    const int tr = text_row[i], cid = codec_id[i];
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float v;
+        const float cv = cid >= 0 ? bf16_to_f32(codec_emb[(size_t)cid * H + c]) : (cid == -2 ? xvec[c] : 0.0f);
+        if (tr >= 0 && cid != -1) v = rows[(size_t)tr * H + c] + cv;       // text.add(codec)  (talker.rs:480, 782)
+        else if (tr >= 0) v = rows[(size_t)tr * H + c];
+        else v = cv;
+        out[i * H + c] = v;
+    }
+}
+hipError_t launch_assemble_rows(const float* rows, const int* text_row, const uint16_t* codec_emb, const int* codec_id,
+                                const float* xvec, float* out, int n, int H, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assemble_rows, dim3(n), dim3(256), 0, st, rows, text_row, codec_emb, codec_id, xvec, out, H);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_copy_rows(const float* src, int lds, float* dst, int ldd, int cols) {
+    const size_t r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += 256) dst[r * ldd + c] = src[r * lds + c];
+}
+hipError_t launch_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_rows, dim3(rows), dim3(256), 0, st, src, lds, dst, ldd, cols);
+    return hipGetLastError();
+}
+
+// Code-predictor input of pass p (code_predictor.rs:337-345, 386-396): pass 0 = talker hidden,
+// pass 1 = semantic embedding, pass p>=2 = embedding (table p-2) of argmax(previous pass logits);
+// the argmax'd code is also recorded as codes[b][frame][p-1].
+__global__ __launch_bounds__(256) void k_cp_gather(CpGatherArgs a) {
+    __shared__ float red_v[4]; __shared__ int red_i[4];
+    const int b = blockIdx.x;
+    float* out = a.out + (size_t)b * a.ld_out;
+    if (a.pass == 0) {
+        const float* src = a.last_hidden + (size_t)b * a.H;
+        for (int c = threadIdx.x; c < a.H; c += 256) out[c] = src[c];
+        return;
+    }
+    const uint16_t* src;
+    if (a.pass == 1) {
+        src = a.codec_emb + (size_t)a.tok[b] * a.H;
+    } else {
+        const int code = block_argmax_first(a.cp_logits + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
+        if (threadIdx.x == 0) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)code;
+        src = a.cp_emb + (size_t)code * a.H;
+    }
+    for (int c = threadIdx.x; c < a.H; c += 256) out[c] = bf16_to_f32(src[c]);
+}
+hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_cp_gather, dim3(a.B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// lib.rs:605-622 + code_predictor.rs:497-519: record the frame's 16 codes and build the next talker
+// input = semantic_embed + ((e0+e1)+…+e14) + (trailing_text[frame] | tts_pad).
+__global__ __launch_bounds__(256) void k_frame_embed(FrameEmbedArgs a) {
+    __shared__ float red_v[4]; __shared__ int red_i[4];
+    __shared__ uint32_t codes_s[16];
+    const int b = blockIdx.x;
+    const int f = a.frame_idx[b];
+    uint32_t* frame = a.codes + ((size_t)b * a.max_frames + f) * 16;
+    const int last = block_argmax_first(a.cp_logits_last + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
+    if (threadIdx.x == 0) {
+        frame[0] = a.tok[b];
+        frame[a.n_acoustic] = (uint32_t)last;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) codes_s[threadIdx.x] = frame[threadIdx.x];
+    __syncthreads();
+    const int H = a.H;
+    const int row = f < a.trail_len[b] ? a.trail_base[b] + f : a.pad_row[b];
+    const float* text = a.text_rows + (size_t)row * H;
+    const uint16_t* sem = a.codec_emb + (size_t)codes_s[0] * H;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float acc = bf16_to_f32(a.cp_embs[0][(size_t)codes_s[1] * H + c]);
+        for (int g = 1; g < a.n_acoustic; ++g) acc = __fadd_rn(acc, bf16_to_f32(a.cp_embs[g][(size_t)codes_s[1 + g] * H + c]));
+        const float summed = __fadd_rn(bf16_to_f32(sem[c]), acc);
+        a.out[(size_t)b * H + c] = __fadd_rn(summed, text[c]);
+    }
+}
+hipError_t launch_frame_embed(const FrameEmbedArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_embed, dim3(a.B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// On-device sampler: penalties (lib.rs:1271-1322) → temperature → top-k → top-p → softmax →
+// inverse-CDF multinomial (sampling.rs:140-319), one 1024-thread workgroup per sequence.
+// Exactness plan: a full bitonic sort of (value desc, index asc) in LDS gives the oracle's sorted
+// order; every floating-point SUM the reference does sequentially (top-p softmax/cumsum over the
+// sorted row, final softmax/cdf in index order) is done sequentially by one lane over the kept
+// entries only (the dropped ones contribute exact zeros), so ids are bit-exact up to expf ulps.
+// ------------------------------------------------------------------------------------------------
+constexpr int SAMPLE_THREADS = 1024;
+constexpr int SAMPLE_MAX = 4096;
+
+__device__ __forceinline__ bool sort_before(float av, int ai, float bv, int bi) {
+    return av > bv || (av == bv && ai < bi);
+}
+
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
+    __shared__ float s_val[SAMPLE_MAX];
+    __shared__ float s_oval[SAMPLE_MAX];
+    __shared__ uint16_t s_idx[SAMPLE_MAX];
+    __shared__ uint16_t s_oidx[SAMPLE_MAX];
+    __shared__ float red_v[SAMPLE_THREADS / 64];
+    __shared__ int red_i[SAMPLE_THREADS / 64];
+    __shared__ int s_keep, s_cut, s_pick;
+
+    const int b = blockIdx.x, tid = threadIdx.x, V = a.vocab;
+    const float* lg = a.logits + (size_t)b * a.ld;
+    uint8_t* seen = a.seen ? a.seen + (size_t)b * V : nullptr;
+    const int tc = a.token_count ? a.token_count[b] : a.token_count_static;
+    int n_sort = 2; while (n_sort < V) n_sort <<= 1;
+
+    if (a.logits_hist && tc < a.hist_cap) {
+        float* dst = a.logits_hist + (size_t)b * a.hist_stride_b + (size_t)tc * V;
+        for (int i = tid; i < V; i += SAMPLE_THREADS) dst[i] = lg[i];
+    }
+    // penalties + temperature
+    for (int i = tid; i < n_sort; i += SAMPLE_THREADS) {
+        float v = -INFINITY;
+        if (i < V) {
+            v = lg[i];
+            if (a.use_rep && seen && seen[i]) v = __fmul_rn(v, v > 0.0f ? a.rep_inv : a.rep_pen);
+            if (a.use_suppress && i >= V - 1024 && i != a.codec_eos) v = -INFINITY;
+            if (tc < a.min_new_tokens && i == a.eos_id) v = -INFINITY;
+            if (a.apply_temp) v = __fadd_rn(__fmul_rn(v, a.inv_temp), 0.0f);
+        }
+        s_val[i] = v; s_idx[i] = (uint16_t)i;
+    }
+    __syncthreads();
+
+    int pick = 0;
+    if (a.greedy) {
+        pick = block_argmax_first(s_val, V, red_v, red_i);
+    } else {
+        // bitonic sort, descending by (value, then ascending index)
+        for (int k = 2; k <= n_sort; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (n_sort >> 1); t += SAMPLE_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int p = i + j;
+                    const float av = s_val[i], bv = s_val[p];
+                    const int ai = s_idx[i], bi = s_idx[p];
+                    const bool desc = (i & k) == 0;
+                    const bool swap = desc ? sort_before(bv, bi, av, ai) : sort_before(av, ai, bv, bi);
+                    if (swap) { s_val[i] = bv; s_val[p] = av; s_idx[i] = (uint16_t)bi; s_idx[p] = (uint16_t)ai; }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) { s_keep = 0; }
+        __syncthreads();
+        if (a.top_k > 0) {
+            const int k = a.top_k < V ? a.top_k : V;
+            const float thr = s_val[k - 1];
+            int cnt = 0;
+            for (int i = tid; i < V; i += SAMPLE_THREADS) cnt += (s_val[i] >= thr) ? 1 : 0;
+            if (cnt) atomicAdd(&s_keep, cnt);
+        } else if (tid == 0) {
+            s_keep = V;
+        }
+        __syncthreads();
+        const int n_keep = s_keep;
+        if (tid == 0) {
+            int cut = n_keep;
+            if (a.use_top_p) {
+                const float mx = s_val[0];
+                float sum = 0.0f;
+                for (int i = 0; i < n_keep; ++i) { const float e = expf(s_val[i] - mx); s_oval[i] = e; sum += e; }
+                float cum = 0.0f;
+                for (int i = 0; i < n_keep; ++i) {
+                    cum += s_oval[i] / sum;
+                    if (cum > a.top_p) { cut = i + 1; break; }
+                }
+            }
+            s_cut = cut;
+        }
+        __syncthreads();
+        const int cut = s_cut;
+        // order the kept entries by vocabulary index
+        for (int i = tid; i < cut; i += SAMPLE_THREADS) {
+            const int me = s_idx[i];
+            int rank = 0;
+            for (int j = 0; j < cut; ++j) rank += (s_idx[j] < me) ? 1 : 0;
+            s_oval[rank] = s_val[i];     // safe: s_oval[] temporaries of the top-p pass are dead
+            s_oidx[rank] = (uint16_t)me;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float mx = s_val[0];
+            float sum = 0.0f;
+            for (int r = 0; r < cut; ++r) sum += expf(s_oval[r] - mx);
+            const float u = a.u[(size_t)b * a.u_stride + (a.draw_idx ? a.draw_idx[b] : 0)];
+            float cdf = 0.0f; int pk = 0;
+            for (int r = 0; r < cut; ++r) {
+                cdf += expf(s_oval[r] - mx) / sum;
+                if (cdf >= u) { pk = s_oidx[r]; break; }
+            }
+            s_pick = pk;
+        }
+        __syncthreads();
+        pick = s_pick;
+    }
+    if (tid == 0) {
+        a.tok[b] = (uint32_t)pick;
+        if (seen && pick < V) seen[pick] = 1;
+        if (a.token_count) a.token_count[b] = tc + 1;
+        if (a.advance) { a.frame_idx[b] += 1; a.pos[b] += 1; }
+    }
+}
+
+hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
+    if (a.vocab > SAMPLE_MAX || a.vocab < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sample, dim3(a.B), dim3(SAMPLE_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace q3

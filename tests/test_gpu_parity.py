@@ -1,0 +1,317 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs. Tolerances are stated per test; ids must be bit-exact except at oracle
+near-ties (top-2 logit margin below MARGIN_EPS), which are reported and bounded."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import qwen3_tts_rs_amd as q
+from qwen3_tts_rs_amd import synth
+import oracle as O
+from common import model_pair, synthetic_prompt, top2_margin, rel_err
+
+pytestmark = pytest.mark.gpu
+
+MARGIN_EPS = 2e-3      # a GPU/CPU id mismatch is tolerated only if the oracle's top-2 margin is below this
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _dump(name, obj):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, name), "w") as f:
+        json.dump(obj, f, indent=1)
+
+
+# ---------------------------------------------------------------- ops
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (1, 1000, 1024), (2, 4096, 2048), (4, 2048, 6144), (8, 3072, 2048),
+                                   (8, 1024, 3072), (3, 520, 136), (5, 12288, 2048), (11, 256, 512)])
+def test_linear_matches_oracle(M, N, K):
+    rng = np.random.default_rng(M * 1000 + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = synth.f32_to_bf16((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(N).astype(np.float32)
+    y = q.linear(x, w, b)
+    wf = synth.bf16_to_f32(w).reshape(N, K)
+    yo = np.zeros((M, N), dtype=np.float32)
+    O.olib.q3o_linear(O.ptr(x), O.ptr(np.ascontiguousarray(wf)), O.ptr(b), O.ptr(yo), M, N, K)
+    ref64 = x.astype(np.float64) @ wf.astype(np.float64).T + b
+    # f32 accumulation in a different order: both sides within 2e-5 (relative to max |y|) of the f64 result
+    assert rel_err(y, ref64) < 2e-5 and rel_err(yo, ref64) < 2e-5
+    assert rel_err(y, yo) < 2e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1024), (1, 2048), (4, 2048), (3, 96), (2, 4100)])
+def test_fused_residual_rmsnorm_f32(rows, cols):
+    rng = np.random.default_rng(rows * 7 + cols)
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    r = rng.standard_normal((rows, cols)).astype(np.float32)
+    w = (1 + 0.02 * rng.standard_normal(cols)).astype(np.float32)
+    n, s = q.fused_residual_rmsnorm(x, r, w, 1e-6)
+    no = np.zeros_like(x); so = np.zeros_like(x)
+    O.olib.q3o_fused_residual_rmsnorm(O.ptr(x), O.ptr(r), O.ptr(w), rows, cols, 1e-6, O.ptr(no), O.ptr(so))
+    assert (s == so).all()                       # the sum is a single f32 add: bit-exact
+    assert np.abs(n - no).max() <= 4e-6          # normalisation differs only by the Σx² order
+
+
+def test_fused_residual_rmsnorm_bf16():
+    rng = np.random.default_rng(5)
+    rows, cols = 2, 2048
+    x = synth.f32_to_bf16(rng.standard_normal((rows, cols)).astype(np.float32)).reshape(rows, cols)
+    r = synth.f32_to_bf16(rng.standard_normal((rows, cols)).astype(np.float32)).reshape(rows, cols)
+    w = synth.f32_to_bf16((1 + 0.02 * rng.standard_normal(cols)).astype(np.float32))
+    n, s = q.fused_residual_rmsnorm(x, r, w, 1e-6)
+    xf, rf, wf = synth.bf16_to_f32(x), synth.bf16_to_f32(r), synth.bf16_to_f32(w)
+    sf = (xf + rf)
+    s_ref = synth.f32_to_bf16(sf).reshape(rows, cols)
+    assert (s == s_ref).all()                    # kernels/fused_residual_rmsnorm.cu: sum stored rounded to T
+    sr = synth.bf16_to_f32(s_ref).reshape(rows, cols)
+    den = np.sqrt((sf.reshape(rows, cols).astype(np.float64) ** 2).mean(axis=1, keepdims=True) + 1e-6)
+    n_ref = sr / den * wf
+    assert np.abs(synth.bf16_to_f32(n).reshape(rows, cols) - n_ref).max() <= 2e-2   # one bf16 ulp at |x|<=4
+
+
+# ---------------------------------------------------------------- sampler
+def _oracle_sample(logits, seen, opts, token_count, u_seed):
+    """penalties + sample with the oracle; returns (token, u) where u is the draw it consumed."""
+    import ctypes
+    lg = np.array(logits, dtype=np.float32)
+    V = lg.shape[0]
+    if token_count >= 0:
+        O.olib.q3o_apply_penalties(O.ptr(lg), V, O.ptr(seen), float(opts.repetition_penalty), token_count,
+                                   opts.min_new_tokens, -1 if opts.eos_token_id is None else opts.eos_token_id)
+    st = ctypes.c_uint64(); O.olib.q3o_rng_seed(u_seed, ctypes.byref(st))
+    st2 = ctypes.c_uint64(st.value)
+    u = O.olib.q3o_rng_next(ctypes.byref(st2))
+    tok = O.olib.q3o_sample(O.ptr(lg), V, float(opts.temperature), opts.top_k, float(opts.top_p), ctypes.byref(st))
+    return tok, u
+
+
+@pytest.mark.parametrize("temp,top_k,top_p,rep", [(0.9, 50, 0.9, 1.05), (0.0, 50, 0.9, 1.05), (1.0, 0, 1.0, 1.0),
+                                                  (0.7, 10, 0.5, 1.5), (1.3, 0, 0.8, 1.05), (0.9, 3072, 0.99, 2.0),
+                                                  (0.5, 1, 0.9, 1.0)])
+def test_sampler_ids_bit_exact(temp, top_k, top_p, rep):
+    V, rows = 3072, 64
+    rng = np.random.default_rng(int(temp * 100) + top_k)
+    opts = q.SynthesisOptions(temperature=temp, top_k=top_k, top_p=top_p, repetition_penalty=rep, seed=1)
+    logits = (3.5 * rng.standard_normal((rows, V))).astype(np.float32)
+    logits[0] = (5.0 * np.sin(0.1 * np.arange(V))).astype(np.float32)       # benches/sampling.rs:12-17 pattern
+    logits[1, :100] = 2.0                                                    # exact ties straddling top-k
+    seen = (rng.random((rows, V)) < 0.05).astype(np.uint8)
+    us = np.zeros(rows, dtype=np.float32); ref = np.zeros(rows, dtype=np.uint32)
+    for r in range(rows):
+        ref[r], us[r] = _oracle_sample(logits[r], seen[r], opts, 1, 100 + r)
+    got = q.sample(logits, us, opts, seen=seen, token_count=1)
+    bad = np.nonzero(got != ref)[0]
+    assert len(bad) == 0, f"rows {bad[:8]} differ: gpu {got[bad[:8]]} oracle {ref[bad[:8]]}"
+
+
+def test_sampler_reference_kats_small_vocab():
+    """The reference's own sampler unit tests (sampling.rs:473-624), on the device sampler."""
+    g = q.SynthesisOptions(temperature=0.001)
+    assert q.sample(np.array([[1.0, 2.0, 5.0, 1.0]], np.float32), np.zeros(1, np.float32), g)[0] == 2
+    assert list(q.sample(np.array([[1.0, 5.0, 2.0], [3.0, 1.0, 2.0], [1.0, 2.0, 10.0]], np.float32), np.zeros(3, np.float32), g)) == [1, 0, 2]
+    assert q.sample(np.array([[1.0, 10.0, 2.0, 1.0]], np.float32), np.zeros(1, np.float32), g)[0] == 1
+    # multinomial with a one-hot distribution always picks that index (sampling.rs:601-609)
+    o = q.SynthesisOptions(temperature=1.0, top_k=0, top_p=1.0)
+    lg = np.array([[-np.inf, 0.0, -np.inf, -np.inf]], np.float32)
+    for u in (0.0, 0.3, 0.999, 1.0):
+        assert q.sample(lg, np.array([u], np.float32), o)[0] == 1
+
+
+# ---------------------------------------------------------------- model-level
+@pytest.fixture(scope="module", params=["tiny", "tiny_same_width"])
+def pair(request):
+    cfg = q.tiny() if request.param == "tiny" else q.tiny_same_width()
+    gm, om = model_pair(cfg, seed=1234)
+    yield cfg, gm, om
+    gm.close(); om.close()
+
+
+def _utts(mode, n_text=9, index=0, hidden=64):
+    text = synthetic_prompt(n_text, index)
+    if mode == "custom":
+        return q.Utterance(text, q.Speaker.Ryan, q.Language.English, seed=42 + index)
+    if mode == "design":
+        return q.Utterance(text, language=q.Language.German, instruct_ids=synthetic_prompt(7, 50 + index), seed=42 + index)
+    rng = np.random.default_rng(index)
+    return q.Utterance(text, language=q.Language.French, xvector=rng.standard_normal(hidden).astype(np.float32), seed=42 + index)
+
+
+@pytest.mark.parametrize("mode", ["custom", "design", "clone"])
+@pytest.mark.parametrize("n_text", [0, 1, 9])
+def test_prefill_stages(pair, mode, n_text):
+    cfg, gm, om = pair
+    utt = _utts(mode, n_text, hidden=cfg.hidden)
+    opts = q.SynthesisOptions(max_length=4, seed=42)
+    s = gm.session([utt], opts); s.prefill()
+    osess = O.OracleSession(om, utt, opts)
+    S, Ttr = s.prefill_len(0)
+    assert S == osess.prefill_len()
+    emb = s.get(0, (S, cfg.hidden)); oemb = osess.prefill_embeds()
+    assert np.abs(emb - oemb).max() <= 2e-5 * max(1.0, np.abs(oemb).max())
+    otr, opad = osess.trailing()
+    assert Ttr == otr.shape[0]
+    tr = s.get(3, (Ttr, cfg.hidden)); pad = s.get(4, (cfg.hidden,))
+    assert np.abs(tr - otr).max() <= 2e-5 * max(1.0, np.abs(otr).max())
+    assert np.abs(pad - opad).max() <= 2e-5 * max(1.0, np.abs(opad).max())
+    hid = s.get(1, (cfg.hidden,)); lg = s.get(2, (cfg.codec_vocab,))
+    ohid, olg = osess.prefill_out()
+    assert np.abs(hid - ohid).max() <= 1e-4, np.abs(hid - ohid).max()
+    assert np.abs(lg - olg).max() <= 1e-3, np.abs(lg - olg).max()
+    s.close(); osess.close()
+
+
+def test_teacher_forced_steps(pair):
+    cfg, gm, om = pair
+    utt = _utts("custom", 9, hidden=cfg.hidden)
+    opts = q.SynthesisOptions(max_length=8, seed=42)
+    s = gm.session([utt], opts); s.prefill()
+    osess = O.OracleSession(om, utt, opts)
+    rng = np.random.default_rng(3)
+    ohid, _ = osess.prefill_out()
+    for step in range(4):
+        sem = rng.standard_normal(cfg.hidden).astype(np.float32)
+        ocodes, ocl = osess.cp_generate(ohid, sem)
+        codes, cl = s.cp_generate(ohid[None], sem[None])
+        assert np.abs(cl[0] - ocl).max() <= 2e-3, (step, np.abs(cl[0] - ocl).max())
+        for g in range(15):
+            if codes[0, g] != ocodes[g]:
+                assert top2_margin(ocl[g]) < MARGIN_EPS, (step, g, codes[0, g], ocodes[g], top2_margin(ocl[g]))
+                break
+        emb = rng.standard_normal(cfg.hidden).astype(np.float32)
+        ohid, olg = osess.talker_step(emb)
+        hid, lg = s.talker_step(emb[None])
+        assert np.abs(hid[0] - ohid).max() <= 2e-4, (step, np.abs(hid[0] - ohid).max())
+        assert np.abs(lg[0] - olg).max() <= 2e-3, (step, np.abs(lg[0] - olg).max())
+    s.close(); osess.close()
+
+
+def _free_run_compare(cfg, gm, om, utt, opts, use_graph, tag):
+    s = gm.session([utt], opts, debug=not use_graph); s.prefill()
+    s.generate(opts.max_length, use_graph=use_graph)
+    codes = s.codes(0)
+    osess = O.OracleSession(om, utt, opts)
+    ocodes, otl, ocl = osess.generate(capture=True)
+    n = min(len(codes), len(ocodes))
+    first_div = None
+    for f in range(n):
+        if not (codes[f] == ocodes[f]).all():
+            first_div = f; break
+    report = {"tag": tag, "frames_gpu": int(len(codes)), "frames_oracle": int(len(ocodes)), "first_divergence": first_div}
+    if first_div is None and len(codes) != len(ocodes):
+        first_div = n
+    if first_div is not None:
+        # a divergence is acceptable only at an oracle near-tie: find the deciding margin
+        f = first_div
+        margins = []
+        if f < len(ocodes):
+            g = int(np.nonzero(codes[f] != ocodes[f])[0][0]) if f < len(codes) else 0
+            margins.append(top2_margin(otl[f]) if g == 0 else top2_margin(ocl[f][g - 1]))
+        report["margin_at_divergence"] = margins
+        _dump(f"divergence_{tag}.json", report)
+        assert margins and margins[0] < MARGIN_EPS, report
+    s.close(); osess.close()
+    return report, codes, ocodes
+
+
+@pytest.mark.parametrize("sampling", ["greedy", "default"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_free_run_codes_bit_exact_tiny(pair, sampling, use_graph):
+    cfg, gm, om = pair
+    utt = _utts("custom", 20, hidden=cfg.hidden)
+    opts = q.SynthesisOptions(max_length=24, seed=42, eos_token_id=None) if sampling == "default" else \
+        q.SynthesisOptions(max_length=24, temperature=0.0, seed=42, eos_token_id=None)
+    rep, codes, ocodes = _free_run_compare(cfg, gm, om, utt, opts, use_graph, f"{cfg.name}_{sampling}_{int(use_graph)}")
+    assert rep["first_divergence"] is None, rep
+    assert (codes == ocodes).all()
+
+
+def test_eos_and_min_new_tokens(pair):
+    """EOS handling: frame whose semantic token is EOS is never emitted (lib.rs:581-585); frame counts
+    match the oracle with the default eos id."""
+    cfg, gm, om = pair
+    for idx in range(3):
+        utt = _utts("custom", 5, index=idx, hidden=cfg.hidden)
+        opts = q.SynthesisOptions(max_length=40, temperature=1.3, top_k=0, top_p=1.0, seed=7 + idx)
+        s = gm.session([utt], opts); s.prefill(); s.generate(40, use_graph=True)
+        codes = s.codes(0)
+        osess = O.OracleSession(om, utt, opts); ocodes = osess.generate()
+        assert len(codes) == len(ocodes) and (codes == ocodes).all()
+        assert not (codes[:, 0] == q.CODEC_EOS_TOKEN_ID).any()
+        s.close(); osess.close()
+
+
+def test_batch_equals_single(pair):
+    """Every sequence of a batch behaves exactly like its own batch-1 run (bit-exact codes)."""
+    cfg, gm, om = pair
+    utts = [_utts("custom", 11, index=i, hidden=cfg.hidden) for i in range(5)]
+    opts = q.SynthesisOptions(max_length=12, seed=1, eos_token_id=None)
+    sb = gm.session(utts, opts); sb.prefill(); sb.generate(12, use_graph=True)
+    for i, u in enumerate(utts):
+        s1 = gm.session([u], opts); s1.prefill(); s1.generate(12, use_graph=False)
+        assert (sb.codes(i) == s1.codes(0)).all(), i
+        s1.close()
+    sb.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 10])
+def test_decoder_stages_and_pcm(pair, T):
+    cfg, gm, om = pair
+    rng = np.random.default_rng(T)
+    codes = rng.integers(0, 2048, size=(T, 16)).astype(np.uint32)
+    codes[:, 0] = rng.integers(0, 3072, size=T)          # semantic ids use the 3072 vocab (mod 2048 in the decoder)
+    opcm, otaps = om.decode(codes, taps=True)
+    taps = [np.zeros_like(t) for t in otaps]
+    pcm = gm.decode_codes(codes, taps=taps).samples
+    names = ["quant", "pre_conv", "pre_transformer", "up0", "up1", "init", "blk0", "blk1", "blk2", "blk3"]
+    for nme, a, b in zip(names, taps, otaps):
+        e = np.abs(a - b).max() / (np.abs(b).max() + 1e-9)
+        assert e <= 2e-4, (nme, e)
+    rms = float(np.sqrt(np.mean((pcm - opcm) ** 2)))
+    assert rms <= 1e-3, rms                                # north-star tolerance: PCM within 1e-3 RMS
+    assert pcm.shape[0] == T * 1920
+
+
+def test_streaming_chunks(pair):
+    cfg, gm, om = pair
+    utt = _utts("custom", 9, hidden=cfg.hidden)
+    opts = q.SynthesisOptions(max_length=25, seed=42, eos_token_id=None, chunk_frames=10)
+    ss = gm.synthesize_streaming(utt.text_ids, utt.speaker, utt.language, opts)
+    chunks = list(ss)
+    assert [len(c) for c in chunks] == [19200, 19200, 9600]
+    # each chunk is decoded context-free (lib.rs:1755-1758): equals decoding those frames alone
+    s = gm.session([q.Utterance(utt.text_ids, utt.speaker, utt.language)], opts); s.prefill(); s.generate(25)
+    codes = s.codes(0)
+    osess = O.OracleSession(om, q.Utterance(utt.text_ids, utt.speaker, utt.language), opts); ocodes = osess.generate()
+    assert (codes == ocodes).all()
+    ref = om.decode(ocodes[10:20])
+    assert float(np.sqrt(np.mean((chunks[1].samples - ref) ** 2))) <= 1e-3
+    s.close(); osess.close()
+
+
+def test_frame_embed_exact(pair):
+    cfg, gm, om = pair
+    rng = np.random.default_rng(9)
+    for _ in range(4):
+        sem = int(rng.integers(0, 3072)); codes = rng.integers(0, 2048, 15).astype(np.uint32)
+        t = rng.standard_normal(cfg.hidden).astype(np.float32)
+        assert (gm.frame_embed(sem, codes, t) == om.frame_embed(sem, codes, t)).all()   # pure f32 adds: bit-exact
+
+
+# ---------------------------------------------------------------- full-size shapes
+@pytest.mark.parametrize("size", ["0.6b", "1.7b"])
+def test_full_size_frames(size):
+    cfg = q.qwen3_tts_0_6b() if size == "0.6b" else q.qwen3_tts_1_7b()
+    gm, om = model_pair(cfg, seed=synth.DEFAULT_SEED)
+    utt = q.Utterance(synthetic_prompt(32, 0), seed=42)
+    opts = q.SynthesisOptions(max_length=6, seed=42, eos_token_id=None)
+    rep, codes, ocodes = _free_run_compare(cfg, gm, om, utt, opts, False, f"full_{size}")
+    _dump(f"full_{size}.json", rep)
+    if rep["first_divergence"] is None:
+        pcm = gm.decode_codes(codes).samples
+        opcm = om.decode(ocodes)
+        rms = float(np.sqrt(np.mean((pcm - opcm) ** 2)))
+        assert rms <= 1e-3, rms
+    gm.close(); om.close()
