@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — RTF / acoustic-frames-per-second of the MI355X-native Qwen3-TTS hot path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under
+torch.distributed.run, one rank per GPU. Prints ONE JSON line on rank 0.
+
+A "step" = one non-streaming synthesis (prefill → generate → decode, the reference's
+`synthesize_with_timing`, lib.rs:425-501 / benches/e2e_bench.rs:207-262) of this rank's batch of
+utterances: synthetic 512-token prompts, CustomVoice prefill, eos_token_id = None and a fixed frame
+count so the work is identical across engines, default sampling (temperature 0.9, top-k 50, top-p
+0.9, repetition penalty 1.05, seed 42 + utterance index) — SURVEY.md §8(d).
+Weak scaling: every GPU gets `--batch` utterances (config[3] of BASELINE.json: 64 utterances over 8
+GPUs = 8 per GPU); value = frames of ALL ranks / max-over-ranks time.
+
+Extra objects: "roofline" (dominant kernel = the bf16 GEMV family: algorithmic weight bytes per
+launch ÷ launch duration measured with HIP events on the session stream) and "cpu_baseline" (the
+C oracle = port of the reference's candle-CPU F32 path, timed on this host's cores on a bounded
+sample of the same workload; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="1.7b", choices=["1.7b", "0.6b", "tiny"])
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=640, help="frames generated per utterance (eos disabled)")
+    ap.add_argument("--prompt-tokens", type=int, default=512)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--profile-frames", type=int, default=6)
+    ap.add_argument("--ttfa-reps", type=int, default=5)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import qwen3_tts_rs_amd as q
+    from qwen3_tts_rs_amd import dp, synth
+
+    rank, local_rank, world = dp.env_rank()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = local_rank
+    if world > 1:
+        dp.init("nccl")
+
+    cfg = {"1.7b": q.qwen3_tts_1_7b, "0.6b": q.qwen3_tts_0_6b, "tiny": q.tiny}[args.model]()
+
+    # ---- weights: rank 0 builds the synthetic checkpoint; one RCCL broadcast of the arena ----
+    t_load = time.time()
+    oracle_sink = []
+    if rank == 0:
+        model = q.Qwen3TTS.from_synthetic(cfg, device=dev, seed=synth.DEFAULT_SEED)
+    else:
+        model = q.Qwen3TTS(cfg, device=dev)
+    bcast_bytes = 0
+    if world > 1:
+        t_b = time.time()
+        bcast_bytes = dp.broadcast_arena(model, dev)
+        bcast_s = time.time() - t_b
+        if rank != 0:
+            model.mark_loaded(); model.finalize()
+    else:
+        bcast_s = 0.0
+    load_s = time.time() - t_load
+
+    # ---- workload ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import synthetic_prompt
+    B = args.batch
+    n_total = B * world
+    my_idx = dp.shard_indices(n_total, rank, world)
+    utts = [q.Utterance(synthetic_prompt(args.prompt_tokens, i), q.Speaker.Ryan, q.Language.English, seed=42 + i) for i in my_idx]
+    opts = q.SynthesisOptions(max_length=args.frames, eos_token_id=None, seed=42)
+    use_graph = not args.no_graph
+
+    def one_step():
+        s = model.session(utts, opts)
+        try:
+            return s.run_timing_only(use_graph=use_graph)
+        finally:
+            s.close()
+
+    for _ in range(args.warmup):
+        one_step()
+    dp.barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    timings = [one_step() for _ in range(args.steps)]
+    torch.cuda.synchronize(dev); dp.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = dp.max_over_ranks(elapsed, device=f"cuda:{dev}" if world > 1 else None)
+    frames_rank = sum(t.generation_frames for t in timings)
+    frames_total = dp.sum_over_ranks(float(frames_rank), device=f"cuda:{dev}" if world > 1 else None)
+
+    if rank != 0:
+        return
+
+    ms_per_step = elapsed / args.steps * 1000.0
+    fps = frames_total / elapsed
+    audio_s_per_utt = args.frames * cfg.samples_per_frame / 24000.0
+    rtf_job = (elapsed / args.steps) / (audio_s_per_utt * n_total)      # wall per second of audio, whole job
+    rtf_utt = (elapsed / args.steps) / audio_s_per_utt                  # latency view: each utterance's RTF
+    stage = {"prefill_ms": float(np.mean([t.prefill_ms for t in timings])),
+             "generation_ms": float(np.mean([t.generation_ms for t in timings])),
+             "decode_ms": float(np.mean([t.decode_ms for t in timings]))}
+
+    # ---- roofline of the dominant kernel (bf16 GEMV family), HIP events on the session stream ----
+    s = model.session(utts, q.SynthesisOptions(max_length=args.profile_frames + 2, eos_token_id=None, seed=42))
+    s.prefill()
+    s.generate(2, use_graph=False)
+    s.set_profile(True)
+    s.generate(args.profile_frames, use_graph=False)
+    ms, nbytes, launches = s.profile_read()
+    wbytes, kvbytes = s.frame_bytes(10 + args.frames // 2)
+    s.close()
+    achieved = (nbytes / (ms / 1000.0)) / 1e9 if ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": None, "kernel": "k_linear<M,R,RMS,EPI> (bf16-weight GEMV family)",
+                "launches_measured": launches, "avg_launch_us": (ms * 1000.0 / launches) if launches else None,
+                "avg_bytes_per_launch": (nbytes / launches) if launches else None,
+                "frame_weight_bytes": wbytes, "frame_kv_bytes": kvbytes,
+                "frame_model_gbps": (wbytes + kvbytes) / (stage["generation_ms"] / 1000.0 / args.frames) / 1e9}
+
+    # ---- single-utterance latency + streaming TTFA (config[2]) ----
+    lat = {}
+    try:
+        u1 = [q.Utterance(synthetic_prompt(args.prompt_tokens, 0), seed=42)]
+        f1 = min(args.frames, 160)
+        s1 = model.session(u1, q.SynthesisOptions(max_length=f1, eos_token_id=None, seed=42))
+        t1 = s1.run_timing_only(use_graph=use_graph); s1.close()
+        s1 = model.session(u1, q.SynthesisOptions(max_length=f1, eos_token_id=None, seed=42))
+        t1 = s1.run_timing_only(use_graph=use_graph); s1.close()
+        wall = (t1.prefill_ms + t1.generation_ms + t1.decode_ms) / 1000.0
+        lat = {"b1_frames": f1, "b1_frames_per_s": f1 / wall, "b1_rtf": wall / (f1 * 0.08), "b1_prefill_ms": t1.prefill_ms,
+               "b1_ms_per_frame": t1.generation_ms / f1, "b1_decode_ms": t1.decode_ms}
+        ttfa = []
+        for _ in range(args.ttfa_reps):
+            ta = time.perf_counter()
+            ss = model.synthesize_streaming(u1[0].text_ids, q.Speaker.Ryan, q.Language.English,
+                                            q.SynthesisOptions(max_length=30, eos_token_id=None, seed=42, chunk_frames=10))
+            ss.next_chunk()
+            ttfa.append((time.perf_counter() - ta) * 1000.0)
+            ss._s.close()
+        lat["ttfa_ms_p50"] = float(np.median(ttfa))
+    except Exception as e:   # latency extras must never kill the headline line
+        lat["error"] = str(e)
+
+    # ---- CPU baseline: the oracle (port of the candle-CPU F32 path) on this host, bounded sample ----
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            import oracle as O
+            from common import oracle_model
+            t_o = time.time()
+            om = oracle_model(cfg, synth.DEFAULT_SEED, which=3)
+            o_load = time.time() - t_o
+            ncores = os.cpu_count() or 1
+            utt0 = q.Utterance(synthetic_prompt(args.prompt_tokens, 0), seed=42)
+            oo = q.SynthesisOptions(max_length=args.cpu_frames, eos_token_id=None, seed=42)
+            tc = time.perf_counter()
+            osess = O.OracleSession(om, utt0, oo)
+            codes = osess.generate()
+            pcm = om.decode(codes)
+            cpu_wall = time.perf_counter() - tc
+            osess.close(); om.close()
+            cpu = {"value": len(codes) / cpu_wall, "unit": "frames/s", "cores": ncores, "kind": "port",
+                   "rtf": cpu_wall / (len(codes) * 0.08),
+                   "sample": f"1 utterance, {args.prompt_tokens}-token prompt: prefill + {len(codes)} frames + vocoder "
+                             f"({cpu_wall:.1f}s wall, oracle load {o_load:.0f}s not counted); reference-published CPU: "
+                             f"2.3/2.1/1.9 frames/s, RTF 5.39-6.48 on 20 Arm cores (docs/BENCHMARKS.md:111-115)"}
+        except Exception as e:
+            cpu = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+
+    out = {
+        "metric": "acoustic_frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Qwen3-TTS-{args.model} synthetic weights; {B} utterances/GPU x {world} GPU(s), "
+                               f"{args.prompt_tokens}-token prompts, CustomVoice prefill, {args.frames} frames each "
+                               f"(eos off), default sampling, non-streaming prefill+generate+decode",
+                   "utterances_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"dp{world}",
+                   "weights": "bf16", "activations_kv": "f32", "hip_graph": use_graph},
+        "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "latency": lat,
+        "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -31,13 +31,22 @@ static int fail(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return -1;
 }
-void q3o_set_threads(int n) {
+/* Thread policy: parallel regions are used only when there is enough work (PAR_IF), and never with
+ * more than g_threads threads (default min(cores, 32)): on a 256-thread host a fork/join per tiny
+ * matmul costs far more than the matmul. Results do not depend on the thread count. */
+static int g_threads = 0;
+static int n_threads(void) {
+    if (g_threads > 0) return g_threads;
 #ifdef _OPENMP
-    if (n > 0) omp_set_num_threads(n);
+    int n = omp_get_num_procs();
+    g_threads = n > 32 ? 32 : (n < 1 ? 1 : n);
 #else
-    (void)n;
+    g_threads = 1;
 #endif
+    return g_threads;
 }
+void q3o_set_threads(int n) { if (n > 0) g_threads = n; }
+#define PAR_IF(work) if ((double)(work) > 2.0e5) num_threads(n_threads())
 
 static float* fmalloc(size_t n) {
     float* p = (float*)malloc((n ? n : 1) * sizeof(float));
@@ -67,7 +76,7 @@ static inline float dot_f32(const float* a, const float* b, int n) {
 
 /* Linear: y = x·Wᵀ (+b), W [N][K] row-major (candle_nn::Linear) */
 void q3o_linear(const float* x, const float* w, const float* b, float* y, int M, int N, int K) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) PAR_IF((double)M * N * K)
     for (int n = 0; n < N; ++n) {
         const float* wr = w + (size_t)n * K;
         for (int m = 0; m < M; ++m) {
@@ -417,7 +426,7 @@ static void layer_forward(const layer_w* L, float* x, int S, int H, int I, int n
     kv->len = offset + S;
     /* SDPA: repeat_kv (head h uses kv h / n_rep), scores * scale, +mask, softmax, ·V */
     float scale = (float)(1.0 / sqrt((double)hd));
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) PAR_IF((double)S * nh * hd * (offset + S) * 4)
     for (int s = 0; s < S; ++s)
         for (int hh = 0; hh < nh; ++hh) {
             int n_ctx = offset + s + 1;      /* S==1: all of the cache; S>1: causal mask */
@@ -825,7 +834,7 @@ int q3o_session_generate(q3o_session* s, uint32_t* codes_out, float* talker_logi
 void q3o_causal_conv1d(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L,
                        int k, int dil, int groups) {
     int cin_g = cin / groups, cout_g = cout / groups;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) PAR_IF((double)cout * cin_g * k * L)
     for (int co = 0; co < cout; ++co) {
         float* yr = y + (size_t)co * L;
         for (int t = 0; t < L; ++t) yr[t] = 0.0f;
@@ -849,7 +858,7 @@ void q3o_causal_trans_conv1d(const float* x, const float* w, const float* b, flo
                              int k, int stride) {
     int trim = k > stride ? k - stride : 0;
     int Lout = (L - 1) * stride + k - trim;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) PAR_IF((double)cout * cin * k * L)
     for (int co = 0; co < cout; ++co) {
         float* yr = y + (size_t)co * Lout;
         for (int t = 0; t < Lout; ++t) yr[t] = 0.0f;
@@ -870,7 +879,7 @@ void q3o_causal_trans_conv1d(const float* x, const float* w, const float* b, flo
 
 /* SnakeBeta::forward (snake_beta.rs:58-77): x + sin²(x·exp(α)) · 1/(exp(β)+1e-9) */
 void q3o_snake_beta(const float* x, const float* alpha, const float* beta, float* y, int C, int L) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) PAR_IF((double)C * L * 20)
     for (int c = 0; c < C; ++c) {
         float a = expf(alpha[c]);
         float ib = 1.0f / (expf(beta[c]) + (float)1e-9);
@@ -916,7 +925,7 @@ static void dec_layer_forward(const q3o_config* c, const dec_layer_w* L, float* 
             memcpy(p, tmp, (size_t)hd * sizeof(float));
         }
     float scale = (float)pow((double)hd, -0.5);
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) PAR_IF((double)T * T * nh * hd)
     for (int t = 0; t < T; ++t)
         for (int hh = 0; hh < nh; ++hh) {
             float* sc = fmalloc((size_t)t + 1);

@@ -6,7 +6,7 @@ OUT="$HERE/../libq3tts.so"
 BUILD="$HERE/../../build"
 mkdir -p "$BUILD"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -Wall -Wno-unused-function -Wno-unused-variable"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 pids=()
 for f in q3_kernels_lm q3_kernels_codec q3_engine; do
   if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/q3_kernels.h" -nt "$BUILD/$f.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/$f.o" ]; then
@@ -15,5 +15,5 @@ for f in q3_kernels_lm q3_kernels_codec q3_engine; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -fopenmp -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_engine.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_engine.o"
 echo "built $OUT"

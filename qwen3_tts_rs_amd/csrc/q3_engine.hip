@@ -18,6 +18,7 @@
 #include <chrono>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -85,14 +86,26 @@ extern "C" q3_status q3_synth_fill(uint64_t seed, const char* name, int dtype, f
     // Irwin-Hall(4) of 16-bit uniforms: exact integer sum, std = 65536/sqrt(3)
     const float c = (float)((double)scale / (65536.0 / 1.7320508075688772));
     float* of = (float*)out_host; uint16_t* ob = (uint16_t*)out_host;
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) {
-        const uint64_t z = splitmix64(key + (uint64_t)i * 0x9E3779B97F4A7C15ULL);
-        const int s = (int)(z & 0xffff) + (int)((z >> 16) & 0xffff) + (int)((z >> 32) & 0xffff) + (int)((z >> 48) & 0xffff) - 131070;
-        const float v = offset + (float)s * c;
-        if (dtype == Q3_DTYPE_BF16) ob[i] = f32_to_bf16_host(v);
-        else of[i] = v;
+    auto body = [=](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint64_t z = splitmix64(key + (uint64_t)i * 0x9E3779B97F4A7C15ULL);
+            const int s = (int)(z & 0xffff) + (int)((z >> 16) & 0xffff) + (int)((z >> 32) & 0xffff) + (int)((z >> 48) & 0xffff) - 131070;
+            const float v = offset + (float)s * c;
+            if (dtype == Q3_DTYPE_BF16) ob[i] = f32_to_bf16_host(v);
+            else of[i] = v;
+        }
+    };
+    // plain std::thread fan-out (no OpenMP runtime inside the product library)
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 2 || n < (1 << 20)) { body(0, n); return Q3_OK; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int64_t lo = (int64_t)t * per, hi = lo + per < n ? lo + per : n;
+        if (lo < hi) th.emplace_back(body, lo, hi);
     }
+    for (auto& t : th) t.join();
     return Q3_OK;
 }
 
