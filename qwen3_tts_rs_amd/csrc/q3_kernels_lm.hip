@@ -682,9 +682,13 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
             for (int r = 0; r < cut; ++r) sum += expf(s_oval[r] - mx);
             const float u = a.u[(size_t)b * a.u_stride + (a.draw_idx ? a.draw_idx[b] : 0)];
             float cdf = 0.0f; int pk = 0;
-            for (int r = 0; r < cut; ++r) {
-                cdf += expf(s_oval[r] - mx) / sum;
-                if (cdf >= u) { pk = s_oidx[r]; break; }
+            // `first i with cdf[i] >= u` over the whole vocabulary: for u > 0 that index always has
+            // non-zero probability (so scanning the kept entries is exact); for u == 0 it is index 0.
+            if (u > 0.0f) {
+                for (int r = 0; r < cut; ++r) {
+                    cdf += expf(s_oval[r] - mx) / sum;
+                    if (cdf >= u) { pk = s_oidx[r]; break; }
+                }
             }
             s_pick = pk;
         }

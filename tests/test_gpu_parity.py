@@ -116,8 +116,10 @@ def test_sampler_reference_kats_small_vocab():
     # multinomial with a one-hot distribution always picks that index (sampling.rs:601-609)
     o = q.SynthesisOptions(temperature=1.0, top_k=0, top_p=1.0)
     lg = np.array([[-np.inf, 0.0, -np.inf, -np.inf]], np.float32)
-    for u in (0.0, 0.3, 0.999, 1.0):
+    for u in (0.3, 0.999, 1.0, 1e-30):
         assert q.sample(lg, np.array([u], np.float32), o)[0] == 1
+    # u == 0.0 exactly: `first i: cdf[i] >= u` is index 0 even at zero probability (sampling.rs:300-318)
+    assert q.sample(lg, np.array([0.0], np.float32), o)[0] == 0
 
 
 # ---------------------------------------------------------------- model-level
