@@ -126,10 +126,11 @@ extern "C" void q3_codes_to_tensor(const uint32_t* frames, int n_frames, int64_t
 // ------------------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------------------
-enum SlotKind { SK_PLAIN = 0, SK_TRANSCONV = 1 };
+enum SlotKind { SK_PLAIN = 0, SK_TRANSCONV = 1, SK_TILED = 2 };
 struct Slot {
     std::string name; int64_t n = 0; int stored = Q3_DTYPE_F32; size_t offset = 0; bool loaded = false;
     int kind = SK_PLAIN; int tc_cin = 0, tc_cout = 0, tc_k = 0, tc_stride = 0;
+    int rows = 0, cols = 0;      // SK_TILED: logical [rows][cols]; stored padded to [rows↑16][cols↑32]
 };
 struct LayerW {
     const float *in_ln, *q_norm, *k_norm, *post_ln;
@@ -172,19 +173,32 @@ static void add_slot(q3_model* m, const std::string& name, int64_t n, int stored
     m->index[name] = (int)m->slots.size();
     m->slots.push_back(s);
 }
+static inline int up16(int v) { return (v + 15) & ~15; }
+static inline int up32(int v) { return (v + 31) & ~31; }
+// GEMV weight [rows][cols] bf16, stored MFMA-tiled (q3_kernels_gemv.hip); element count reported to the
+// caller stays rows*cols (the checkpoint's), the arena holds the padded tiled image.
+static void add_tiled(q3_model* m, const std::string& name, int rows, int cols, bool align = true) {
+    Slot s; s.name = name; s.n = (int64_t)rows * cols; s.stored = Q3_DTYPE_BF16; s.kind = SK_TILED; s.rows = rows; s.cols = cols;
+    size_t off = m->arena_bytes;
+    if (align) off = (off + 255) & ~(size_t)255;
+    s.offset = off;
+    m->arena_bytes = off + (size_t)up16(rows) * up32(cols) * 2;
+    m->index[name] = (int)m->slots.size();
+    m->slots.push_back(s);
+}
 static void add_layer_slots(q3_model* m, const std::string& p, int H, int I, int nh, int nkv, int hd) {
     add_slot(m, p + ".input_layernorm.weight", H, Q3_DTYPE_F32);
     // q,k,v rows are stored back to back so the fused QKV GEMV sees one [QD+2KD][H] matrix
-    add_slot(m, p + ".self_attn.q_proj.weight", (int64_t)nh * hd * H, Q3_DTYPE_BF16);
-    add_slot(m, p + ".self_attn.k_proj.weight", (int64_t)nkv * hd * H, Q3_DTYPE_BF16, false);
-    add_slot(m, p + ".self_attn.v_proj.weight", (int64_t)nkv * hd * H, Q3_DTYPE_BF16, false);
-    add_slot(m, p + ".self_attn.o_proj.weight", (int64_t)H * nh * hd, Q3_DTYPE_BF16);
+    add_tiled(m, p + ".self_attn.q_proj.weight", nh * hd, H);
+    add_tiled(m, p + ".self_attn.k_proj.weight", nkv * hd, H, false);
+    add_tiled(m, p + ".self_attn.v_proj.weight", nkv * hd, H, false);
+    add_tiled(m, p + ".self_attn.o_proj.weight", H, nh * hd);
     add_slot(m, p + ".self_attn.q_norm.weight", hd, Q3_DTYPE_F32);
     add_slot(m, p + ".self_attn.k_norm.weight", hd, Q3_DTYPE_F32);
     add_slot(m, p + ".post_attention_layernorm.weight", H, Q3_DTYPE_F32);
-    add_slot(m, p + ".mlp.gate_proj.weight", (int64_t)I * H, Q3_DTYPE_BF16);
-    add_slot(m, p + ".mlp.up_proj.weight", (int64_t)I * H, Q3_DTYPE_BF16);
-    add_slot(m, p + ".mlp.down_proj.weight", (int64_t)H * I, Q3_DTYPE_BF16);
+    add_tiled(m, p + ".mlp.gate_proj.weight", I, H);
+    add_tiled(m, p + ".mlp.up_proj.weight", I, H);
+    add_tiled(m, p + ".mlp.down_proj.weight", H, I);
 }
 static std::string fmt(const char* f, ...) {
     char b[256]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return b;
@@ -196,17 +210,17 @@ static void build_manifest(q3_model* m) {
     const q3_config& c = m->cfg;
     const int H = c.hidden, TD = c.text_dim, CH = c.cp_hidden;
     add_slot(m, "talker.model.text_embedding.weight", (int64_t)c.text_vocab * TD, Q3_DTYPE_BF16);
-    add_slot(m, "talker.text_projection.linear_fc1.weight", (int64_t)TD * TD, Q3_DTYPE_BF16);
+    add_tiled(m, "talker.text_projection.linear_fc1.weight", TD, TD);
     add_slot(m, "talker.text_projection.linear_fc1.bias", TD, Q3_DTYPE_F32);
-    add_slot(m, "talker.text_projection.linear_fc2.weight", (int64_t)H * TD, Q3_DTYPE_BF16);
+    add_tiled(m, "talker.text_projection.linear_fc2.weight", H, TD);
     add_slot(m, "talker.text_projection.linear_fc2.bias", H, Q3_DTYPE_F32);
     add_slot(m, "talker.model.codec_embedding.weight", (int64_t)c.codec_vocab * H, Q3_DTYPE_BF16);
     for (int i = 0; i < c.n_layers; ++i)
         add_layer_slots(m, fmt("talker.model.layers.%d", i), H, c.inter, c.n_heads, c.n_kv_heads, c.head_dim);
     add_slot(m, "talker.model.norm.weight", H, Q3_DTYPE_F32);
-    add_slot(m, "talker.codec_head.weight", (int64_t)c.codec_vocab * H, Q3_DTYPE_BF16);
+    add_tiled(m, "talker.codec_head.weight", c.codec_vocab, H);
     if (H != CH) {
-        add_slot(m, "talker.code_predictor.small_to_mtp_projection.weight", (int64_t)CH * H, Q3_DTYPE_BF16);
+        add_tiled(m, "talker.code_predictor.small_to_mtp_projection.weight", CH, H);
         add_slot(m, "talker.code_predictor.small_to_mtp_projection.bias", CH, Q3_DTYPE_F32);
     }
     for (int g = 0; g < c.n_groups - 1; ++g)
@@ -215,7 +229,7 @@ static void build_manifest(q3_model* m) {
         add_layer_slots(m, fmt("talker.code_predictor.model.layers.%d", i), CH, c.cp_inter, c.cp_heads, c.cp_kv_heads, c.head_dim);
     add_slot(m, "talker.code_predictor.model.norm.weight", CH, Q3_DTYPE_F32);
     for (int g = 0; g < c.n_groups - 1; ++g)
-        add_slot(m, fmt("talker.code_predictor.lm_head.%d.weight", g), (int64_t)c.cp_vocab * CH, Q3_DTYPE_BF16);
+        add_tiled(m, fmt("talker.code_predictor.lm_head.%d.weight", g), c.cp_vocab, CH);
     // decoder (all f32)
     const int CB = c.dec_cb_size, CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden;
     const int QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
@@ -295,8 +309,8 @@ static void build_manifest(q3_model* m) {
 static q3_status check_config(const q3_config& c) {
     if (c.head_dim != HEAD_DIM) return set_err(Q3_UNSUPPORTED, "head_dim %d unsupported (kernels are built for 128)", c.head_dim);
     if (c.dec_head_dim != 64) return set_err(Q3_UNSUPPORTED, "decoder head_dim %d unsupported (64)", c.dec_head_dim);
-    if (c.hidden % 8 || c.inter % 8 || c.text_dim % 8 || c.cp_hidden % 8 || c.cp_inter % 8)
-        return set_err(Q3_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 8");
+    if (c.hidden % 32 || c.inter % 32 || c.text_dim % 32 || c.cp_hidden % 32 || c.cp_inter % 32)
+        return set_err(Q3_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 32");
     if (c.n_groups != 16) return set_err(Q3_UNSUPPORTED, "n_groups must be 16");
     if (c.codec_vocab > 4096 || c.codec_vocab < 1024) return set_err(Q3_UNSUPPORTED, "codec_vocab must be in [1024, 4096]");
     const int nrep = c.n_heads / (c.n_kv_heads ? c.n_kv_heads : 1), crep = c.cp_heads / (c.cp_kv_heads ? c.cp_kv_heads : 1);
@@ -347,6 +361,30 @@ extern "C" q3_status q3_model_tensor_info(const q3_model* m, int i, const char**
     return Q3_OK;
 }
 
+// row-major [N][K] bf16 → MFMA tiles [N↑16/16][K↑32/32][lane 0..63][8], lane = (k-group << 4) | row (zero padded)
+static void retile_bf16(const uint16_t* src, int N, int K, uint16_t* dst) {
+    const int T = up16(N) / 16, S = up32(K) / 32;
+    auto body = [=](int t0, int t1) {
+        for (int t = t0; t < t1; ++t)
+            for (int s = 0; s < S; ++s)
+                for (int l = 0; l < 64; ++l) {
+                    const int n = t * 16 + (l & 15), k0 = s * 32 + (l >> 4) * 8;
+                    uint16_t* d = dst + (((size_t)t * S + s) * 64 + l) * 8;
+                    for (int e = 0; e < 8; ++e) d[e] = (n < N && k0 + e < K) ? src[(size_t)n * K + k0 + e] : (uint16_t)0;
+                }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 2 || (size_t)N * K < (1u << 20)) { body(0, T); return; }
+    std::vector<std::thread> th;
+    const int per = (T + (int)nt - 1) / (int)nt;
+    for (unsigned i = 0; i < nt; ++i) {
+        const int a = (int)i * per, b = a + per < T ? a + per : T;
+        if (a < b) th.emplace_back(body, a, b);
+    }
+    for (auto& x : th) x.join();
+}
+
 extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtype, const void* data, int64_t n) {
     if (!m || !name || !data) return set_err(Q3_INVALID_ARG, "q3_model_set_tensor: null argument");
     auto it = m->index.find(name);
@@ -358,7 +396,17 @@ extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtyp
     const size_t bytes = (size_t)n * (s.stored == Q3_DTYPE_BF16 ? 2 : 4);
     std::vector<char> tmp;
     const void* src = data;
-    if (s.kind == SK_TRANSCONV) {
+    size_t up_bytes = bytes;
+    if (s.kind == SK_TILED) {
+        std::vector<uint16_t> w((size_t)n);
+        if (dtype == Q3_DTYPE_BF16) memcpy(w.data(), data, (size_t)n * 2);
+        else if (dtype == Q3_DTYPE_F32) for (int64_t i = 0; i < n; ++i) w[(size_t)i] = f32_to_bf16_host(((const float*)data)[i]);
+        else return set_err(Q3_INVALID_ARG, "unsupported source dtype %d", dtype);
+        up_bytes = (size_t)up16(s.rows) * up32(s.cols) * 2;
+        tmp.resize(up_bytes);
+        retile_bf16(w.data(), s.rows, s.cols, (uint16_t*)tmp.data());
+        src = tmp.data();
+    } else if (s.kind == SK_TRANSCONV) {
         // [cin][cout][k] → per-phase causal-conv weights [stride][cout][cin][taps]
         std::vector<float> w((size_t)n);
         if (dtype == Q3_DTYPE_F32) memcpy(w.data(), data, (size_t)n * 4);
@@ -388,7 +436,7 @@ extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtyp
     } else if (dtype != Q3_DTYPE_F32 && dtype != Q3_DTYPE_BF16) {
         return set_err(Q3_INVALID_ARG, "unsupported source dtype %d", dtype);
     }
-    HIPC(hipMemcpy(m->arena + s.offset, src, bytes, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(m->arena + s.offset, src, up_bytes, hipMemcpyHostToDevice));
     s.loaded = true;
     m->finalized = false;
     return Q3_OK;
@@ -795,7 +843,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, B = s->B;
     LinArgs a;
     a.W = w.qkv; a.N = QD + 2 * KD; a.K = d.H; a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
-    a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE;
+    a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE; a.tiled = 1; a.Kpad = d.H;
     HIPC(run_linear(s, a));
     AttnArgs t{};
     t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
@@ -806,14 +854,14 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     HIPC(launch_attn_decode(t, s->stream));
     HIPC(launch_attn_merge(t, s->stream));
     LinArgs o;
-    o.W = w.o; o.N = d.H; o.K = QD; o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID;
+    o.W = w.o; o.N = d.H; o.K = QD; o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID; o.tiled = 1; o.Kpad = QD;
     HIPC(run_linear(s, o));
     LinArgs g;
     g.W = w.gate; g.W2 = w.up; g.N = d.I; g.K = d.H; g.x = b.SUM; g.ldx = d.H; g.norm_w = w.post_ln; g.eps = d.eps;
-    g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU;
+    g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU; g.tiled = 1; g.Kpad = d.H;
     HIPC(run_linear(s, g));
     LinArgs dn;
-    dn.W = w.down; dn.N = d.H; dn.K = d.I; dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID;
+    dn.W = w.down; dn.N = d.H; dn.K = d.I; dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID; dn.tiled = 1; dn.Kpad = d.I;
     HIPC(run_linear(s, dn));
     return Q3_OK;
 }
@@ -833,7 +881,7 @@ static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, 
         HIPC(launch_rmsnorm(s->tb.X, c.hidden, m->norm, s->LASTH, c.hidden, s->B, c.hidden, c.rms_eps, s->stream));
         LinArgs h;
         h.W = m->codec_head; h.N = c.codec_vocab; h.K = c.hidden; h.x = s->LASTH; h.ldx = c.hidden; h.y = s->LOGITS; h.ldy = c.codec_vocab;
-        h.M = s->B; h.epi = EPI_NONE;
+        h.M = s->B; h.epi = EPI_NONE; h.tiled = 1; h.Kpad = c.hidden;
         HIPC(run_linear(s, h));
     }
     return Q3_OK;
@@ -859,7 +907,7 @@ static q3_status cp_run(q3_session* s) {
         HIPC(launch_cp_gather(g, s->stream));
         if (m->mtp_w) {
             LinArgs a;
-            a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
+            a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = 1; a.Kpad = H;
             HIPC(run_linear(s, a));
         }
         for (int i = 0; i < c.cp_layers; ++i)
@@ -868,7 +916,7 @@ static q3_status cp_run(q3_session* s) {
         if (p >= 1) {
             LinArgs h;
             h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
-            h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
+            h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = 1; h.Kpad = CH;
             HIPC(run_linear(s, h));
         }
     }
@@ -1063,11 +1111,11 @@ static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, flo
     for (int r0 = 0; r0 < n && er == hipSuccess; r0 += 8) {
         const int M = (n - r0) < 8 ? (n - r0) : 8;
         LinArgs a;
-        a.W = m->fc1w; a.N = TD; a.K = TD; a.x = e + (size_t)r0 * TD; a.ldx = TD; a.bias = m->fc1b; a.y = h + (size_t)r0 * TD; a.ldy = TD; a.M = M; a.epi = EPI_SILU;
+        a.W = m->fc1w; a.N = TD; a.K = TD; a.x = e + (size_t)r0 * TD; a.ldx = TD; a.bias = m->fc1b; a.y = h + (size_t)r0 * TD; a.ldy = TD; a.M = M; a.epi = EPI_SILU; a.tiled = 1; a.Kpad = TD;
         er = launch_linear(a, s->stream);
         if (er != hipSuccess) break;
         LinArgs b2;
-        b2.W = m->fc2w; b2.N = H; b2.K = TD; b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE;
+        b2.W = m->fc2w; b2.N = H; b2.K = TD; b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE; b2.tiled = 1; b2.Kpad = TD;
         er = launch_linear(b2, s->stream);
     }
     if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
@@ -1394,7 +1442,7 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
             else HIPC(launch_cp_gather(g, s->stream));
             if (m->mtp_w) {
                 LinArgs a;
-                a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
+                a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = 1; a.Kpad = H;
                 HIPC(launch_linear(a, s->stream));
             }
             for (int i = 0; i < c.cp_layers; ++i)
@@ -1403,7 +1451,7 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
             if (p >= 1) {
                 LinArgs h;
                 h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
-                h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
+                h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = 1; h.Kpad = CH;
                 HIPC(launch_linear(h, s->stream));
             }
         }
@@ -1507,12 +1555,16 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
     HIPC(hipSetDevice(device));
     DevPool pool;
     float *x, *y, *b = nullptr; uint16_t* w;
-    HIPC(pool.alloc(&x, (size_t)M * K)); HIPC(pool.alloc(&y, (size_t)M * N)); HIPC(pool.alloc(&w, (size_t)N * K));
-    HIPC(hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(w, w_host, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    const size_t wt_elems = (size_t)up16(N) * up32(K);
+    std::vector<uint16_t> wt(wt_elems);
+    retile_bf16(w_host, N, K, wt.data());
+    HIPC(pool.alloc(&x, (size_t)M * K)); HIPC(pool.alloc(&y, (size_t)M * N)); HIPC(pool.alloc(&w, wt_elems));
+    HIPC(hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(w, wt.data(), wt_elems * 2, hipMemcpyHostToDevice));
     if (bias_host) { HIPC(pool.alloc(&b, (size_t)N)); HIPC(hipMemcpy(b, bias_host, (size_t)N * 4, hipMemcpyHostToDevice)); }
-    for (int m0 = 0; m0 < M; m0 += 8) {
+    for (int m0 = 0; m0 < M; m0 += 16) {
         LinArgs a;
-        a.W = w; a.N = N; a.K = K; a.x = x + (size_t)m0 * K; a.ldx = K; a.bias = b; a.y = y + (size_t)m0 * N; a.ldy = N; a.M = (M - m0) < 8 ? (M - m0) : 8; a.epi = EPI_NONE;
+        a.W = w; a.N = N; a.K = K; a.x = x + (size_t)m0 * K; a.ldx = K; a.bias = b; a.y = y + (size_t)m0 * N; a.ldy = N; a.M = (M - m0) < 16 ? (M - m0) : 16; a.epi = EPI_NONE;
+        a.tiled = 1; a.Kpad = up32(K);
         HIPC(launch_linear(a, 0));
     }
     HIPC(hipDeviceSynchronize());
@@ -1541,5 +1593,65 @@ extern "C" q3_status q3_session_profile_read(q3_session* s, double* ms, double* 
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     if (ms) *ms = s->prof_linear.ms; if (bytes) *bytes = s->prof_linear.bytes; if (launches) *launches = s->prof_linear.launches;
     if (reset) s->prof_linear = ProfAcc();
+    return Q3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// micro-benchmark of one GEMV shape (kernel development aid, used by tests/bench_kernels.py):
+// `iters` back-to-back launches cycling over `n_copies` distinct weight buffers (so the stream comes
+// from HBM, not the 256 MiB Infinity Cache), captured in one hipGraph and timed with HIP events.
+// epi: LinEpi; rms: fused input RMSNorm; tiled: 1 = MFMA kernel, 0 = first-generation VALU kernel.
+// ------------------------------------------------------------------------------------------------
+extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
+                                     double* avg_us) {
+    if (M < 1 || M > 16 || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
+    HIPC(hipSetDevice(device));
+    DevPool pool;
+    const size_t welems = (size_t)up16(N) * up32(K);
+    const int nmat = epi == EPI_SWIGLU ? 2 : 1;
+    uint16_t* w; float *x, *y, *nw, *res;
+    HIPC(pool.alloc(&w, welems * nmat * n_copies));
+    HIPC(pool.alloc(&x, (size_t)16 * K)); HIPC(pool.alloc(&y, (size_t)16 * N)); HIPC(pool.alloc(&nw, (size_t)K)); HIPC(pool.alloc(&res, (size_t)16 * N));
+    {   // random-ish bf16 weights / f32 activations (never zeros: DVFS, guide §5.4 rule 25)
+        std::vector<uint16_t> hw(welems);
+        q3_synth_fill(1, "bench.w", Q3_DTYPE_BF16, 0.02f, 0.0f, (int64_t)welems, hw.data());
+        for (int c = 0; c < nmat * n_copies; ++c) HIPC(hipMemcpy(w + (size_t)c * welems, hw.data(), welems * 2, hipMemcpyHostToDevice));
+        std::vector<float> hx((size_t)16 * K), hn((size_t)K, 1.0f);
+        q3_synth_fill(2, "bench.x", Q3_DTYPE_F32, 1.0f, 0.0f, (int64_t)hx.size(), hx.data());
+        HIPC(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(nw, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
+    }
+    hipStream_t st; HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    auto one = [&](int i) -> hipError_t {
+        LinArgs a;
+        const int c = i % n_copies;
+        a.W = w + (size_t)c * nmat * welems; a.W2 = nmat == 2 ? a.W + welems : nullptr;
+        a.N = N; a.K = K; a.Kpad = up32(K); a.tiled = tiled; a.x = x; a.ldx = K; a.y = y; a.ldy = N; a.M = M; a.epi = epi;
+        if (rms) { a.norm_w = nw; a.eps = 1e-6f; }
+        if (epi == EPI_RESID) { a.resid = res; a.ldr = N; }
+        return launch_linear(a, st);
+    };
+    for (int i = 0; i < 4; ++i) HIPC(one(i));
+    HIPC(hipStreamSynchronize(st));
+    hipGraph_t g; hipGraphExec_t ge;
+    HIPC(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = one(i);
+    hipError_t e2 = hipStreamEndCapture(st, &g);
+    if (e != hipSuccess || e2 != hipSuccess) return set_err(Q3_HIP_ERROR, "bench capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIPC(hipGraphLaunch(ge, st)); HIPC(hipStreamSynchronize(st));     // warm
+    hipEvent_t ev0, ev1; HIPC(hipEventCreate(&ev0)); HIPC(hipEventCreate(&ev1));
+    double best = 1e30;
+    for (int rep = 0; rep < 5; ++rep) {
+        HIPC(hipEventRecord(ev0, st));
+        HIPC(hipGraphLaunch(ge, st));
+        HIPC(hipEventRecord(ev1, st));
+        HIPC(hipStreamSynchronize(st));
+        float ms = 0; HIPC(hipEventElapsedTime(&ms, ev0, ev1));
+        if (ms < best) best = ms;
+    }
+    *avg_us = best * 1000.0 / iters;
+    hipEventDestroy(ev0); hipEventDestroy(ev1); hipGraphExecDestroy(ge); hipGraphDestroy(g); hipStreamDestroy(st);
     return Q3_OK;
 }

@@ -23,8 +23,12 @@ struct LinArgs {
     float* y = nullptr; int ldy = 0;
     int M = 1, N = 0, K = 0;
     int epi = EPI_NONE;
+    int tiled = 0;                  // 1: W/W2 are MFMA-tiled ([N/16][Kpad/32][64 lanes][8 bf16]), see q3_kernels_gemv.hip
+    int Kpad = 0;                   // K rounded up to 32 (tiled layout)
 };
-hipError_t launch_linear(const LinArgs& a, hipStream_t st);
+hipError_t launch_linear(const LinArgs& a, hipStream_t st);       // dispatches on a.tiled
+hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st);   // MFMA bf16x3 kernel (tiled weights)
+hipError_t launch_linear_rowmajor(const LinArgs& a, hipStream_t st);   // first-generation VALU kernel
 
 // standalone analogue of kernels/fused_residual_rmsnorm.cu: (normed, sum) for [rows][cols]
 hipError_t launch_fused_residual_rmsnorm_f32(const float* x, const float* res, const float* w, float* normed,

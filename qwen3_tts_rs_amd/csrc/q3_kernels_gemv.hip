@@ -1,0 +1,163 @@
+// q3_kernels_gemv.hip — the weight-streaming kernel of the decode path, second generation:
+// skinny GEMM y[m][n] = Σ_k x[m][k]·W[n][k] for the M ≤ 16 live tokens of a batch, on the matrix
+// cores without giving up f32 accuracy.
+//
+//   * Weights are bf16 in HBM, PRE-TILED at upload into MFMA A-operand order: tile (n/16, k/32) is
+//     one contiguous 1 KiB block whose 16-byte slot `lane` holds W[n0 + (lane&15)][k0 + (lane>>4)*8 .. +8],
+//     so one `global_load_dwordx4` per lane streams a whole tile, fully coalesced, and consecutive
+//     k-steps of a row-tile are consecutive in memory.
+//   * x stays f32 in global memory (it is a few KB and L2-resident); each lane loads the 8 values of its
+//     (m = lane&15, k-group = lane>>4) slot and splits them EXACTLY into three bf16 terms
+//     x = hi + mid + lo (24 mantissa bits), so three `v_mfma_f32_16x16x32_bf16` per tile reproduce the
+//     f32 product W·x to f32-roundoff — the "bf16x3" trick; bf16·bf16 products are exact in the f32
+//     accumulator, only the summation order differs from a VALU fmaf chain.
+//   * A workgroup = 8 waves owns ONE 16-row tile (two for SwiGLU: gate and up) and splits K eight ways;
+//     partial 16×16 tiles are reduced through LDS in fixed wave order (deterministic), then the epilogue
+//     (÷rms, +bias, +residual, SiLU, SwiGLU) runs on 256 threads and stores 64-byte row segments.
+//   * Fused input RMSNorm costs nothing extra: Σx² is accumulated from the same x loads, the norm weight
+//     is folded into x before the split (z = x·w), and the 1/sqrt(mean+eps) scalar is applied to the
+//     finished dot product: y = (Σ W·(x·w)) / den.  No LDS staging, one barrier per kernel.
+#include "q3_kernels.h"
+
+#include <math.h>
+
+namespace q3 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+struct Split3 { u32x4_t hi, mid, lo; };
+
+// exact 3-way bf16 split of 8 floats (packed pairs: element 2i in the low half of word i)
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const uint32_t h = cvt_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const uint32_t m = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        s.hi[i] = h; s.mid[i] = m; s.lo[i] = cvt_pk_bf16(sa, sb);
+    }
+    return s;
+}
+
+__device__ __forceinline__ f32x4_t mfma3(const u32x4_t& w, const Split3& s, f32x4_t acc) {
+    const bf16x8_t a = __builtin_bit_cast(bf16x8_t, w);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, s.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, s.mid), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, s.lo), acc, 0, 0, 0);
+    return acc;
+}
+
+constexpr int GV_WAVES = 8;
+
+template <int EPI, bool RMS>
+__global__ __launch_bounds__(GV_WAVES * 64) void k_gemv_mfma(LinArgs a) {
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float red[GV_WAVES][NW][256];
+    __shared__ float ssq[GV_WAVES][4][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int S = a.Kpad >> 5;                       // k-steps of 32
+    const int s0 = (wave * S) / GV_WAVES, s1 = ((wave + 1) * S) / GV_WAVES;
+    const size_t tile_base = (size_t)blockIdx.x * S * 64 + lane;
+    const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + tile_base;
+    const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : nullptr;
+    const bool act = m < a.M;
+    const float* __restrict__ xr = a.x + (size_t)(act ? m : 0) * a.ldx + kg * 8;
+    const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 : nullptr;
+
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float ss = 0.0f;
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) {
+        const u32x4_t wa = __builtin_nontemporal_load(wp + (size_t)s * 64);
+        u32x4_t wb;
+        if constexpr (NW == 2) wb = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+        float xv[8];
+        const int k = s * 32 + kg * 8;
+        if (act && k < a.K) {
+            const float4 x0 = *reinterpret_cast<const float4*>(xr + s * 32);
+            const float4 x1 = *reinterpret_cast<const float4*>(xr + s * 32 + 4);
+            xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+            if constexpr (RMS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss = fmaf(xv[e], xv[e], ss);
+                const float4 n0 = *reinterpret_cast<const float4*>(nwp + s * 32);
+                const float4 n1 = *reinterpret_cast<const float4*>(nwp + s * 32 + 4);
+                xv[0] *= n0.x; xv[1] *= n0.y; xv[2] *= n0.z; xv[3] *= n0.w; xv[4] *= n1.x; xv[5] *= n1.y; xv[6] *= n1.z; xv[7] *= n1.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = 0.0f;
+        }
+        const Split3 sp = split3(xv);
+        acc0 = mfma3(wa, sp, acc0);
+        if constexpr (NW == 2) acc1 = mfma3(wb, sp, acc1);
+    }
+    // partial tile → LDS, layout [col m][row]: lane (m, kg) owns rows kg*4 .. kg*4+3
+    *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = acc0;
+    if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = acc1;
+    if constexpr (RMS) ssq[wave][kg][m] = ss;
+    __syncthreads();
+    if (tid < 256) {
+        const int col = tid >> 4, row = tid & 15;
+        if (col < a.M) {
+            float v = 0.0f, v2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < GV_WAVES; ++w) {
+                v += red[w][0][tid];
+                if constexpr (NW == 2) v2 += red[w][1][tid];
+            }
+            if constexpr (RMS) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int w = 0; w < GV_WAVES; ++w)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) tot += ssq[w][g][col];
+                const float den = sqrtf(tot / (float)a.K + a.eps);
+                v = v / den;
+                if constexpr (NW == 2) v2 = v2 / den;
+            }
+            const int n = blockIdx.x * 16 + row;
+            if (n < a.N) {
+                if (a.bias) v = v + a.bias[n];
+                if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)col * a.ldr + n] + v;
+                if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+                if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+                a.y[(size_t)col * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+template <int EPI, bool RMS>
+static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
+    const int tiles = (a.N + 15) / 16;
+    hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS>), dim3(tiles), dim3(GV_WAVES * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st) {
+    if (a.Kpad % 32 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
+        return hipErrorInvalidValue;
+    const bool rms = a.norm_w != nullptr;
+    switch (a.epi) {
+        case EPI_NONE: return rms ? launch_gemv_t<EPI_NONE, true>(a, st) : launch_gemv_t<EPI_NONE, false>(a, st);
+        case EPI_RESID: return rms ? hipErrorInvalidValue : launch_gemv_t<EPI_RESID, false>(a, st);
+        case EPI_SILU: return rms ? hipErrorInvalidValue : launch_gemv_t<EPI_SILU, false>(a, st);
+        case EPI_SWIGLU: return rms ? launch_gemv_t<EPI_SWIGLU, true>(a, st) : launch_gemv_t<EPI_SWIGLU, false>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace q3

@@ -251,6 +251,10 @@ static hipError_t launch_linear_mr(const LinArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_linear(const LinArgs& a, hipStream_t st) {
+    return a.tiled ? launch_gemv_tiled(a, st) : launch_linear_rowmajor(a, st);
+}
+
+hipError_t launch_linear_rowmajor(const LinArgs& a, hipStream_t st) {
     if (a.K % 8 != 0 || a.ldx % 4 != 0 || a.M < 1 || a.M > 8 || a.N < 1) return hipErrorInvalidValue;
     // rows per wave: 2 when that still leaves >= 512 workgroups (2 per CU), else 1
     const bool r2 = (a.N / 8) >= 512;
