@@ -820,6 +820,7 @@ struct q3_session {
     std::vector<uint32_t> codes_host; bool codes_host_valid = false;
     int stream_pos = 0;    // streaming: frames already decoded
     bool profile = false; ProfAcc prof_linear;
+    bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
 };
 
@@ -850,9 +851,14 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits;
-    HIPC(launch_qknorm_rope_kv(t, s->stream));
-    HIPC(launch_attn_decode(t, s->stream));
-    HIPC(launch_attn_merge(t, s->stream));
+    if (s->legacy_attn) {
+        HIPC(launch_qknorm_rope_kv(t, s->stream));
+        HIPC(launch_attn_decode(t, s->stream));
+        HIPC(launch_attn_merge(t, s->stream));
+    } else {
+        HIPC(launch_attn_fused(t, s->stream));
+        if (n_splits > 1) HIPC(launch_attn_merge(t, s->stream));
+    }
     LinArgs o;
     o.W = w.o; o.N = d.H; o.K = QD; o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID; o.tiled = 1; o.Kpad = QD;
     HIPC(run_linear(s, o));

@@ -56,6 +56,8 @@ struct AttnArgs {
 hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st);
+// fused q/k-norm + RoPE + KV append + attention (+ final normalisation when n_splits == 1)
+hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st);
 
 // ---- frame glue ----
 // gather rows: out[r][0..dim) = f32(table_bf16[ids[r]][0..dim))

@@ -20,6 +20,7 @@
 #include "q3_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace q3 {
 
@@ -58,51 +59,70 @@ __device__ __forceinline__ f32x4_t mfma3(const u32x4_t& w, const Split3& s, f32x
     return acc;
 }
 
-constexpr int GV_WAVES = 8;
+// One k-step for this lane: finish the B operand (mask, Σx², norm weight, bf16x3 split) and run the MFMAs.
+template <int NW, bool RMS>
+__device__ __forceinline__ void gemv_step(bool valid, const float4& x0, const float4& x1, const float4& n0, const float4& n1,
+                                          const u32x4_t& wa, const u32x4_t& wb, f32x4_t& acc0, f32x4_t& acc1, float& ss) {
+    float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[e] = valid ? xv[e] : 0.0f;
+    if constexpr (RMS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = fmaf(xv[e], xv[e], ss);
+        xv[0] *= n0.x; xv[1] *= n0.y; xv[2] *= n0.z; xv[3] *= n0.w; xv[4] *= n1.x; xv[5] *= n1.y; xv[6] *= n1.z; xv[7] *= n1.w;
+    }
+    const Split3 sp = split3(xv);
+    acc0 = mfma3(wa, sp, acc0);
+    if constexpr (NW == 2) acc1 = mfma3(wb, sp, acc1);
+}
 
-template <int EPI, bool RMS>
-__global__ __launch_bounds__(GV_WAVES * 64) void k_gemv_mfma(LinArgs a) {
+// NWAVES waves split K; weights for up to G k-steps are requested up front (G KiB per wave in flight per
+// matrix) before any of them is consumed, so a wave's whole slice is usually one HBM round trip.
+template <int EPI, bool RMS, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float red[GV_WAVES][NW][256];
-    __shared__ float ssq[GV_WAVES][4][16];
+    constexpr int G = (NW == 2 || RMS) ? 4 : 6;
+    __shared__ __attribute__((aligned(16))) float red[NWAVES][NW][256];
+    __shared__ float ssq[NWAVES][4][16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
     const int S = a.Kpad >> 5;                       // k-steps of 32
-    const int s0 = (wave * S) / GV_WAVES, s1 = ((wave + 1) * S) / GV_WAVES;
+    const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
     const size_t tile_base = (size_t)blockIdx.x * S * 64 + lane;
     const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + tile_base;
-    const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : nullptr;
+    const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : wp;
     const bool act = m < a.M;
     const float* __restrict__ xr = a.x + (size_t)(act ? m : 0) * a.ldx + kg * 8;
     const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 : nullptr;
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.0f;
-#pragma unroll 4
-    for (int s = s0; s < s1; ++s) {
-        const u32x4_t wa = __builtin_nontemporal_load(wp + (size_t)s * 64);
-        u32x4_t wb;
-        if constexpr (NW == 2) wb = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
-        float xv[8];
-        const int k = s * 32 + kg * 8;
-        if (act && k < a.K) {
-            const float4 x0 = *reinterpret_cast<const float4*>(xr + s * 32);
-            const float4 x1 = *reinterpret_cast<const float4*>(xr + s * 32 + 4);
-            xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+    for (int sb = s0; sb < s1; sb += G) {
+        // every load of the group (weights from HBM, x / norm weight from L2) is issued before any is consumed
+        u32x4_t wa[G], wb[G];
+        float4 xa[G], xb[G], na[G], nb[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);      // clamp: duplicate load, masked below
+            wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+            if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+            const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;    // K tail (K % 32 != 0): clamp, masked below
+            xa[i] = *reinterpret_cast<const float4*>(xr + ko);
+            xb[i] = *reinterpret_cast<const float4*>(xr + ko + 4);
             if constexpr (RMS) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss = fmaf(xv[e], xv[e], ss);
-                const float4 n0 = *reinterpret_cast<const float4*>(nwp + s * 32);
-                const float4 n1 = *reinterpret_cast<const float4*>(nwp + s * 32 + 4);
-                xv[0] *= n0.x; xv[1] *= n0.y; xv[2] *= n0.z; xv[3] *= n0.w; xv[4] *= n1.x; xv[5] *= n1.y; xv[6] *= n1.z; xv[7] *= n1.w;
+                na[i] = *reinterpret_cast<const float4*>(nwp + ko);
+                nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = 0.0f;
         }
-        const Split3 sp = split3(xv);
-        acc0 = mfma3(wa, sp, acc0);
-        if constexpr (NW == 2) acc1 = mfma3(wb, sp, acc1);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = sb + i;
+            if (s < s1) {
+                const bool valid = act && (s * 32 + kg * 8) < a.K;
+                gemv_step<NW, RMS>(valid, xa[i], xb[i], RMS ? na[i] : xa[i], RMS ? nb[i] : xb[i], wa[i], NW == 2 ? wb[i] : wa[i],
+                                   acc0, acc1, ss);
+            }
+        }
     }
     // partial tile → LDS, layout [col m][row]: lane (m, kg) owns rows kg*4 .. kg*4+3
     *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = acc0;
@@ -114,14 +134,14 @@ __global__ __launch_bounds__(GV_WAVES * 64) void k_gemv_mfma(LinArgs a) {
         if (col < a.M) {
             float v = 0.0f, v2 = 0.0f;
 #pragma unroll
-            for (int w = 0; w < GV_WAVES; ++w) {
+            for (int w = 0; w < NWAVES; ++w) {
                 v += red[w][0][tid];
                 if constexpr (NW == 2) v2 += red[w][1][tid];
             }
             if constexpr (RMS) {
                 float tot = 0.0f;
 #pragma unroll
-                for (int w = 0; w < GV_WAVES; ++w)
+                for (int w = 0; w < NWAVES; ++w)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) tot += ssq[w][g][col];
                 const float den = sqrtf(tot / (float)a.K + a.eps);
@@ -143,7 +163,13 @@ __global__ __launch_bounds__(GV_WAVES * 64) void k_gemv_mfma(LinArgs a) {
 template <int EPI, bool RMS>
 static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     const int tiles = (a.N + 15) / 16;
-    hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS>), dim3(tiles), dim3(GV_WAVES * 64), 0, st, a);
+    const int S = a.Kpad >> 5;
+    // 16 waves per tile when the tile count alone cannot fill the chip or the per-wave slice gets long
+    bool big = (tiles < 256 && S >= 32) || S >= 128;
+    static const int force = [] { const char* e = getenv("Q3_GEMV_WAVES"); return e ? atoi(e) : 0; }();   // tuning aid
+    if (force == 8) big = false; else if (force == 16) big = true;
+    if (big) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16>), dim3(tiles), dim3(16 * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8>), dim3(tiles), dim3(8 * 64), 0, st, a);
     return hipGetLastError();
 }
 

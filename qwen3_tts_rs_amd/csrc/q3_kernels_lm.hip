@@ -450,6 +450,126 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// Fused decode attention: per-head q/k RMSNorm + rotate-half RoPE + in-place KV append + GQA attention in
+// ONE launch (replaces k_qknorm_rope_kv + k_attn_decode, and k_attn_merge too when n_splits == 1, which is the
+// code predictor's case: 16 positions at most). Every split block re-derives the (tiny) normed/roped q heads
+// and the new K/V row in LDS; the split that owns position `pos` appends them to the cache, and every block
+// takes position `pos` from LDS, never from the just-written global memory.
+template <int NREP>
+__global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_q[NREP][HEAD_DIM];
+    __shared__ __attribute__((aligned(16))) float s_k[HEAD_DIM], s_v[HEAD_DIM];
+    __shared__ float sm_m[NREP][8], sm_l[NREP][8];
+    __shared__ __attribute__((aligned(16))) float sm_acc[NREP][8][HEAD_DIM];
+    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, grp = tid >> 5, li = tid & 31, wave = tid >> 6, lane = tid & 63;
+    const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
+    const int pos = a.pos_dev ? a.pos_dev[b] : a.pos_static;
+    const int len = pos + 1;
+    const int chunk = (len + a.n_splits - 1) / a.n_splits;
+    const int start = split * chunk;
+    const int end = (start + chunk) < len ? (start + chunk) : len;
+    const float scale = 0.08838834764831845f;
+    const size_t cache_base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+
+    // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v)
+    for (int j = wave; j <= NREP; j += 4) {
+        const bool is_q = j < NREP;
+        const float* src = a.qkv + (size_t)b * a.ld_qkv + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM);
+        float x1 = src[lane], x2 = src[lane + 64];
+        const float ss = wave_sum(x1 * x1 + x2 * x2);
+        const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
+        const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
+        x1 = x1 / den * nw[lane];
+        x2 = x2 / den * nw[lane + 64];
+        const float c = a.rope_cos[(size_t)pos * 64 + lane], sn = a.rope_sin[(size_t)pos * 64 + lane];
+        const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, sn));
+        const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
+        if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
+        else {
+            const float* vs = a.qkv + (size_t)b * a.ld_qkv + QD + KD + kvh * HEAD_DIM;
+            const float v1 = vs[lane], v2 = vs[lane + 64];
+            s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
+            if (split == pos / chunk) {
+                float* kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM;
+                float* vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM;
+                kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
+            }
+        }
+    }
+    __syncthreads();
+
+    float4 q[NREP];
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) q[r] = *reinterpret_cast<const float4*>(&s_q[r][li * 4]);
+    float m[NREP], l[NREP];
+    float4 acc[NREP];
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    const size_t base = cache_base + li * 4;
+    for (int p = start + grp; p < end; p += 8) {
+        float4 kk, vv;
+        if (p == pos) {
+            kk = *reinterpret_cast<const float4*>(&s_k[li * 4]);
+            vv = *reinterpret_cast<const float4*>(&s_v[li * 4]);
+        } else {
+            kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
+            vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
+        }
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            float s = q[r].x * kk.x + q[r].y * kk.y + q[r].z * kk.z + q[r].w * kk.w;
+            s = half_wave_sum(s) * scale;
+            const float mn = fmaxf(m[r], s);
+            const float corr = expf(m[r] - mn);
+            const float pe = expf(s - mn);
+            l[r] = l[r] * corr + pe;
+            acc[r].x = acc[r].x * corr + pe * vv.x; acc[r].y = acc[r].y * corr + pe * vv.y;
+            acc[r].z = acc[r].z * corr + pe * vv.z; acc[r].w = acc[r].w * corr + pe * vv.w;
+            m[r] = mn;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+        if (li == 0) { sm_m[r][grp] = m[r]; sm_l[r][grp] = l[r]; }
+        *reinterpret_cast<float4*>(&sm_acc[r][grp][li * 4]) = acc[r];
+    }
+    __syncthreads();
+    for (int t = tid; t < NREP * HEAD_DIM; t += 256) {
+        const int r = t / HEAD_DIM, d = t % HEAD_DIM;
+        float M = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) M = fmaxf(M, sm_m[r][g]);
+        float L = 0.0f, A = 0.0f;
+        if (M != -INFINITY) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float wgt = sm_m[r][g] == -INFINITY ? 0.0f : expf(sm_m[r][g] - M);
+                L += sm_l[r][g] * wgt;
+                A += sm_acc[r][g][d] * wgt;
+            }
+        }
+        const int h = kvh * NREP + r;
+        if (a.n_splits == 1) {
+            a.out[(size_t)b * a.ld_out + h * HEAD_DIM + d] = A / L;
+        } else {
+            float* rec = a.part + (((size_t)b * a.nh + h) * a.n_splits + split) * PART_STRIDE;
+            rec[d] = A;
+            if (d == 0) { rec[HEAD_DIM] = M; rec[HEAD_DIM + 1] = L; }
+        }
+    }
+}
+
+hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
+    const int nrep = a.nh / a.nkv;
+    dim3 grid(a.n_splits, a.nkv, a.B);
+    if (nrep == 1) hipLaunchKernelGGL(k_attn_fused<1>, grid, dim3(256), 0, st, a);
+    else if (nrep == 2) hipLaunchKernelGGL(k_attn_fused<2>, grid, dim3(256), 0, st, a);
+    else if (nrep == 4) hipLaunchKernelGGL(k_attn_fused<4>, grid, dim3(256), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // merge the split partials: out[b][h*128+d] = Σ_s A_s[d] e^{m_s-M} / Σ_s l_s e^{m_s-M}
 __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
@@ -552,26 +672,32 @@ __global__ __launch_bounds__(256) void k_frame_embed(FrameEmbedArgs a) {
     const int f = a.frame_idx[b];
     uint32_t* frame = a.codes + ((size_t)b * a.max_frames + f) * 16;
     const int last = block_argmax_first(a.cp_logits_last + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
         frame[0] = a.tok[b];
         frame[a.n_acoustic] = (uint32_t)last;
     }
-    __syncthreads();
-    if (threadIdx.x < 16) codes_s[threadIdx.x] = frame[threadIdx.x];
+    if (threadIdx.x < 16)
+        codes_s[threadIdx.x] = threadIdx.x == 0 ? a.tok[b] : (threadIdx.x == (unsigned)a.n_acoustic ? (uint32_t)last : frame[threadIdx.x]);
     __syncthreads();
     const int H = a.H;
     const int row = f < a.trail_len[b] ? a.trail_base[b] + f : a.pad_row[b];
     const float* text = a.text_rows + (size_t)row * H;
     const uint16_t* sem = a.codec_emb + (size_t)codes_s[0] * H;
-    for (int c = threadIdx.x; c < H; c += 256) {
-        float acc = bf16_to_f32(a.cp_embs[0][(size_t)codes_s[1] * H + c]);
-        for (int g = 1; g < a.n_acoustic; ++g) acc = __fadd_rn(acc, bf16_to_f32(a.cp_embs[g][(size_t)codes_s[1 + g] * H + c]));
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c < H) {
+        float e[15];
+#pragma unroll
+        for (int g = 0; g < 15; ++g) e[g] = g < a.n_acoustic ? bf16_to_f32(a.cp_embs[g][(size_t)codes_s[1 + g] * H + c]) : 0.0f;
+        float acc = e[0];
+#pragma unroll
+        for (int g = 1; g < 15; ++g) if (g < a.n_acoustic) acc = __fadd_rn(acc, e[g]);
         const float summed = __fadd_rn(bf16_to_f32(sem[c]), acc);
         a.out[(size_t)b * H + c] = __fadd_rn(summed, text[c]);
     }
 }
 hipError_t launch_frame_embed(const FrameEmbedArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_frame_embed, dim3(a.B), dim3(256), 0, st, a);
+    if (a.n_acoustic != 15) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_frame_embed, dim3(a.B, (a.H + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
