@@ -120,14 +120,19 @@ def main():
     s = model.session(utts, q.SynthesisOptions(max_length=args.profile_frames + 2, eos_token_id=None, seed=42))
     s.prefill()
     s.generate(2, use_graph=False)
-    s.set_profile(True)
-    s.generate(args.profile_frames, use_graph=False)
+    prof_mode = "graph-event-nodes"
+    try:
+        s.profile_frames(args.profile_frames)
+    except Exception:
+        prof_mode = "eager-events"
+        s.set_profile(True)
+        s.generate(args.profile_frames, use_graph=False)
     ms, nbytes, launches = s.profile_read()
     wbytes, kvbytes = s.frame_bytes(10 + args.frames // 2)
     s.close()
     achieved = (nbytes / (ms / 1000.0)) / 1e9 if ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": None, "kernel": "k_linear<M,R,RMS,EPI> (bf16-weight GEMV family)",
+                "traffic": None, "kernel": "k_gemv_mfma<EPI,RMS,NWAVES> (bf16-weight MFMA GEMV family)", "timing": prof_mode,
                 "launches_measured": launches, "avg_launch_us": (ms * 1000.0 / launches) if launches else None,
                 "avg_bytes_per_launch": (nbytes / launches) if launches else None,
                 "frame_weight_bytes": wbytes, "frame_kv_bytes": kvbytes,

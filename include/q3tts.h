@@ -234,6 +234,12 @@ q3_status q3_session_set_profile(q3_session* s, int enable);
 /* accumulated since the last reset: GPU milliseconds, algorithmic weight bytes and launch count of
  * the bf16 GEMV family (the dominant kernel) */
 q3_status q3_session_profile_read(q3_session* s, double* ms, double* bytes, long* launches, int reset);
+/* generate `reps` frames from a graph that carries event-record nodes around every GEMV launch (GPU-side
+ * timestamps, no host launch latency inside the measured intervals); results via q3_session_profile_read */
+q3_status q3_session_profile_frames(q3_session* s, int reps);
+/* kernel development aid: µs per launch of one GEMV shape replayed from a graph (tests/bench_kernels.py) */
+q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
+                          double* avg_us);
 /* raw stream handle (hipStream_t) the session launches on */
 q3_status q3_session_stream(q3_session* s, void** stream);
 /* Algorithmic HBM bytes of one frame for this session's batch at KV length L */

@@ -260,6 +260,9 @@ class Session:
     def set_profile(self, on: bool):
         check(lib.q3_session_set_profile(self._h, 1 if on else 0))
 
+    def profile_frames(self, reps: int):
+        check(lib.q3_session_profile_frames(self._h, int(reps)))
+
     def profile_read(self, reset: bool = True) -> Tuple[float, float, int]:
         ms = ctypes.c_double(); by = ctypes.c_double(); n = ctypes.c_long()
         check(lib.q3_session_profile_read(self._h, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n), 1 if reset else 0))

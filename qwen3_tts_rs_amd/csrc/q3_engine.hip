@@ -130,7 +130,7 @@ enum SlotKind { SK_PLAIN = 0, SK_TRANSCONV = 1, SK_TILED = 2 };
 struct Slot {
     std::string name; int64_t n = 0; int stored = Q3_DTYPE_F32; size_t offset = 0; bool loaded = false;
     int kind = SK_PLAIN; int tc_cin = 0, tc_cout = 0, tc_k = 0, tc_stride = 0;
-    int rows = 0, cols = 0;      // SK_TILED: logical [rows][cols]; stored padded to [rows↑16][cols↑32]
+    int rows = 0, cols = 0, tmode = 1;   // SK_TILED: logical [rows][cols]; stored as 16-row (1) or 4-row (2) MFMA tiles
 };
 struct LayerW {
     const float *in_ln, *q_norm, *k_norm, *post_ln;
@@ -175,30 +175,40 @@ static void add_slot(q3_model* m, const std::string& name, int64_t n, int stored
 }
 static inline int up16(int v) { return (v + 15) & ~15; }
 static inline int up32(int v) { return (v + 31) & ~31; }
+static inline int up4(int v) { return (v + 3) & ~3; }
+static inline int up128(int v) { return (v + 127) & ~127; }
+// GEMV tiling mode by the output width of the (possibly fused) projection: 4-row tiles below 4096 rows
+// (more workgroups for small matrices), 16-row tiles from 4096 rows up
+static inline int tmode(int n_total) { return n_total < 4096 ? 2 : 1; }
+static inline int kpad_for(int mode, int K) { return mode == 2 ? up128(K) : up32(K); }
+static inline size_t tiled_elems(int mode, int rows, int cols) {
+    return mode == 2 ? (size_t)up4(rows) * up128(cols) : (size_t)up16(rows) * up32(cols);
+}
 // GEMV weight [rows][cols] bf16, stored MFMA-tiled (q3_kernels_gemv.hip); element count reported to the
 // caller stays rows*cols (the checkpoint's), the arena holds the padded tiled image.
-static void add_tiled(q3_model* m, const std::string& name, int rows, int cols, bool align = true) {
-    Slot s; s.name = name; s.n = (int64_t)rows * cols; s.stored = Q3_DTYPE_BF16; s.kind = SK_TILED; s.rows = rows; s.cols = cols;
+static void add_tiled(q3_model* m, const std::string& name, int rows, int cols, int mode, bool align = true) {
+    Slot s; s.name = name; s.n = (int64_t)rows * cols; s.stored = Q3_DTYPE_BF16; s.kind = SK_TILED; s.rows = rows; s.cols = cols; s.tmode = mode;
     size_t off = m->arena_bytes;
     if (align) off = (off + 255) & ~(size_t)255;
     s.offset = off;
-    m->arena_bytes = off + (size_t)up16(rows) * up32(cols) * 2;
+    m->arena_bytes = off + tiled_elems(mode, rows, cols) * 2;
     m->index[name] = (int)m->slots.size();
     m->slots.push_back(s);
 }
 static void add_layer_slots(q3_model* m, const std::string& p, int H, int I, int nh, int nkv, int hd) {
     add_slot(m, p + ".input_layernorm.weight", H, Q3_DTYPE_F32);
     // q,k,v rows are stored back to back so the fused QKV GEMV sees one [QD+2KD][H] matrix
-    add_tiled(m, p + ".self_attn.q_proj.weight", nh * hd, H);
-    add_tiled(m, p + ".self_attn.k_proj.weight", nkv * hd, H, false);
-    add_tiled(m, p + ".self_attn.v_proj.weight", nkv * hd, H, false);
-    add_tiled(m, p + ".self_attn.o_proj.weight", H, nh * hd);
+    const int mq = tmode((nh + 2 * nkv) * hd);
+    add_tiled(m, p + ".self_attn.q_proj.weight", nh * hd, H, mq);
+    add_tiled(m, p + ".self_attn.k_proj.weight", nkv * hd, H, mq, false);
+    add_tiled(m, p + ".self_attn.v_proj.weight", nkv * hd, H, mq, false);
+    add_tiled(m, p + ".self_attn.o_proj.weight", H, nh * hd, tmode(H));
     add_slot(m, p + ".self_attn.q_norm.weight", hd, Q3_DTYPE_F32);
     add_slot(m, p + ".self_attn.k_norm.weight", hd, Q3_DTYPE_F32);
     add_slot(m, p + ".post_attention_layernorm.weight", H, Q3_DTYPE_F32);
-    add_tiled(m, p + ".mlp.gate_proj.weight", I, H);
-    add_tiled(m, p + ".mlp.up_proj.weight", I, H);
-    add_tiled(m, p + ".mlp.down_proj.weight", H, I);
+    add_tiled(m, p + ".mlp.gate_proj.weight", I, H, tmode(I));
+    add_tiled(m, p + ".mlp.up_proj.weight", I, H, tmode(I));
+    add_tiled(m, p + ".mlp.down_proj.weight", H, I, tmode(H));
 }
 static std::string fmt(const char* f, ...) {
     char b[256]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return b;
@@ -210,17 +220,17 @@ static void build_manifest(q3_model* m) {
     const q3_config& c = m->cfg;
     const int H = c.hidden, TD = c.text_dim, CH = c.cp_hidden;
     add_slot(m, "talker.model.text_embedding.weight", (int64_t)c.text_vocab * TD, Q3_DTYPE_BF16);
-    add_tiled(m, "talker.text_projection.linear_fc1.weight", TD, TD);
+    add_tiled(m, "talker.text_projection.linear_fc1.weight", TD, TD, tmode(TD));
     add_slot(m, "talker.text_projection.linear_fc1.bias", TD, Q3_DTYPE_F32);
-    add_tiled(m, "talker.text_projection.linear_fc2.weight", H, TD);
+    add_tiled(m, "talker.text_projection.linear_fc2.weight", H, TD, tmode(H));
     add_slot(m, "talker.text_projection.linear_fc2.bias", H, Q3_DTYPE_F32);
     add_slot(m, "talker.model.codec_embedding.weight", (int64_t)c.codec_vocab * H, Q3_DTYPE_BF16);
     for (int i = 0; i < c.n_layers; ++i)
         add_layer_slots(m, fmt("talker.model.layers.%d", i), H, c.inter, c.n_heads, c.n_kv_heads, c.head_dim);
     add_slot(m, "talker.model.norm.weight", H, Q3_DTYPE_F32);
-    add_tiled(m, "talker.codec_head.weight", c.codec_vocab, H);
+    add_tiled(m, "talker.codec_head.weight", c.codec_vocab, H, tmode(c.codec_vocab));
     if (H != CH) {
-        add_tiled(m, "talker.code_predictor.small_to_mtp_projection.weight", CH, H);
+        add_tiled(m, "talker.code_predictor.small_to_mtp_projection.weight", CH, H, tmode(CH));
         add_slot(m, "talker.code_predictor.small_to_mtp_projection.bias", CH, Q3_DTYPE_F32);
     }
     for (int g = 0; g < c.n_groups - 1; ++g)
@@ -229,7 +239,7 @@ static void build_manifest(q3_model* m) {
         add_layer_slots(m, fmt("talker.code_predictor.model.layers.%d", i), CH, c.cp_inter, c.cp_heads, c.cp_kv_heads, c.head_dim);
     add_slot(m, "talker.code_predictor.model.norm.weight", CH, Q3_DTYPE_F32);
     for (int g = 0; g < c.n_groups - 1; ++g)
-        add_tiled(m, fmt("talker.code_predictor.lm_head.%d.weight", g), c.cp_vocab, CH);
+        add_tiled(m, fmt("talker.code_predictor.lm_head.%d.weight", g), c.cp_vocab, CH, tmode(c.cp_vocab));
     // decoder (all f32)
     const int CB = c.dec_cb_size, CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden;
     const int QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
@@ -361,14 +371,17 @@ extern "C" q3_status q3_model_tensor_info(const q3_model* m, int i, const char**
     return Q3_OK;
 }
 
-// row-major [N][K] bf16 → MFMA tiles [N↑16/16][K↑32/32][lane 0..63][8], lane = (k-group << 4) | row (zero padded)
-static void retile_bf16(const uint16_t* src, int N, int K, uint16_t* dst) {
-    const int T = up16(N) / 16, S = up32(K) / 32;
+// row-major [N][K] bf16 → MFMA tiles, zero padded.
+//   mode 1: [N↑16/16][K↑32/32][lane][8],  lane = (k-group << 4) | row      (16 rows x 32 k per KiB)
+//   mode 2: [N↑4/4][K↑128/128][lane][8],  lane = (k-group << 2) | row      (4 rows x 128 k per KiB)
+static void retile_bf16(const uint16_t* src, int N, int K, uint16_t* dst, int mode) {
+    const int RT = mode == 2 ? 4 : 16, KS = mode == 2 ? 128 : 32, RB = mode == 2 ? 2 : 4;
+    const int T = (N + RT - 1) / RT, S = (K + KS - 1) / KS;
     auto body = [=](int t0, int t1) {
         for (int t = t0; t < t1; ++t)
             for (int s = 0; s < S; ++s)
                 for (int l = 0; l < 64; ++l) {
-                    const int n = t * 16 + (l & 15), k0 = s * 32 + (l >> 4) * 8;
+                    const int n = t * RT + (l & (RT - 1)), k0 = s * KS + (l >> RB) * 8;
                     uint16_t* d = dst + (((size_t)t * S + s) * 64 + l) * 8;
                     for (int e = 0; e < 8; ++e) d[e] = (n < N && k0 + e < K) ? src[(size_t)n * K + k0 + e] : (uint16_t)0;
                 }
@@ -402,9 +415,9 @@ extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtyp
         if (dtype == Q3_DTYPE_BF16) memcpy(w.data(), data, (size_t)n * 2);
         else if (dtype == Q3_DTYPE_F32) for (int64_t i = 0; i < n; ++i) w[(size_t)i] = f32_to_bf16_host(((const float*)data)[i]);
         else return set_err(Q3_INVALID_ARG, "unsupported source dtype %d", dtype);
-        up_bytes = (size_t)up16(s.rows) * up32(s.cols) * 2;
+        up_bytes = tiled_elems(s.tmode, s.rows, s.cols) * 2;
         tmp.resize(up_bytes);
-        retile_bf16(w.data(), s.rows, s.cols, (uint16_t*)tmp.data());
+        retile_bf16(w.data(), s.rows, s.cols, (uint16_t*)tmp.data(), s.tmode);
         src = tmp.data();
     } else if (s.kind == SK_TRANSCONV) {
         // [cin][cout][k] → per-phase causal-conv weights [stride][cout][cin][taps]
@@ -822,19 +835,26 @@ struct q3_session {
     bool profile = false; ProfAcc prof_linear;
     bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
+    std::vector<hipEvent_t> prof_pool; size_t prof_pool_next = 0;
 };
 
 static hipError_t run_linear(q3_session* s, const LinArgs& a) {
     if (!s->profile) return launch_linear(a, s->stream);
+    // profiling: bracket the launch with event records (inside graph capture these become event-record
+    // nodes, so the timestamps are taken on the GPU timeline without host launch latency in between)
     hipEvent_t e0, e1;
-    hipError_t e = hipEventCreate(&e0); if (e != hipSuccess) return e;
-    e = hipEventCreate(&e1); if (e != hipSuccess) return e;
-    hipEventRecord(e0, s->stream);
+    if (s->prof_pool_next + 2 <= s->prof_pool.size()) { e0 = s->prof_pool[s->prof_pool_next++]; e1 = s->prof_pool[s->prof_pool_next++]; }
+    else {
+        hipError_t e = hipEventCreate(&e0); if (e != hipSuccess) return e;
+        e = hipEventCreate(&e1); if (e != hipSuccess) return e;
+        s->prof_pool.push_back(e0); s->prof_pool.push_back(e1); s->prof_pool_next = s->prof_pool.size();
+    }
+    hipError_t e = hipEventRecord(e0, s->stream); if (e != hipSuccess) return e;
     e = launch_linear(a, s->stream);
-    hipEventRecord(e1, s->stream);
+    hipError_t e2 = hipEventRecord(e1, s->stream);
     s->prof_events.push_back({e0, e1});
     s->prof_event_bytes.push_back((double)a.N * a.K * 2.0 * (a.epi == EPI_SWIGLU ? 2.0 : 1.0));
-    return e;
+    return e != hipSuccess ? e : e2;
 }
 
 // one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
@@ -844,7 +864,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, B = s->B;
     LinArgs a;
     a.W = w.qkv; a.N = QD + 2 * KD; a.K = d.H; a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
-    a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE; a.tiled = 1; a.Kpad = d.H;
+    a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE; a.tiled = tmode(QD + 2 * KD); a.Kpad = kpad_for(a.tiled, d.H);
     HIPC(run_linear(s, a));
     AttnArgs t{};
     t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
@@ -860,14 +880,14 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
         if (n_splits > 1) HIPC(launch_attn_merge(t, s->stream));
     }
     LinArgs o;
-    o.W = w.o; o.N = d.H; o.K = QD; o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID; o.tiled = 1; o.Kpad = QD;
+    o.W = w.o; o.N = d.H; o.K = QD; o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID; o.tiled = tmode(d.H); o.Kpad = kpad_for(o.tiled, QD);
     HIPC(run_linear(s, o));
     LinArgs g;
     g.W = w.gate; g.W2 = w.up; g.N = d.I; g.K = d.H; g.x = b.SUM; g.ldx = d.H; g.norm_w = w.post_ln; g.eps = d.eps;
-    g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU; g.tiled = 1; g.Kpad = d.H;
+    g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU; g.tiled = tmode(d.I); g.Kpad = kpad_for(g.tiled, d.H);
     HIPC(run_linear(s, g));
     LinArgs dn;
-    dn.W = w.down; dn.N = d.H; dn.K = d.I; dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID; dn.tiled = 1; dn.Kpad = d.I;
+    dn.W = w.down; dn.N = d.H; dn.K = d.I; dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID; dn.tiled = tmode(d.H); dn.Kpad = kpad_for(dn.tiled, d.I);
     HIPC(run_linear(s, dn));
     return Q3_OK;
 }
@@ -887,7 +907,7 @@ static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, 
         HIPC(launch_rmsnorm(s->tb.X, c.hidden, m->norm, s->LASTH, c.hidden, s->B, c.hidden, c.rms_eps, s->stream));
         LinArgs h;
         h.W = m->codec_head; h.N = c.codec_vocab; h.K = c.hidden; h.x = s->LASTH; h.ldx = c.hidden; h.y = s->LOGITS; h.ldy = c.codec_vocab;
-        h.M = s->B; h.epi = EPI_NONE; h.tiled = 1; h.Kpad = c.hidden;
+        h.M = s->B; h.epi = EPI_NONE; h.tiled = tmode(c.codec_vocab); h.Kpad = kpad_for(h.tiled, c.hidden);
         HIPC(run_linear(s, h));
     }
     return Q3_OK;
@@ -913,7 +933,7 @@ static q3_status cp_run(q3_session* s) {
         HIPC(launch_cp_gather(g, s->stream));
         if (m->mtp_w) {
             LinArgs a;
-            a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = 1; a.Kpad = H;
+            a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = tmode(CH); a.Kpad = kpad_for(a.tiled, H);
             HIPC(run_linear(s, a));
         }
         for (int i = 0; i < c.cp_layers; ++i)
@@ -922,7 +942,7 @@ static q3_status cp_run(q3_session* s) {
         if (p >= 1) {
             LinArgs h;
             h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
-            h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = 1; h.Kpad = CH;
+            h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = tmode(V); h.Kpad = kpad_for(h.tiled, CH);
             HIPC(run_linear(s, h));
         }
     }
@@ -1071,7 +1091,7 @@ extern "C" void q3_session_free(q3_session* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
     if (s->graph) hipGraphDestroy(s->graph);
-    for (auto& p : s->prof_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto& ev : s->prof_pool) hipEventDestroy(ev);
     s->cws.release();
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
@@ -1117,11 +1137,11 @@ static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, flo
     for (int r0 = 0; r0 < n && er == hipSuccess; r0 += 8) {
         const int M = (n - r0) < 8 ? (n - r0) : 8;
         LinArgs a;
-        a.W = m->fc1w; a.N = TD; a.K = TD; a.x = e + (size_t)r0 * TD; a.ldx = TD; a.bias = m->fc1b; a.y = h + (size_t)r0 * TD; a.ldy = TD; a.M = M; a.epi = EPI_SILU; a.tiled = 1; a.Kpad = TD;
+        a.W = m->fc1w; a.N = TD; a.K = TD; a.x = e + (size_t)r0 * TD; a.ldx = TD; a.bias = m->fc1b; a.y = h + (size_t)r0 * TD; a.ldy = TD; a.M = M; a.epi = EPI_SILU; a.tiled = tmode(TD); a.Kpad = kpad_for(a.tiled, TD);
         er = launch_linear(a, s->stream);
         if (er != hipSuccess) break;
         LinArgs b2;
-        b2.W = m->fc2w; b2.N = H; b2.K = TD; b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE; b2.tiled = 1; b2.Kpad = TD;
+        b2.W = m->fc2w; b2.N = H; b2.K = TD; b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE; b2.tiled = tmode(H); b2.Kpad = kpad_for(b2.tiled, TD);
         er = launch_linear(b2, s->stream);
     }
     if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
@@ -1271,9 +1291,8 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         for (size_t i = 0; i < s->prof_events.size(); ++i) {
             float ms = 0; hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second);
             s->prof_linear.ms += ms; s->prof_linear.bytes += s->prof_event_bytes[i]; s->prof_linear.launches += 1;
-            hipEventDestroy(s->prof_events[i].first); hipEventDestroy(s->prof_events[i].second);
         }
-        s->prof_events.clear(); s->prof_event_bytes.clear();
+        s->prof_events.clear(); s->prof_event_bytes.clear(); s->prof_pool_next = 0;
     }
     return Q3_OK;
 }
@@ -1448,7 +1467,7 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
             else HIPC(launch_cp_gather(g, s->stream));
             if (m->mtp_w) {
                 LinArgs a;
-                a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = 1; a.Kpad = H;
+                a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = tmode(CH); a.Kpad = kpad_for(a.tiled, H);
                 HIPC(launch_linear(a, s->stream));
             }
             for (int i = 0; i < c.cp_layers; ++i)
@@ -1457,7 +1476,7 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
             if (p >= 1) {
                 LinArgs h;
                 h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
-                h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = 1; h.Kpad = CH;
+                h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = tmode(V); h.Kpad = kpad_for(h.tiled, CH);
                 HIPC(launch_linear(h, s->stream));
             }
         }
@@ -1561,16 +1580,17 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
     HIPC(hipSetDevice(device));
     DevPool pool;
     float *x, *y, *b = nullptr; uint16_t* w;
-    const size_t wt_elems = (size_t)up16(N) * up32(K);
+    const int mode = tmode(N);
+    const size_t wt_elems = tiled_elems(mode, N, K);
     std::vector<uint16_t> wt(wt_elems);
-    retile_bf16(w_host, N, K, wt.data());
+    retile_bf16(w_host, N, K, wt.data(), mode);
     HIPC(pool.alloc(&x, (size_t)M * K)); HIPC(pool.alloc(&y, (size_t)M * N)); HIPC(pool.alloc(&w, wt_elems));
     HIPC(hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(w, wt.data(), wt_elems * 2, hipMemcpyHostToDevice));
     if (bias_host) { HIPC(pool.alloc(&b, (size_t)N)); HIPC(hipMemcpy(b, bias_host, (size_t)N * 4, hipMemcpyHostToDevice)); }
     for (int m0 = 0; m0 < M; m0 += 16) {
         LinArgs a;
         a.W = w; a.N = N; a.K = K; a.x = x + (size_t)m0 * K; a.ldx = K; a.bias = b; a.y = y + (size_t)m0 * N; a.ldy = N; a.M = (M - m0) < 16 ? (M - m0) : 16; a.epi = EPI_NONE;
-        a.tiled = 1; a.Kpad = up32(K);
+        a.tiled = mode; a.Kpad = kpad_for(mode, K);
         HIPC(launch_linear(a, 0));
     }
     HIPC(hipDeviceSynchronize());
@@ -1613,7 +1633,7 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
     if (M < 1 || M > 16 || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
     HIPC(hipSetDevice(device));
     DevPool pool;
-    const size_t welems = (size_t)up16(N) * up32(K);
+    const size_t welems = tiled == 2 ? tiled_elems(2, N, K) : tiled_elems(1, N, K);
     const int nmat = epi == EPI_SWIGLU ? 2 : 1;
     uint16_t* w; float *x, *y, *nw, *res;
     HIPC(pool.alloc(&w, welems * nmat * n_copies));
@@ -1632,7 +1652,7 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
         LinArgs a;
         const int c = i % n_copies;
         a.W = w + (size_t)c * nmat * welems; a.W2 = nmat == 2 ? a.W + welems : nullptr;
-        a.N = N; a.K = K; a.Kpad = up32(K); a.tiled = tiled; a.x = x; a.ldx = K; a.y = y; a.ldy = N; a.M = M; a.epi = epi;
+        a.N = N; a.K = K; a.Kpad = tiled == 2 ? up128(K) : up32(K); a.tiled = tiled; a.x = x; a.ldx = K; a.y = y; a.ldy = N; a.M = M; a.epi = epi;
         if (rms) { a.norm_w = nw; a.eps = 1e-6f; }
         if (epi == EPI_RESID) { a.resid = res; a.ldr = N; }
         return launch_linear(a, st);
@@ -1659,5 +1679,43 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
     }
     *avg_us = best * 1000.0 / iters;
     hipEventDestroy(ev0); hipEventDestroy(ev1); hipGraphExecDestroy(ge); hipGraphDestroy(g); hipStreamDestroy(st);
+    return Q3_OK;
+}
+
+// Profile `reps` frames with GPU-side timestamps: one frame is captured into a hipGraph WITH event-record
+// nodes around every GEMV launch, replayed `reps` times (each replay is a real generation frame), and the
+// per-launch elapsed times are accumulated into the profile counters (q3_session_profile_read).
+extern "C" q3_status q3_session_profile_frames(q3_session* s, int reps) {
+    if (!s || reps < 1) return set_err(Q3_INVALID_ARG, "bad argument");
+    if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
+    if (s->debug) return set_err(Q3_INVALID_ARG, "debug sessions cannot be graph-profiled");
+    if (s->frames_run + reps > s->max_frames) return set_err(Q3_INVALID_ARG, "not enough frames left (%d + %d > %d)", s->frames_run, reps, s->max_frames);
+    HIPC(hipSetDevice(s->m->device));
+    if (s->prof_pool.empty()) {
+        s->prof_pool.resize(2048);
+        for (auto& ev : s->prof_pool) HIPC(hipEventCreate(&ev));
+    }
+    s->prof_pool_next = 0; s->prof_events.clear(); s->prof_event_bytes.clear();
+    const bool was = s->profile; s->profile = true;
+    HIPC(hipStreamSynchronize(s->stream));
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    HIPC(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    q3_status st = frame_launch(s);
+    hipError_t e = hipStreamEndCapture(s->stream, &g);
+    s->profile = was;
+    if (st != Q3_OK) return st;
+    if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "profile capture: %s", hipGetErrorString(e));
+    HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int r = 0; r < reps; ++r) {
+        HIPC(hipGraphLaunch(ge, s->stream));
+        HIPC(hipStreamSynchronize(s->stream));
+        s->frames_run += 1; s->codes_host_valid = false;
+        for (size_t i = 0; i < s->prof_events.size(); ++i) {
+            float ms = 0; HIPC(hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second));
+            s->prof_linear.ms += ms; s->prof_linear.bytes += s->prof_event_bytes[i]; s->prof_linear.launches += 1;
+        }
+    }
+    s->prof_events.clear(); s->prof_event_bytes.clear(); s->prof_pool_next = 0;
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
     return Q3_OK;
 }

@@ -23,11 +23,12 @@ struct LinArgs {
     float* y = nullptr; int ldy = 0;
     int M = 1, N = 0, K = 0;
     int epi = EPI_NONE;
-    int tiled = 0;                  // 1: W/W2 are MFMA-tiled ([N/16][Kpad/32][64 lanes][8 bf16]), see q3_kernels_gemv.hip
-    int Kpad = 0;                   // K rounded up to 32 (tiled layout)
+    int tiled = 0;                  // 1: 16-row MFMA tiles [N/16][Kpad/32][64 lanes][8 bf16]; 2: 4-row tiles [N/4][Kpad/128][64][8]
+    int Kpad = 0;                   // K rounded up to 32 (tiled == 1) or 128 (tiled == 2)
 };
 hipError_t launch_linear(const LinArgs& a, hipStream_t st);       // dispatches on a.tiled
-hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st);   // MFMA bf16x3 kernel (tiled weights)
+hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st);   // MFMA bf16x3 kernel (16-row tiles, tiled == 1)
+hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st);  // 4-row tiles on the 4x4x4 16-block MFMA (tiled == 2)
 hipError_t launch_linear_rowmajor(const LinArgs& a, hipStream_t st);   // first-generation VALU kernel
 
 // standalone analogue of kernels/fused_residual_rmsnorm.cu: (normed, sum) for [rows][cols]

@@ -173,6 +173,175 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-N variant: 4-row tiles on v_mfma_f32_4x4x4_16b_bf16. A 16-row tile leaves most of the chip idle
+// when N <= 2048 (64-128 workgroups); here a workgroup owns 4 output rows, so N = 1024 already gives 256
+// workgroups. The instruction's 16 independent 4x4x4 blocks are used as 16 K-slices: lane = 4*b + i loads
+// the 16 bytes W[n0+i][k0 + 8b .. +8) (tile = 4 rows x 128 k = 1 KiB, again one coalesced load per lane),
+// lane = 4*b + j supplies x[m = 4*mg + j][k0 + 8b .. +8) split into three bf16 terms; block b accumulates
+// its own slice and the 16 partial 4x4 results are summed across lanes (xor 4, 8, 16, 32) at the end.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+__device__ __forceinline__ f32x4_t mfma4(unsigned a0, unsigned a1, unsigned b0, unsigned b1, f32x4_t acc) {
+    const u32x2_t a = {a0, a1}, b = {b0, b1};
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma4_tile(const u32x4_t& w, const Split3& s, f32x4_t acc) {
+    acc = mfma4(w[0], w[1], s.hi[0], s.hi[1], acc);  acc = mfma4(w[2], w[3], s.hi[2], s.hi[3], acc);
+    acc = mfma4(w[0], w[1], s.mid[0], s.mid[1], acc); acc = mfma4(w[2], w[3], s.mid[2], s.mid[3], acc);
+    acc = mfma4(w[0], w[1], s.lo[0], s.lo[1], acc);  acc = mfma4(w[2], w[3], s.lo[2], s.lo[3], acc);
+    return acc;
+}
+__device__ __forceinline__ float sum_over_blocks(float v) {   // lanes 4b+j, all b
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int EPI, bool RMS, int MG>
+__global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int G = 2;
+    __shared__ float red[8][NW][MG][4][4];
+    __shared__ float ssq[8][MG][4];
+    const int nwv = blockDim.x >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 3, kb = lane >> 2;
+    const int S = a.Kpad >> 7;                       // k-steps of 128
+    const int s0 = (wave * S) / nwv, s1 = ((wave + 1) * S) / nwv;
+    const size_t tile_base = (size_t)blockIdx.x * S * 64 + lane;
+    const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + tile_base;
+    const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : wp;
+    const float* xr[MG]; bool act[MG];
+#pragma unroll
+    for (int g = 0; g < MG; ++g) {
+        const int m = g * 4 + j;
+        act[g] = m < a.M;
+        xr[g] = a.x + (size_t)(act[g] ? m : 0) * a.ldx + kb * 8;
+    }
+    const float* __restrict__ nwp = RMS ? a.norm_w + kb * 8 : nullptr;
+
+    f32x4_t acc[NW][MG];
+    float ss[MG];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int g = 0; g < MG; ++g) acc[w][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < MG; ++g) ss[g] = 0.0f;
+
+    for (int sb = s0; sb < s1; sb += G) {
+        u32x4_t wa[G], wb[G];
+        float4 xa[G][MG], xb[G][MG], na[G], nb[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+            wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+            if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+            const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
+#pragma unroll
+            for (int g = 0; g < MG; ++g) {
+                xa[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko);
+                xb[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko + 4);
+            }
+            if constexpr (RMS) {
+                na[i] = *reinterpret_cast<const float4*>(nwp + ko);
+                nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = sb + i;
+            if (s < s1) {
+                const bool kok = (s * 128 + kb * 8) < a.K;
+#pragma unroll
+                for (int g = 0; g < MG; ++g) {
+                    const bool valid = act[g] && kok;
+                    float xv[8] = {xa[i][g].x, xa[i][g].y, xa[i][g].z, xa[i][g].w, xb[i][g].x, xb[i][g].y, xb[i][g].z, xb[i][g].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = valid ? xv[e] : 0.0f;
+                    if constexpr (RMS) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss[g] = fmaf(xv[e], xv[e], ss[g]);
+                        xv[0] *= na[i].x; xv[1] *= na[i].y; xv[2] *= na[i].z; xv[3] *= na[i].w;
+                        xv[4] *= nb[i].x; xv[5] *= nb[i].y; xv[6] *= nb[i].z; xv[7] *= nb[i].w;
+                    }
+                    const Split3 sp = split3(xv);
+                    acc[0][g] = mfma4_tile(wa[i], sp, acc[0][g]);
+                    if constexpr (NW == 2) acc[1][g] = mfma4_tile(wb[i], sp, acc[1][g]);
+                }
+            }
+        }
+    }
+    // sum the 16 k-blocks across lanes; lanes 0..3 (block 0) then hold D[i][j = lane] in acc[.][.][i]
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int g = 0; g < MG; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = sum_over_blocks(acc[w][g][i]);
+                if (lane < 4) red[wave][w][g][i][lane] = v;
+            }
+    if constexpr (RMS) {
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+            const float v = sum_over_blocks(ss[g]);
+            if (lane < 4) ssq[wave][g][lane] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < 16 * MG) {
+        const int m = tid >> 2, i = tid & 3, g = m >> 2, jj = m & 3;
+        const int n = blockIdx.x * 4 + i;
+        if (m < a.M && n < a.N) {
+            float v = 0.0f, v2 = 0.0f;
+            for (int w = 0; w < nwv; ++w) {
+                v += red[w][0][g][i][jj];
+                if constexpr (NW == 2) v2 += red[w][1][g][i][jj];
+            }
+            if constexpr (RMS) {
+                float tot = 0.0f;
+                for (int w = 0; w < nwv; ++w) tot += ssq[w][g][jj];
+                const float den = sqrtf(tot / (float)a.K + a.eps);
+                v = v / den;
+                if constexpr (NW == 2) v2 = v2 / den;
+            }
+            if (a.bias) v = v + a.bias[n];
+            if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n] + v;
+            if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+            if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+            a.y[(size_t)m * a.ldy + n] = v;
+        }
+    }
+}
+
+template <int EPI, bool RMS>
+static hipError_t launch_gemv4_t(const LinArgs& a, hipStream_t st) {
+    const int tiles = (a.N + 3) / 4;
+    const int S = a.Kpad >> 7;
+    const int nwv = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 1));
+    const int mg = (a.M + 3) / 4;
+    if (mg <= 1) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+    else if (mg == 2) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 4>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st) {
+    if (a.Kpad % 128 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
+        return hipErrorInvalidValue;
+    const bool rms = a.norm_w != nullptr;
+    switch (a.epi) {
+        case EPI_NONE: return rms ? launch_gemv4_t<EPI_NONE, true>(a, st) : launch_gemv4_t<EPI_NONE, false>(a, st);
+        case EPI_RESID: return rms ? hipErrorInvalidValue : launch_gemv4_t<EPI_RESID, false>(a, st);
+        case EPI_SILU: return rms ? hipErrorInvalidValue : launch_gemv4_t<EPI_SILU, false>(a, st);
+        case EPI_SWIGLU: return rms ? launch_gemv4_t<EPI_SWIGLU, true>(a, st) : launch_gemv4_t<EPI_SWIGLU, false>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st) {
     if (a.Kpad % 32 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
         return hipErrorInvalidValue;

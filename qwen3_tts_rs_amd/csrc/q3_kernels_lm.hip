@@ -251,7 +251,7 @@ static hipError_t launch_linear_mr(const LinArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_linear(const LinArgs& a, hipStream_t st) {
-    return a.tiled ? launch_gemv_tiled(a, st) : launch_linear_rowmajor(a, st);
+    return a.tiled == 2 ? launch_gemv_tiled4(a, st) : a.tiled == 1 ? launch_gemv_tiled(a, st) : launch_linear_rowmajor(a, st);
 }
 
 hipError_t launch_linear_rowmajor(const LinArgs& a, hipStream_t st) {
