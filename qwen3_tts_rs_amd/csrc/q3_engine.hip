@@ -130,12 +130,16 @@ enum SlotKind { SK_PLAIN = 0, SK_TRANSCONV = 1, SK_TILED = 2 };
 struct Slot {
     std::string name; int64_t n = 0; int stored = Q3_DTYPE_F32; size_t offset = 0; bool loaded = false;
     int kind = SK_PLAIN; int tc_cin = 0, tc_cout = 0, tc_k = 0, tc_stride = 0;
-    int rows = 0, cols = 0, tmode = 1;   // SK_TILED: logical [rows][cols]; stored as 16-row (1) or 4-row (2) MFMA tiles
+    int rows = 0, cols = 0;      // SK_TILED: logical [rows][cols]; 16-row-tile image at `offset`,
+    size_t offset2 = 0; bool dual = false;   // plus a 4-row-tile image at `offset2` when the projection is narrow
 };
+// a GEMV weight: 16-row-tile image (t1) and, for narrow projections, a 4-row-tile image (t2)
+struct TW { const uint16_t* t1 = nullptr; const uint16_t* t2 = nullptr; };
 struct LayerW {
     const float *in_ln, *q_norm, *k_norm, *post_ln;
-    const uint16_t *qkv, *o, *gate, *up, *down;
+    TW qkv, o, gate, up, down;
 };
+
 struct DecLayerW { const float *in_ln, *q, *k, *v, *o, *attn_scale, *post_ln, *gate, *up, *down, *mlp_scale; };
 struct ResUnitW { const float *a1, *ib1, *c1w, *c1b, *a2, *ib2, *c2w, *c2b; };
 struct DecBlockW { const float *a, *ib, *tw, *tb; ResUnitW res[3]; int cin, cout, rate; };
@@ -154,10 +158,11 @@ struct q3_model {
     const float* first_cb = nullptr; const float** rest_cbs_dev = nullptr; // device array of 15 pointers
     const uint16_t** cp_embs_dev = nullptr;                                // device array of 15 pointers
     // resolved pointers
-    const uint16_t *text_emb, *fc1w, *fc2w, *codec_emb, *codec_head, *mtp_w;
+    const uint16_t *text_emb, *codec_emb;
+    TW fc1w, fc2w, codec_head, mtp_w;
     const float *fc1b, *fc2b, *norm, *mtp_b, *cp_norm;
     std::vector<LayerW> tl, cl;
-    std::vector<const uint16_t*> cp_emb, cp_head;
+    std::vector<const uint16_t*> cp_emb; std::vector<TW> cp_head;
     const float *first_proj, *rest_proj, *pre_w, *pre_b, *inp_w, *inp_b, *outp_w, *outp_b, *dec_norm;
     std::vector<DecLayerW> dl;
     UpW up[2]; const float *init_w, *init_b; DecBlockW blk[4];
@@ -177,38 +182,66 @@ static inline int up16(int v) { return (v + 15) & ~15; }
 static inline int up32(int v) { return (v + 31) & ~31; }
 static inline int up4(int v) { return (v + 3) & ~3; }
 static inline int up128(int v) { return (v + 127) & ~127; }
-// GEMV tiling mode by the output width of the (possibly fused) projection: 4-row tiles below 4096 rows
-// (more workgroups for small matrices), 16-row tiles from 4096 rows up
-static inline int tmode(int n_total) { return n_total < 4096 ? 2 : 1; }
+// Narrow projections (fewer than 4096 output rows) keep BOTH tilings resident — HBM capacity is not the
+// constraint, launch latency is: the 4-row-tile kernel fills the chip for M <= 2 tokens (and for N <= 1024 up
+// to M = 8), the 16-row-tile kernel is cheaper per token for larger batches.
+static inline bool dual_tiled(int n_total) { return n_total < 4096; }
 static inline int kpad_for(int mode, int K) { return mode == 2 ? up128(K) : up32(K); }
 static inline size_t tiled_elems(int mode, int rows, int cols) {
     return mode == 2 ? (size_t)up4(rows) * up128(cols) : (size_t)up16(rows) * up32(cols);
 }
+
+static inline int pick_mode(const TW& w, int M, int N) {
+    if (w.t2 && (M <= 2 || (N <= 1024 && M <= 8) || !w.t1)) return 2;
+    return 1;
+}
+static inline void set_w(LinArgs& a, const TW& w, int M, int N, int K) {
+    a.tiled = pick_mode(w, M, N); a.W = a.tiled == 2 ? w.t2 : w.t1; a.Kpad = kpad_for(a.tiled, K);
+}
+static inline void set_w2(LinArgs& a, const TW& w, const TW& w2, int M, int N, int K) {
+    set_w(a, w, M, N, K); a.W2 = a.tiled == 2 ? w2.t2 : w2.t1;
+}
 // GEMV weight [rows][cols] bf16, stored MFMA-tiled (q3_kernels_gemv.hip); element count reported to the
 // caller stays rows*cols (the checkpoint's), the arena holds the padded tiled image.
-static void add_tiled(q3_model* m, const std::string& name, int rows, int cols, int mode, bool align = true) {
-    Slot s; s.name = name; s.n = (int64_t)rows * cols; s.stored = Q3_DTYPE_BF16; s.kind = SK_TILED; s.rows = rows; s.cols = cols; s.tmode = mode;
+static void add_tiled(q3_model* m, const std::string& name, int rows, int cols, bool dual, bool align = true) {
+    Slot s; s.name = name; s.n = (int64_t)rows * cols; s.stored = Q3_DTYPE_BF16; s.kind = SK_TILED; s.rows = rows; s.cols = cols; s.dual = dual;
     size_t off = m->arena_bytes;
     if (align) off = (off + 255) & ~(size_t)255;
     s.offset = off;
-    m->arena_bytes = off + tiled_elems(mode, rows, cols) * 2;
+    m->arena_bytes = off + tiled_elems(1, rows, cols) * 2;
     m->index[name] = (int)m->slots.size();
     m->slots.push_back(s);
+}
+// second (4-row-tile) images of a group of tensors, laid out back to back (fused QKV needs them contiguous)
+static void add_alt_images(q3_model* m, std::initializer_list<std::string> names) {
+    bool first = true;
+    for (const auto& nme : names) {
+        Slot& s = m->slots[m->index[nme]];
+        if (!s.dual) continue;
+        size_t off = m->arena_bytes;
+        if (first) off = (off + 255) & ~(size_t)255;
+        first = false;
+        s.offset2 = off;
+        m->arena_bytes = off + tiled_elems(2, s.rows, s.cols) * 2;
+    }
 }
 static void add_layer_slots(q3_model* m, const std::string& p, int H, int I, int nh, int nkv, int hd) {
     add_slot(m, p + ".input_layernorm.weight", H, Q3_DTYPE_F32);
     // q,k,v rows are stored back to back so the fused QKV GEMV sees one [QD+2KD][H] matrix
-    const int mq = tmode((nh + 2 * nkv) * hd);
-    add_tiled(m, p + ".self_attn.q_proj.weight", nh * hd, H, mq);
-    add_tiled(m, p + ".self_attn.k_proj.weight", nkv * hd, H, mq, false);
-    add_tiled(m, p + ".self_attn.v_proj.weight", nkv * hd, H, mq, false);
-    add_tiled(m, p + ".self_attn.o_proj.weight", H, nh * hd, tmode(H));
+    const bool dq = dual_tiled((nh + 2 * nkv) * hd);
+    add_tiled(m, p + ".self_attn.q_proj.weight", nh * hd, H, dq);
+    add_tiled(m, p + ".self_attn.k_proj.weight", nkv * hd, H, dq, false);
+    add_tiled(m, p + ".self_attn.v_proj.weight", nkv * hd, H, dq, false);
+    add_alt_images(m, {p + ".self_attn.q_proj.weight", p + ".self_attn.k_proj.weight", p + ".self_attn.v_proj.weight"});
+    add_tiled(m, p + ".self_attn.o_proj.weight", H, nh * hd, dual_tiled(H));
+    add_alt_images(m, {p + ".self_attn.o_proj.weight"});
     add_slot(m, p + ".self_attn.q_norm.weight", hd, Q3_DTYPE_F32);
     add_slot(m, p + ".self_attn.k_norm.weight", hd, Q3_DTYPE_F32);
     add_slot(m, p + ".post_attention_layernorm.weight", H, Q3_DTYPE_F32);
-    add_tiled(m, p + ".mlp.gate_proj.weight", I, H, tmode(I));
-    add_tiled(m, p + ".mlp.up_proj.weight", I, H, tmode(I));
-    add_tiled(m, p + ".mlp.down_proj.weight", H, I, tmode(H));
+    add_tiled(m, p + ".mlp.gate_proj.weight", I, H, dual_tiled(I));
+    add_tiled(m, p + ".mlp.up_proj.weight", I, H, dual_tiled(I));
+    add_tiled(m, p + ".mlp.down_proj.weight", H, I, dual_tiled(H));
+    add_alt_images(m, {p + ".mlp.gate_proj.weight"}); add_alt_images(m, {p + ".mlp.up_proj.weight"}); add_alt_images(m, {p + ".mlp.down_proj.weight"});
 }
 static std::string fmt(const char* f, ...) {
     char b[256]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return b;
@@ -220,17 +253,17 @@ static void build_manifest(q3_model* m) {
     const q3_config& c = m->cfg;
     const int H = c.hidden, TD = c.text_dim, CH = c.cp_hidden;
     add_slot(m, "talker.model.text_embedding.weight", (int64_t)c.text_vocab * TD, Q3_DTYPE_BF16);
-    add_tiled(m, "talker.text_projection.linear_fc1.weight", TD, TD, tmode(TD));
+    add_tiled(m, "talker.text_projection.linear_fc1.weight", TD, TD, dual_tiled(TD)); add_alt_images(m, {"talker.text_projection.linear_fc1.weight"});
     add_slot(m, "talker.text_projection.linear_fc1.bias", TD, Q3_DTYPE_F32);
-    add_tiled(m, "talker.text_projection.linear_fc2.weight", H, TD, tmode(H));
+    add_tiled(m, "talker.text_projection.linear_fc2.weight", H, TD, dual_tiled(H)); add_alt_images(m, {"talker.text_projection.linear_fc2.weight"});
     add_slot(m, "talker.text_projection.linear_fc2.bias", H, Q3_DTYPE_F32);
     add_slot(m, "talker.model.codec_embedding.weight", (int64_t)c.codec_vocab * H, Q3_DTYPE_BF16);
     for (int i = 0; i < c.n_layers; ++i)
         add_layer_slots(m, fmt("talker.model.layers.%d", i), H, c.inter, c.n_heads, c.n_kv_heads, c.head_dim);
     add_slot(m, "talker.model.norm.weight", H, Q3_DTYPE_F32);
-    add_tiled(m, "talker.codec_head.weight", c.codec_vocab, H, tmode(c.codec_vocab));
+    add_tiled(m, "talker.codec_head.weight", c.codec_vocab, H, dual_tiled(c.codec_vocab)); add_alt_images(m, {"talker.codec_head.weight"});
     if (H != CH) {
-        add_tiled(m, "talker.code_predictor.small_to_mtp_projection.weight", CH, H, tmode(CH));
+        add_tiled(m, "talker.code_predictor.small_to_mtp_projection.weight", CH, H, dual_tiled(CH)); add_alt_images(m, {"talker.code_predictor.small_to_mtp_projection.weight"});
         add_slot(m, "talker.code_predictor.small_to_mtp_projection.bias", CH, Q3_DTYPE_F32);
     }
     for (int g = 0; g < c.n_groups - 1; ++g)
@@ -239,7 +272,7 @@ static void build_manifest(q3_model* m) {
         add_layer_slots(m, fmt("talker.code_predictor.model.layers.%d", i), CH, c.cp_inter, c.cp_heads, c.cp_kv_heads, c.head_dim);
     add_slot(m, "talker.code_predictor.model.norm.weight", CH, Q3_DTYPE_F32);
     for (int g = 0; g < c.n_groups - 1; ++g)
-        add_tiled(m, fmt("talker.code_predictor.lm_head.%d.weight", g), c.cp_vocab, CH, tmode(c.cp_vocab));
+        { const std::string nm = fmt("talker.code_predictor.lm_head.%d.weight", g); add_tiled(m, nm, c.cp_vocab, CH, dual_tiled(c.cp_vocab)); add_alt_images(m, {nm}); }
     // decoder (all f32)
     const int CB = c.dec_cb_size, CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden;
     const int QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
@@ -415,10 +448,15 @@ extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtyp
         if (dtype == Q3_DTYPE_BF16) memcpy(w.data(), data, (size_t)n * 2);
         else if (dtype == Q3_DTYPE_F32) for (int64_t i = 0; i < n; ++i) w[(size_t)i] = f32_to_bf16_host(((const float*)data)[i]);
         else return set_err(Q3_INVALID_ARG, "unsupported source dtype %d", dtype);
-        up_bytes = tiled_elems(s.tmode, s.rows, s.cols) * 2;
+        up_bytes = tiled_elems(1, s.rows, s.cols) * 2;
         tmp.resize(up_bytes);
-        retile_bf16(w.data(), s.rows, s.cols, (uint16_t*)tmp.data(), s.tmode);
+        retile_bf16(w.data(), s.rows, s.cols, (uint16_t*)tmp.data(), 1);
         src = tmp.data();
+        if (s.dual) {
+            std::vector<uint16_t> t2(tiled_elems(2, s.rows, s.cols));
+            retile_bf16(w.data(), s.rows, s.cols, t2.data(), 2);
+            HIPC(hipMemcpy(m->arena + s.offset2, t2.data(), t2.size() * 2, hipMemcpyHostToDevice));
+        }
     } else if (s.kind == SK_TRANSCONV) {
         // [cin][cout][k] → per-phase causal-conv weights [stride][cout][cin][taps]
         std::vector<float> w((size_t)n);
@@ -473,16 +511,25 @@ static const T* P(const q3_model* m, const std::string& name) {
     if (it == m->index.end()) return nullptr;
     return (const T*)(m->arena + m->slots[it->second].offset);
 }
+static TW PT(const q3_model* m, const std::string& name) {
+    TW w;
+    auto it = m->index.find(name);
+    if (it == m->index.end()) return w;
+    const Slot& s = m->slots[it->second];
+    w.t1 = (const uint16_t*)(m->arena + s.offset);
+    if (s.dual) w.t2 = (const uint16_t*)(m->arena + s.offset2);
+    return w;
+}
 static void resolve_layer(const q3_model* m, LayerW& L, const std::string& p) {
     L.in_ln = P<float>(m, p + ".input_layernorm.weight");
-    L.qkv = P<uint16_t>(m, p + ".self_attn.q_proj.weight");
-    L.o = P<uint16_t>(m, p + ".self_attn.o_proj.weight");
+    L.qkv = PT(m, p + ".self_attn.q_proj.weight");
+    L.o = PT(m, p + ".self_attn.o_proj.weight");
     L.q_norm = P<float>(m, p + ".self_attn.q_norm.weight");
     L.k_norm = P<float>(m, p + ".self_attn.k_norm.weight");
     L.post_ln = P<float>(m, p + ".post_attention_layernorm.weight");
-    L.gate = P<uint16_t>(m, p + ".mlp.gate_proj.weight");
-    L.up = P<uint16_t>(m, p + ".mlp.up_proj.weight");
-    L.down = P<uint16_t>(m, p + ".mlp.down_proj.weight");
+    L.gate = PT(m, p + ".mlp.gate_proj.weight");
+    L.up = PT(m, p + ".mlp.up_proj.weight");
+    L.down = PT(m, p + ".mlp.down_proj.weight");
 }
 
 extern "C" q3_status q3_model_finalize(q3_model* m) {
@@ -493,14 +540,14 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
     HIPC(hipSetDevice(m->device));
     const q3_config& c = m->cfg;
     m->text_emb = P<uint16_t>(m, "talker.model.text_embedding.weight");
-    m->fc1w = P<uint16_t>(m, "talker.text_projection.linear_fc1.weight");
+    m->fc1w = PT(m, "talker.text_projection.linear_fc1.weight");
     m->fc1b = P<float>(m, "talker.text_projection.linear_fc1.bias");
-    m->fc2w = P<uint16_t>(m, "talker.text_projection.linear_fc2.weight");
+    m->fc2w = PT(m, "talker.text_projection.linear_fc2.weight");
     m->fc2b = P<float>(m, "talker.text_projection.linear_fc2.bias");
     m->codec_emb = P<uint16_t>(m, "talker.model.codec_embedding.weight");
     m->norm = P<float>(m, "talker.model.norm.weight");
-    m->codec_head = P<uint16_t>(m, "talker.codec_head.weight");
-    m->mtp_w = P<uint16_t>(m, "talker.code_predictor.small_to_mtp_projection.weight");
+    m->codec_head = PT(m, "talker.codec_head.weight");
+    m->mtp_w = PT(m, "talker.code_predictor.small_to_mtp_projection.weight");
     m->mtp_b = P<float>(m, "talker.code_predictor.small_to_mtp_projection.bias");
     m->cp_norm = P<float>(m, "talker.code_predictor.model.norm.weight");
     m->tl.resize(c.n_layers); m->cl.resize(c.cp_layers);
@@ -509,7 +556,7 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
     m->cp_emb.resize(15); m->cp_head.resize(15);
     for (int g = 0; g < 15; ++g) {
         m->cp_emb[g] = P<uint16_t>(m, fmt("talker.code_predictor.model.codec_embedding.%d.weight", g));
-        m->cp_head[g] = P<uint16_t>(m, fmt("talker.code_predictor.lm_head.%d.weight", g));
+        m->cp_head[g] = PT(m, fmt("talker.code_predictor.lm_head.%d.weight", g));
     }
     if (!m->cp_embs_dev) HIPC(hipMalloc((void**)&m->cp_embs_dev, 15 * sizeof(void*)));
     HIPC(hipMemcpy((void*)m->cp_embs_dev, m->cp_emb.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
@@ -863,8 +910,8 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     const q3_model* m = s->m;
     const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, B = s->B;
     LinArgs a;
-    a.W = w.qkv; a.N = QD + 2 * KD; a.K = d.H; a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
-    a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE; a.tiled = tmode(QD + 2 * KD); a.Kpad = kpad_for(a.tiled, d.H);
+    a.N = QD + 2 * KD; a.K = d.H; set_w(a, w.qkv, B, a.N, a.K); a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
+    a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE;
     HIPC(run_linear(s, a));
     AttnArgs t{};
     t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
@@ -880,14 +927,14 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
         if (n_splits > 1) HIPC(launch_attn_merge(t, s->stream));
     }
     LinArgs o;
-    o.W = w.o; o.N = d.H; o.K = QD; o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID; o.tiled = tmode(d.H); o.Kpad = kpad_for(o.tiled, QD);
+    o.N = d.H; o.K = QD; set_w(o, w.o, B, o.N, o.K); o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID;
     HIPC(run_linear(s, o));
     LinArgs g;
-    g.W = w.gate; g.W2 = w.up; g.N = d.I; g.K = d.H; g.x = b.SUM; g.ldx = d.H; g.norm_w = w.post_ln; g.eps = d.eps;
-    g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU; g.tiled = tmode(d.I); g.Kpad = kpad_for(g.tiled, d.H);
+    g.N = d.I; g.K = d.H; set_w2(g, w.gate, w.up, B, g.N, g.K); g.x = b.SUM; g.ldx = d.H; g.norm_w = w.post_ln; g.eps = d.eps;
+    g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU;
     HIPC(run_linear(s, g));
     LinArgs dn;
-    dn.W = w.down; dn.N = d.H; dn.K = d.I; dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID; dn.tiled = tmode(d.H); dn.Kpad = kpad_for(dn.tiled, d.I);
+    dn.N = d.H; dn.K = d.I; set_w(dn, w.down, B, dn.N, dn.K); dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID;
     HIPC(run_linear(s, dn));
     return Q3_OK;
 }
@@ -906,8 +953,8 @@ static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, 
     if (with_head) {
         HIPC(launch_rmsnorm(s->tb.X, c.hidden, m->norm, s->LASTH, c.hidden, s->B, c.hidden, c.rms_eps, s->stream));
         LinArgs h;
-        h.W = m->codec_head; h.N = c.codec_vocab; h.K = c.hidden; h.x = s->LASTH; h.ldx = c.hidden; h.y = s->LOGITS; h.ldy = c.codec_vocab;
-        h.M = s->B; h.epi = EPI_NONE; h.tiled = tmode(c.codec_vocab); h.Kpad = kpad_for(h.tiled, c.hidden);
+        h.N = c.codec_vocab; h.K = c.hidden; set_w(h, m->codec_head, s->B, h.N, h.K); h.x = s->LASTH; h.ldx = c.hidden; h.y = s->LOGITS; h.ldy = c.codec_vocab;
+        h.M = s->B; h.epi = EPI_NONE;
         HIPC(run_linear(s, h));
     }
     return Q3_OK;
@@ -929,11 +976,11 @@ static q3_status cp_run(q3_session* s) {
         g.cp_emb = p >= 2 ? m->cp_emb[p - 2] : nullptr;
         g.cp_logits = p >= 2 ? s->CP_LOGITS + (size_t)(p - 2) * B * V : nullptr;
         g.cp_vocab = V; g.codes = s->codes; g.frame_idx = s->frame_idx; g.max_frames = s->max_frames; g.B = B;
-        if (m->mtp_w) { g.out = s->CP_IN; g.ld_out = H; } else { g.out = s->cb.X; g.ld_out = CH; }
+        if (m->mtp_w.t1) { g.out = s->CP_IN; g.ld_out = H; } else { g.out = s->cb.X; g.ld_out = CH; }
         HIPC(launch_cp_gather(g, s->stream));
-        if (m->mtp_w) {
+        if (m->mtp_w.t1) {
             LinArgs a;
-            a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = tmode(CH); a.Kpad = kpad_for(a.tiled, H);
+            a.N = CH; a.K = H; set_w(a, m->mtp_w, B, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
             HIPC(run_linear(s, a));
         }
         for (int i = 0; i < c.cp_layers; ++i)
@@ -941,8 +988,8 @@ static q3_status cp_run(q3_session* s) {
                          n_pass + 1, nullptr, p, 1));
         if (p >= 1) {
             LinArgs h;
-            h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
-            h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = tmode(V); h.Kpad = kpad_for(h.tiled, CH);
+            h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
+            h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
             HIPC(run_linear(s, h));
         }
     }
@@ -996,7 +1043,7 @@ static bool opts_equal_sampling(const q3_options& a, const q3_options& b) {
 extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out) {
     if (!m || !reqs || !out) return set_err(Q3_INVALID_ARG, "q3_session_create: null argument");
     if (!m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
-    if (batch < 1 || batch > 8) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..8 per GPU)", batch);
+    if (batch < 1 || batch > 16) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..16 per GPU)", batch);
     HIPC(hipSetDevice(m->device));
     const q3_config& c = m->cfg;
     std::unique_ptr<q3_session> s(new q3_session());
@@ -1137,11 +1184,11 @@ static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, flo
     for (int r0 = 0; r0 < n && er == hipSuccess; r0 += 8) {
         const int M = (n - r0) < 8 ? (n - r0) : 8;
         LinArgs a;
-        a.W = m->fc1w; a.N = TD; a.K = TD; a.x = e + (size_t)r0 * TD; a.ldx = TD; a.bias = m->fc1b; a.y = h + (size_t)r0 * TD; a.ldy = TD; a.M = M; a.epi = EPI_SILU; a.tiled = tmode(TD); a.Kpad = kpad_for(a.tiled, TD);
+        a.N = TD; a.K = TD; set_w(a, m->fc1w, M, TD, TD); a.x = e + (size_t)r0 * TD; a.ldx = TD; a.bias = m->fc1b; a.y = h + (size_t)r0 * TD; a.ldy = TD; a.M = M; a.epi = EPI_SILU;
         er = launch_linear(a, s->stream);
         if (er != hipSuccess) break;
         LinArgs b2;
-        b2.W = m->fc2w; b2.N = H; b2.K = TD; b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE; b2.tiled = tmode(H); b2.Kpad = kpad_for(b2.tiled, TD);
+        b2.N = H; b2.K = TD; set_w(b2, m->fc2w, M, H, TD); b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE;
         er = launch_linear(b2, s->stream);
     }
     if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
@@ -1461,13 +1508,13 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
             g.cp_emb = p >= 2 ? m->cp_emb[p - 2] : nullptr;
             g.cp_logits = p >= 2 ? s->CP_LOGITS + (size_t)(p - 2) * B * V : nullptr;
             g.cp_vocab = V; g.codes = s->codes; g.frame_idx = s->frame_idx; g.max_frames = s->max_frames; g.B = B;
-            float* dst = m->mtp_w ? s->CP_IN : s->cb.X; const int ld = m->mtp_w ? H : CH;
+            float* dst = m->mtp_w.t1 ? s->CP_IN : s->cb.X; const int ld = m->mtp_w.t1 ? H : CH;
             g.out = dst; g.ld_out = ld;
             if (p == 1 && sem_dev) HIPC(launch_copy_rows(sem_dev, H, dst, ld, B, H, s->stream));
             else HIPC(launch_cp_gather(g, s->stream));
-            if (m->mtp_w) {
+            if (m->mtp_w.t1) {
                 LinArgs a;
-                a.W = m->mtp_w; a.N = CH; a.K = H; a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE; a.tiled = tmode(CH); a.Kpad = kpad_for(a.tiled, H);
+                a.N = CH; a.K = H; set_w(a, m->mtp_w, B, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
                 HIPC(launch_linear(a, s->stream));
             }
             for (int i = 0; i < c.cp_layers; ++i)
@@ -1475,8 +1522,8 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
                              c.n_groups + 1, nullptr, p, 1));
             if (p >= 1) {
                 LinArgs h;
-                h.W = m->cp_head[p - 1]; h.N = V; h.K = CH; h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
-                h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE; h.tiled = tmode(V); h.Kpad = kpad_for(h.tiled, CH);
+                h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
+                h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
                 HIPC(launch_linear(h, s->stream));
             }
         }
@@ -1580,7 +1627,7 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
     HIPC(hipSetDevice(device));
     DevPool pool;
     float *x, *y, *b = nullptr; uint16_t* w;
-    const int mode = tmode(N);
+    const int mode = (N < 4096 && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;
     const size_t wt_elems = tiled_elems(mode, N, K);
     std::vector<uint16_t> wt(wt_elems);
     retile_bf16(w_host, N, K, wt.data(), mode);

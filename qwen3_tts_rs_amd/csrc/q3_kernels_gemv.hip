@@ -28,10 +28,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// one v_cvt_pk_bf16_f32 (RNE); written as a compiler builtin, NOT inline asm, so that hipcc's hazard
+// recognizer pads the VALU-write → MFMA-operand-read wait states itself (an asm statement is opaque to it:
+// the 4x4x4 kernel read stale operands with the asm form)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 struct Split3 { u32x4_t hi, mid, lo; };
