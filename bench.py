@@ -116,25 +116,40 @@ def main():
              "generation_ms": float(np.mean([t.generation_ms for t in timings])),
              "decode_ms": float(np.mean([t.decode_ms for t in timings]))}
 
-    # ---- roofline of the dominant kernel (bf16 GEMV family), HIP events on the session stream ----
-    s = model.session(utts, q.SynthesisOptions(max_length=args.profile_frames + 2, eos_token_id=None, seed=42))
-    s.prefill()
-    s.generate(2, use_graph=False)
-    prof_mode = "graph-event-nodes"
-    try:
-        s.profile_frames(args.profile_frames)
-    except Exception:
-        prof_mode = "eager-events"
-        s.set_profile(True)
-        s.generate(args.profile_frames, use_graph=False)
-    ms, nbytes, launches = s.profile_read()
+    # ---- roofline of the dominant kernel: the bf16-weight MFMA GEMV family (every projection of the frame) ----
+    # Each distinct (N, K, epilogue) of one frame is replayed from a hipGraph over HBM-resident weight copies
+    # and timed with HIP events on the launch stream (q3_bench_linear); achieved = Σ algorithmic weight bytes
+    # of one frame's GEMV launches ÷ Σ their measured launch times, M = this run's batch.
+    from qwen3_tts_rs_amd.api import bench_linear
+    H, I, CH, CI = cfg.hidden, cfg.inter, cfg.cp_hidden, cfg.cp_inter
+    QD, KD = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
+    CQD, CKD = cfg.cp_heads * cfg.head_dim, cfg.cp_kv_heads * cfg.head_dim
+    n_pass = cfg.n_groups
+    inventory = [  # (name, N, K, epi, rms, launches per frame)
+        ("talker qkv", QD + 2 * KD, H, 0, True, cfg.n_layers), ("talker o", H, QD, 1, False, cfg.n_layers),
+        ("talker gate/up", I, H, 3, True, cfg.n_layers), ("talker down", H, I, 1, False, cfg.n_layers),
+        ("codec head", cfg.codec_vocab, H, 0, False, 1),
+        ("cp qkv", CQD + 2 * CKD, CH, 0, True, cfg.cp_layers * n_pass), ("cp o", CH, CQD, 1, False, cfg.cp_layers * n_pass),
+        ("cp gate/up", CI, CH, 3, True, cfg.cp_layers * n_pass), ("cp down", CH, CI, 1, False, cfg.cp_layers * n_pass),
+        ("cp lm_head", cfg.cp_vocab, CH, 0, True, n_pass - 1),
+    ]
+    if H != CH:
+        inventory.append(("cp mtp proj", CH, H, 0, False, n_pass))
+    tot_bytes = tot_us = 0.0; launches = 0; per_shape = {}
+    for name, N, K, epi, rms, cnt in inventory:
+        us = bench_linear(min(B, 16), N, K, epi, rms, device=dev)
+        nb = N * K * 2 * (2 if epi == 3 else 1)
+        per_shape[name] = {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
+        tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
+    s = model.session(utts, q.SynthesisOptions(max_length=4, eos_token_id=None, seed=42))
     wbytes, kvbytes = s.frame_bytes(10 + args.frames // 2)
     s.close()
-    achieved = (nbytes / (ms / 1000.0)) / 1e9 if ms > 0 else 0.0
+    achieved = tot_bytes / tot_us / 1e3     # GB/s
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": None, "kernel": "k_gemv_mfma<EPI,RMS,NWAVES> (bf16-weight MFMA GEMV family)", "timing": prof_mode,
-                "launches_measured": launches, "avg_launch_us": (ms * 1000.0 / launches) if launches else None,
-                "avg_bytes_per_launch": (nbytes / launches) if launches else None,
+                "traffic": None, "kernel": "k_gemv_mfma / k_gemv_mfma4 (bf16-weight MFMA GEMV family, M = batch)",
+                "timing": "hipGraph replay of each GEMV shape over HBM-resident weight copies, HIP events on the launch stream",
+                "launches_per_frame": launches, "avg_launch_us": tot_us / launches, "avg_bytes_per_launch": tot_bytes / launches,
+                "gemv_us_per_frame": tot_us, "per_shape": per_shape,
                 "frame_weight_bytes": wbytes, "frame_kv_bytes": kvbytes,
                 "frame_model_gbps": (wbytes + kvbytes) / (stage["generation_ms"] / 1000.0 / args.frames) / 1e9}
 

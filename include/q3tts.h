@@ -234,10 +234,10 @@ q3_status q3_session_set_profile(q3_session* s, int enable);
 /* accumulated since the last reset: GPU milliseconds, algorithmic weight bytes and launch count of
  * the bf16 GEMV family (the dominant kernel) */
 q3_status q3_session_profile_read(q3_session* s, double* ms, double* bytes, long* launches, int reset);
-/* generate `reps` frames from a graph that carries event-record nodes around every GEMV launch (GPU-side
- * timestamps, no host launch latency inside the measured intervals); results via q3_session_profile_read */
-q3_status q3_session_profile_frames(q3_session* s, int reps);
-/* kernel development aid: µs per launch of one GEMV shape replayed from a graph (tests/bench_kernels.py) */
+/* µs per launch of one GEMV shape: `iters` launches over `n_copies` distinct weight buffers (HBM-resident
+ * stream, not Infinity-Cache hits) replayed from one hipGraph and timed with HIP events on that stream.
+ * tiled: 1 = 16-row tiles, 2 = 4-row tiles, 0 = first-generation row-major kernel, -1 = the engine's choice.
+ * Used by bench.py for the roofline of the dominant kernel and by tests/bench_kernels.py. */
 q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                           double* avg_us);
 /* raw stream handle (hipStream_t) the session launches on */

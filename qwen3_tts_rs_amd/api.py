@@ -260,9 +260,6 @@ class Session:
     def set_profile(self, on: bool):
         check(lib.q3_session_set_profile(self._h, 1 if on else 0))
 
-    def profile_frames(self, reps: int):
-        check(lib.q3_session_profile_frames(self._h, int(reps)))
-
     def profile_read(self, reset: bool = True) -> Tuple[float, float, int]:
         ms = ctypes.c_double(); by = ctypes.c_double(); n = ctypes.c_long()
         check(lib.q3_session_profile_read(self._h, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n), 1 if reset else 0))
@@ -463,6 +460,17 @@ def sample(logits: np.ndarray, u: np.ndarray, options: SynthesisOptions, seen: O
                         uu.ctypes.data_as(ctypes.c_void_p), rows, vocab, ctypes.byref(o), token_count,
                         out.ctypes.data_as(ctypes.c_void_p)))
     return out
+
+
+def bench_linear(M: int, N: int, K: int, epi: int = 0, rms: bool = False, tiled: int = -1, iters: int = 200,
+                 n_copies: int = 0, device: int = 0) -> float:
+    """µs per launch of one GEMV shape (graph replay over HBM-resident weight copies)."""
+    nbytes = N * K * 2 * (2 if epi == 3 else 1)
+    if n_copies <= 0:
+        n_copies = max(2, int(600e6 // nbytes))
+    us = ctypes.c_double()
+    check(lib.q3_bench_linear(device, M, N, K, epi, 1 if rms else 0, tiled, iters, n_copies, ctypes.byref(us)))
+    return us.value
 
 
 def auto_device() -> int:

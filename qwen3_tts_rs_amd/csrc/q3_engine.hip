@@ -1678,6 +1678,7 @@ extern "C" q3_status q3_session_profile_read(q3_session* s, double* ms, double* 
 extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                                      double* avg_us) {
     if (M < 1 || M > 16 || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
+    if (tiled < 0) tiled = (N < 4096 && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
     HIPC(hipSetDevice(device));
     DevPool pool;
     const size_t welems = tiled == 2 ? tiled_elems(2, N, K) : tiled_elems(1, N, K);
@@ -1729,40 +1730,3 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
     return Q3_OK;
 }
 
-// Profile `reps` frames with GPU-side timestamps: one frame is captured into a hipGraph WITH event-record
-// nodes around every GEMV launch, replayed `reps` times (each replay is a real generation frame), and the
-// per-launch elapsed times are accumulated into the profile counters (q3_session_profile_read).
-extern "C" q3_status q3_session_profile_frames(q3_session* s, int reps) {
-    if (!s || reps < 1) return set_err(Q3_INVALID_ARG, "bad argument");
-    if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
-    if (s->debug) return set_err(Q3_INVALID_ARG, "debug sessions cannot be graph-profiled");
-    if (s->frames_run + reps > s->max_frames) return set_err(Q3_INVALID_ARG, "not enough frames left (%d + %d > %d)", s->frames_run, reps, s->max_frames);
-    HIPC(hipSetDevice(s->m->device));
-    if (s->prof_pool.empty()) {
-        s->prof_pool.resize(2048);
-        for (auto& ev : s->prof_pool) HIPC(hipEventCreate(&ev));
-    }
-    s->prof_pool_next = 0; s->prof_events.clear(); s->prof_event_bytes.clear();
-    const bool was = s->profile; s->profile = true;
-    HIPC(hipStreamSynchronize(s->stream));
-    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-    HIPC(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    q3_status st = frame_launch(s);
-    hipError_t e = hipStreamEndCapture(s->stream, &g);
-    s->profile = was;
-    if (st != Q3_OK) return st;
-    if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "profile capture: %s", hipGetErrorString(e));
-    HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    for (int r = 0; r < reps; ++r) {
-        HIPC(hipGraphLaunch(ge, s->stream));
-        HIPC(hipStreamSynchronize(s->stream));
-        s->frames_run += 1; s->codes_host_valid = false;
-        for (size_t i = 0; i < s->prof_events.size(); ++i) {
-            float ms = 0; HIPC(hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second));
-            s->prof_linear.ms += ms; s->prof_linear.bytes += s->prof_event_bytes[i]; s->prof_linear.launches += 1;
-        }
-    }
-    s->prof_events.clear(); s->prof_event_bytes.clear(); s->prof_pool_next = 0;
-    hipGraphExecDestroy(ge); hipGraphDestroy(g);
-    return Q3_OK;
-}
