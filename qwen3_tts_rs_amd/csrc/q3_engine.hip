@@ -674,12 +674,12 @@ struct DevPool {
 // ------------------------------------------------------------------------------------------------
 struct CodecWS {
     int cap_frames = 0;
-    float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr, *bufE = nullptr;
+    float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufF = nullptr, *bufD = nullptr, *bufE = nullptr;
     float *cs = nullptr, *sn = nullptr;
     uint32_t* frames = nullptr; float* pcm = nullptr;
     void release() {
-        hipFree(bufA); hipFree(bufB); hipFree(bufC); hipFree(bufD); hipFree(bufE); hipFree(cs); hipFree(sn); hipFree(frames); hipFree(pcm);
-        bufA = bufB = bufC = bufD = bufE = cs = sn = pcm = nullptr; frames = nullptr; cap_frames = 0;
+        hipFree(bufA); hipFree(bufB); hipFree(bufC); hipFree(bufF); hipFree(bufD); hipFree(bufE); hipFree(cs); hipFree(sn); hipFree(frames); hipFree(pcm);
+        bufA = bufB = bufC = bufF = bufD = bufE = cs = sn = pcm = nullptr; frames = nullptr; cap_frames = 0;
     }
 };
 
@@ -694,6 +694,7 @@ static q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T) {
       for (int b = 0; b < 4; ++b) { L *= c.dec_up_rates[b]; C /= 2; if ((size_t)C * L > per) per = (size_t)C * L; } }
     const size_t n = per * (size_t)T;
     HIPC(hipMalloc((void**)&ws.bufA, n * 4)); HIPC(hipMalloc((void**)&ws.bufB, n * 4)); HIPC(hipMalloc((void**)&ws.bufC, n * 4));
+    HIPC(hipMalloc((void**)&ws.bufF, n * 4));
     const size_t small = (size_t)T * (size_t)(c.dec_heads * c.dec_head_dim > c.dec_latent ? c.dec_heads * c.dec_head_dim : c.dec_latent);
     HIPC(hipMalloc((void**)&ws.bufD, small * 4)); HIPC(hipMalloc((void**)&ws.bufE, small * 4));
     HIPC(hipMalloc((void**)&ws.cs, (size_t)T * 32 * 4)); HIPC(hipMalloc((void**)&ws.sn, (size_t)T * 32 * 4));
@@ -793,29 +794,52 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
         Q3C(TAP(Q3_DEC_UP0 + i, cur, (size_t)LAT * L));
     }
     (void)o1; (void)o2;
-    // D5 decoder.0: → x in (other buffer)
+    // D5-D9. SnakeBeta is applied by the PRODUCER's epilogue (each element activated once, not once per
+    // consuming output-channel tile): every tensor below exists as "raw" (residual / tap) and/or "act"
+    // (= snake of the next consumer).
     int Cc = c.dec_dim;
-    float* x = (cur == A) ? B : A;
-    HIPC(convk(cur, m->init_w, m->init_b, x, LAT, Cc, L, 7, 1, st));
-    Q3C(TAP(Q3_DEC_INIT, x, (size_t)Cc * L));
-    // D6 decoder blocks
+    float* pool4[4] = {A, B, C, ws.bufF};
+    auto other = [&](std::initializer_list<const float*> used) -> float* {
+        for (float* p : pool4) { bool u = false; for (const float* q : used) if (q == p) u = true; if (!u) return p; }
+        return nullptr;
+    };
+    // decoder.0 (k=7): raw only if tapped; activated with block 0's snake
+    float* xact = other({cur});
+    {
+        ConvArgs a; a.x = cur; a.w = m->init_w; a.b = m->init_b; a.cin = LAT; a.cout = Cc; a.L = L; a.k = 7; a.dil = 1;
+        a.post_a = m->blk[0].a; a.post_ib = m->blk[0].ib;
+        if (taps && taps[Q3_DEC_INIT]) { float* raw = other({cur, xact}); a.y = raw; a.y2 = xact; HIPC(launch_conv1d(a, st)); Q3C(TAP(Q3_DEC_INIT, raw, (size_t)Cc * L)); }
+        else { a.y = xact; HIPC(launch_conv1d(a, st)); }
+    }
     static const int dils[3] = {1, 3, 9};
     for (int b = 0; b < 4; ++b) {
         const DecBlockW& Bk = m->blk[b];
-        float* y = (x == A) ? B : A;
-        HIPC(launch_transconv1d_taps(x, Bk.tw, Bk.tb, y, Bk.cin, Bk.cout, L, Bk.rate, 2, Bk.a, Bk.ib, st));
+        // transposed conv: raw Y (residual of unit 0) + YA = snake(act1 of unit 0)
+        float* Y = other({xact});
+        float* YA = other({xact, Y});
+        HIPC(launch_transconv1d_taps(xact, Bk.tw, Bk.tb, Y, Bk.cin, Bk.cout, L, Bk.rate, 2, nullptr, nullptr, st, Bk.res[0].a1, Bk.res[0].ib1, YA));
         L *= Bk.rate; Cc = Bk.cout;
-        float* t2 = C;
+        float* T2 = other({Y, YA});
         for (int uu = 0; uu < 3; ++uu) {
             const ResUnitW& R = Bk.res[uu];
-            HIPC(convk(y, R.c1w, R.c1b, t2, Cc, Cc, L, 7, dils[uu], st, R.a1, R.ib1));
-            HIPC(conv1(t2, R.c2w, R.c2b, y, Cc, Cc, L, st, y, nullptr, 0, R.a2, R.ib2));
+            {   // conv7 (dilated) on the activated input; output activated with act2
+                ConvArgs a; a.x = YA; a.w = R.c1w; a.b = R.c1b; a.y = T2; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 7; a.dil = dils[uu];
+                a.post_a = R.a2; a.post_ib = R.ib2;
+                HIPC(launch_conv1d(a, st));
+            }
+            {   // conv1 + residual: raw → Y (in place), activated → YA for the next consumer
+                ConvArgs a; a.x = T2; a.w = R.c2w; a.b = R.c2b; a.y = Y; a.y2 = YA; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 1; a.dil = 1; a.resid = Y;
+                if (uu < 2) { a.post_a = Bk.res[uu + 1].a1; a.post_ib = Bk.res[uu + 1].ib1; }
+                else if (b < 3) { a.post_a = m->blk[b + 1].a; a.post_ib = m->blk[b + 1].ib; }
+                else { a.post_a = m->fin_a; a.post_ib = m->fin_ib; }
+                HIPC(launch_conv1d(a, st));
+            }
         }
-        x = y;
-        Q3C(TAP(Q3_DEC_BLK0 + b, x, (size_t)Cc * L));
+        Q3C(TAP(Q3_DEC_BLK0 + b, Y, (size_t)Cc * L));
+        xact = YA;
     }
-    // D9 final snake + conv + clamp
-    HIPC(convk(x, m->fin_w, m->fin_b, ws.pcm, Cc, 1, L, 7, 1, st, m->fin_a, m->fin_ib, 2));
+    // D9 final conv on the activated tensor + clamp
+    HIPC(convk(xact, m->fin_w, m->fin_b, ws.pcm, Cc, 1, L, 7, 1, st, nullptr, nullptr, 2));
     return Q3_OK;
 }
 

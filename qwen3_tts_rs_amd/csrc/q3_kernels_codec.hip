@@ -10,6 +10,7 @@
 #include "q3_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace q3 {
 
@@ -34,6 +35,8 @@ struct ConvDev {
     int ostride, ooff, oL;        // output indexing (transposed conv phases write strided)
     size_t w_phase_stride;        // weight offset per blockIdx.z
     int ooff_phase;               // output offset added per blockIdx.z
+    const float* post_a; const float* post_ib;   // SnakeBeta applied to the OUTPUT (the consumer's activation)
+    float* y2;                    // if set: y gets the raw value, y2 the activated one; else y gets the activated value
 };
 
 __global__ __launch_bounds__(256) void k_conv1d(ConvDev a) {
@@ -105,8 +108,127 @@ __global__ __launch_bounds__(256) void k_conv1d(ConvDev a) {
             const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
             if (a.resid) v = a.resid[oi] + v;
             if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
-            a.y[oi] = v;
+            if (a.post_a) {
+                const float va = snake_f(v, a.post_a[o], a.post_ib[o]);
+                if (a.y2) { a.y[oi] = v; a.y2[oi] = va; } else a.y[oi] = va;
+            } else {
+                a.y[oi] = v;
+            }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Same conv as an implicit GEMM on the f32 matrix cores: v_mfma_f32_32x32x2_f32 is an exact f32 fmaf chain
+// at the f32 vector peak (157 TF) that leaves the VALU free for the SnakeBeta staging and the epilogue.
+// Reduction index r = ci*K + kk; one MFMA consumes two consecutive r: A[i][k] = W[co0+i][r0+k] (lane i = l&31,
+// k = l>>5), B[k][j] = x'[ci(r0+k)][t0 + j - (K-1-kk)·dil]. Block = 4 waves; CO_W = 2: 64 co × 128 t (each wave
+// 32 co × 64 t = two 32×32 accumulators sharing one A fragment); CO_W = 1: 32 co × 256 t (cout = 96).
+// LDS: x tile [16 ci][T_T + halo] (SnakeBeta applied once at staging), w tile [16·K][32·CO_W] (co fastest).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int K, int CO_W, int CI_T>
+__global__ __launch_bounds__(256) void k_conv1d_mfma(ConvDev a) {
+    constexpr int CO_T = 32 * CO_W, T_W = 4 / CO_W, T_T = 64 * T_W;
+    constexpr int R_T = CI_T * K;
+    constexpr int XW = T_T + (K > 1 ? CV_MAXHALO : 0) + 2;
+    __shared__ float xs[CI_T][XW];
+    __shared__ float ws[R_T][CO_T + 1];                 // +1: conflict-free transposing stores
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wco = wave % CO_W, wt = wave / CO_W;
+    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const float* w = a.w + (size_t)blockIdx.z * a.w_phase_stride;
+    const int ooff = a.ooff + (int)blockIdx.z * a.ooff_phase;
+    const int halo = (K - 1) * a.dil;
+    const int W = T_T + halo;
+    f32x16_t acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+    const int li = lane & 31, lk = lane >> 5;
+
+    for (int ci0 = 0; ci0 < a.cin; ci0 += CI_T) {
+        __syncthreads();
+        // x tile: one wave per input-channel row, lanes along time (coalesced, no index division)
+        for (int ci = wave; ci < CI_T; ci += 4) {
+            const int c = ci0 + ci;
+            const float* xrow = a.x + (size_t)c * a.L;
+            const bool cok = c < a.cin;
+            float sa = 0.0f, sib = 0.0f;
+            if (a.snake_a && cok) { sa = a.snake_a[c]; sib = a.snake_ib[c]; }
+            for (int tt = lane; tt < W; tt += 64) {
+                const int t = t0 - halo + tt;
+                float v = 0.0f;
+                if (cok && t >= 0 && t < a.L) {
+                    v = xrow[t];
+                    if (a.snake_a) v = snake_f(v, sa, sib);
+                }
+                xs[ci][tt] = v;
+            }
+        }
+        // w tile: for a fixed output channel the chunk's (ci, kk) run is contiguous in memory → coalesced reads
+        const int r_valid = (a.cin - ci0) * K;
+        for (int e = tid; e < R_T * CO_T; e += 256) {
+            const int co = e / R_T, r = e - co * R_T;
+            const int o = co0 + co;
+            ws[r][co] = (o < a.cout && r < r_valid) ? w[((size_t)o * a.cin + ci0) * K + r] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r0 = 0; r0 < R_T; r0 += 2) {
+            const int r = r0 + lk;
+            const int ci = r / K, kk = r - ci * K;
+            const float av = ws[r][wco * 32 + li];
+            const float* xrow = &xs[ci][wt * 64 + li + kk * a.dil];
+            const float b0 = xrow[0], b1 = xrow[32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int t = t0 + wt * 64 + half * 32 + li;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int o = co0 + wco * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            if (o >= a.cout || t >= a.L) continue;
+            float v = (half == 0 ? acc0[reg] : acc1[reg]) + (a.b ? a.b[o] : 0.0f);
+            if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (a.scale) v = v * a.scale[o];
+            const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
+            if (a.resid) v = a.resid[oi] + v;
+            if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
+            if (a.post_a) {
+                const float va = snake_f(v, a.post_a[o], a.post_ib[o]);
+                if (a.y2) { a.y[oi] = v; a.y2[oi] = va; } else a.y[oi] = va;
+            } else {
+                a.y[oi] = v;
+            }
+        }
+    }
+}
+
+template <int K>
+static hipError_t launch_conv_mfma_k(const ConvDev& a, int phases, hipStream_t st) {
+    if (a.cout % 64 == 0) {
+        dim3 grid((a.L + 127) / 128, a.cout / 64, phases);
+        hipLaunchKernelGGL((k_conv1d_mfma<K, 2, 16>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((a.L + 255) / 256, (a.cout + 31) / 32, phases);
+        hipLaunchKernelGGL((k_conv1d_mfma<K, 1, 16>), grid, dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+// returns hipErrorNotSupported when the shape should use the VALU kernel
+static hipError_t launch_conv_mfma(const ConvDev& a, int phases, hipStream_t st) {
+    static const bool off = getenv("Q3_CONV_VALU") != nullptr;       // A/B aid
+    if (off || a.cout < 32) return hipErrorNotSupported;
+    switch (a.k) {
+        case 1: return launch_conv_mfma_k<1>(a, phases, st);
+        case 2: return launch_conv_mfma_k<2>(a, phases, st);
+        case 3: return launch_conv_mfma_k<3>(a, phases, st);
+        case 7: return launch_conv_mfma_k<7>(a, phases, st);
+        default: return hipErrorNotSupported;
     }
 }
 
@@ -136,8 +258,11 @@ hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
     a.x = c.x; a.w = c.w; a.b = c.b; a.y = c.y; a.cin = c.cin; a.cout = c.cout; a.L = c.L; a.k = c.k; a.dil = c.dil;
     a.snake_a = c.snake_a; a.snake_ib = c.snake_b; a.resid = c.resid; a.scale = c.scale; a.act = c.act;
     a.ostride = 1; a.ooff = 0; a.oL = c.L; a.w_phase_stride = 0; a.ooff_phase = 0;
+    a.post_a = c.post_a; a.post_ib = c.post_ib; a.y2 = c.y2;
     if (c.cout == 1) {
         hipLaunchKernelGGL(k_conv_out1, dim3((c.L + 255) / 256), dim3(256), 0, st, a);
+    } else if (hipError_t e = launch_conv_mfma(a, 1, st); e != hipErrorNotSupported) {
+        return e;
     } else {
         dim3 grid((c.L + CV_T - 1) / CV_T, (c.cout + CV_CO - 1) / CV_CO, 1);
         hipLaunchKernelGGL(k_conv1d, grid, dim3(256), 0, st, a);
@@ -150,12 +275,15 @@ hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
 // last tap ↔ x[j] (w[.][.][ph])), so phase ph is a k=taps causal conv whose outputs land at
 // t = j*stride + ph; the right-trim k - s of causal_trans_conv.rs:79 is implicit (length L*stride).
 hipError_t launch_transconv1d_taps(const float* x, const float* wp, const float* b, float* y, int cin, int cout, int L,
-                                   int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st) {
+                                   int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st,
+                                   const float* post_a, const float* post_ib, float* y2) {
     ConvDev a{};
+    a.post_a = post_a; a.post_ib = post_ib; a.y2 = y2;
     a.x = x; a.w = wp; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = taps; a.dil = 1;
     a.snake_a = snake_a; a.snake_ib = snake_ib; a.resid = nullptr; a.scale = nullptr; a.act = 0;
     a.ostride = stride; a.ooff = 0; a.oL = L * stride;
     a.w_phase_stride = (size_t)cout * cin * taps; a.ooff_phase = 1;
+    if (hipError_t e = launch_conv_mfma(a, stride, st); e != hipErrorNotSupported) return e;
     dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO, stride);
     hipLaunchKernelGGL(k_conv1d, grid, dim3(256), 0, st, a);
     return hipGetLastError();

@@ -574,14 +574,25 @@ hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* rec = a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE;
+    // all loads first (fixed unroll, predicated): one memory round trip instead of 2*n_splits dependent ones
+    float ms[MAX_SPLITS], ls[MAX_SPLITS], as[MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < MAX_SPLITS; ++s) {
+        const bool ok = s < a.n_splits;
+        const float* r = rec + (ok ? s : 0) * PART_STRIDE;
+        ms[s] = ok ? r[HEAD_DIM] : -INFINITY;
+        ls[s] = ok ? r[HEAD_DIM + 1] : 0.0f;
+        as[s] = ok ? r[d] : 0.0f;
+    }
     float M = -INFINITY;
-    for (int s = 0; s < a.n_splits; ++s) M = fmaxf(M, rec[s * PART_STRIDE + HEAD_DIM]);
+#pragma unroll
+    for (int s = 0; s < MAX_SPLITS; ++s) M = fmaxf(M, ms[s]);
     float L = 0.0f, A = 0.0f;
-    for (int s = 0; s < a.n_splits; ++s) {
-        const float ms = rec[s * PART_STRIDE + HEAD_DIM];
-        const float wgt = ms == -INFINITY ? 0.0f : expf(ms - M);
-        L += rec[s * PART_STRIDE + HEAD_DIM + 1] * wgt;
-        A += rec[s * PART_STRIDE + d] * wgt;
+#pragma unroll
+    for (int s = 0; s < MAX_SPLITS; ++s) {
+        const float wgt = ms[s] == -INFINITY ? 0.0f : expf(ms[s] - M);
+        L += ls[s] * wgt;
+        A += as[s] * wgt;
     }
     a.out[(size_t)b * a.ld_out + h * HEAD_DIM + d] = A / L;
 }
