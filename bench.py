@@ -145,8 +145,18 @@ def main():
     wbytes, kvbytes = s.frame_bytes(10 + args.frames // 2)
     s.close()
     achieved = tot_bytes / tot_us / 1e3     # GB/s
+    # HBM traffic per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes, FETCH_SIZE x2 gfx950 correction; tests/pmc_collect.sh) — PMC counters cannot be read from inside the run
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", f"r1_pmc_gemv_M{min(B, 16)}.json")
+    if args.model == "1.7b" and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))["shapes"]
+        key = lambda n: n.replace(" ", "_").replace("/", "")
+        if all(key(n) in pmc for n, *_ in inventory):
+            traffic = sum((pmc[key(n)]["fetch_bytes_corrected"] + pmc[key(n)]["write_bytes"]) * cnt for n, _, _, _, _, cnt in inventory) / launches
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": None, "kernel": "k_gemv_mfma / k_gemv_mfma4 (bf16-weight MFMA GEMV family, M = batch)",
+                "traffic": traffic, "traffic_source": os.path.basename(pmc_path) if traffic else None,
+                "kernel": "k_gemv_mfma / k_gemv_mfma4 (bf16-weight MFMA GEMV family, M = batch)",
                 "timing": "hipGraph replay of each GEMV shape over HBM-resident weight copies, HIP events on the launch stream",
                 "launches_per_frame": launches, "avg_launch_us": tot_us / launches, "avg_bytes_per_launch": tot_bytes / launches,
                 "gemv_us_per_frame": tot_us, "per_shape": per_shape,
