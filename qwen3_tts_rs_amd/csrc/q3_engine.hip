@@ -905,6 +905,7 @@ struct q3_session {
     int stream_pos = 0;    // streaming: frames already decoded
     bool profile = false; ProfAcc prof_linear;
     bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
+    bool no_chunk = getenv("Q3_NO_CHUNK") != nullptr;         // A/B aid: one position per prefill step, 16-pass code predictor
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
     std::vector<hipEvent_t> prof_pool; size_t prof_pool_next = 0;
 };
@@ -930,9 +931,11 @@ static hipError_t run_linear(q3_session* s, const LinArgs& a) {
 
 // one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
 static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf& b, float* kc, float* vc, int max_seq,
-                          const int* pos_dev, int pos_static, int n_splits) {
+                          const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1) {
     const q3_model* m = s->m;
-    const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, B = s->B;
+    // B = number of activation ROWS of this step: one per sequence, or rows_per_seq consecutive positions per
+    // sequence (chunked prefill, the code predictor's 2-token first pass)
+    const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, B = s->B * rows_per_seq;
     LinArgs a;
     a.N = QD + 2 * KD; a.K = d.H; set_w(a, w.qkv, B, a.N, a.K); a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
     a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE;
@@ -941,8 +944,8 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
     t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
-    t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits;
-    if (s->legacy_attn) {
+    t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
+    if (s->legacy_attn || rows_per_seq > 1) {     // rows of one sequence depend on each other's K/V: three launches
         HIPC(launch_qknorm_rope_kv(t, s->stream));
         HIPC(launch_attn_decode(t, s->stream));
         HIPC(launch_attn_merge(t, s->stream));
@@ -968,14 +971,16 @@ static LmDims cp_dims(const q3_config& c) { return LmDims{c.cp_hidden, c.cp_inte
 
 // talker layers on the contents of tb.X at position pos (device array or static); with_head: final
 // norm → LASTH and codec_head → LOGITS (talker.rs:716-736)
-static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, bool with_head) {
+static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, bool with_head, int rows_per_seq = 1) {
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     const LmDims d = talker_dims(c);
     for (int i = 0; i < c.n_layers; ++i)
         Q3C(lm_layer(s, d, m->tl[i], s->tb, s->kcache + (size_t)i * s->kv_layer_stride, s->vcache + (size_t)i * s->kv_layer_stride,
-                     s->max_seq, pos_dev, pos_static, s->n_splits));
+                     s->max_seq, pos_dev, pos_static, s->n_splits, rows_per_seq));
     if (with_head) {
-        HIPC(launch_rmsnorm(s->tb.X, c.hidden, m->norm, s->LASTH, c.hidden, s->B, c.hidden, c.rms_eps, s->stream));
+        // final norm of each sequence's LAST row of the step
+        HIPC(launch_rmsnorm(s->tb.X + (size_t)(rows_per_seq - 1) * c.hidden, rows_per_seq * c.hidden, m->norm, s->LASTH, c.hidden, s->B,
+                            c.hidden, c.rms_eps, s->stream));
         LinArgs h;
         h.N = c.codec_vocab; h.K = c.hidden; set_w(h, m->codec_head, s->B, h.N, h.K); h.x = s->LASTH; h.ldx = c.hidden; h.y = s->LOGITS; h.ldy = c.codec_vocab;
         h.M = s->B; h.epi = EPI_NONE;
@@ -994,25 +999,40 @@ static q3_status cp_run(q3_session* s) {
     const LmDims d = cp_dims(c);
     const int H = c.hidden, CH = c.cp_hidden, V = c.cp_vocab, B = s->B;
     const int n_pass = c.n_groups;   // 16
-    for (int p = 0; p < n_pass; ++p) {
+    // First pass as the reference does it (code_predictor.rs:337-367): the talker hidden state and the semantic
+    // embedding go through the layers TOGETHER as a 2-token causal prefill (rows 2b, 2b+1), when 2B rows fit.
+    const bool two = !s->no_chunk && 2 * B <= 16;
+    for (int p = two ? 1 : 0; p < n_pass; ++p) {
+        const int rows = (two && p == 1) ? 2 : 1;
         CpGatherArgs g{};
         g.pass = p; g.last_hidden = s->LASTH; g.H = H; g.codec_emb = m->codec_emb; g.tok = s->tok;
         g.cp_emb = p >= 2 ? m->cp_emb[p - 2] : nullptr;
         g.cp_logits = p >= 2 ? s->CP_LOGITS + (size_t)(p - 2) * B * V : nullptr;
         g.cp_vocab = V; g.codes = s->codes; g.frame_idx = s->frame_idx; g.max_frames = s->max_frames; g.B = B;
-        if (m->mtp_w.t1) { g.out = s->CP_IN; g.ld_out = H; } else { g.out = s->cb.X; g.ld_out = CH; }
-        HIPC(launch_cp_gather(g, s->stream));
+        float* dst = m->mtp_w.t1 ? s->CP_IN : s->cb.X; const int ld = m->mtp_w.t1 ? H : CH;
+        if (rows == 2) {
+            // row 2b = talker hidden (pass-0 source), row 2b+1 = semantic embedding (pass-1 source)
+            g.pass = 0; g.out = dst; g.ld_out = 2 * ld;
+            HIPC(launch_cp_gather(g, s->stream));
+            g.pass = 1; g.out = dst + ld;
+            HIPC(launch_cp_gather(g, s->stream));
+        } else {
+            g.out = dst; g.ld_out = ld;
+            HIPC(launch_cp_gather(g, s->stream));
+        }
         if (m->mtp_w.t1) {
             LinArgs a;
-            a.N = CH; a.K = H; set_w(a, m->mtp_w, B, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
+            a.N = CH; a.K = H; set_w(a, m->mtp_w, B * rows, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH;
+            a.M = B * rows; a.epi = EPI_NONE;
             HIPC(run_linear(s, a));
         }
         for (int i = 0; i < c.cp_layers; ++i)
             Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,
-                         n_pass + 1, nullptr, p, 1));
+                         n_pass + 1, nullptr, rows == 2 ? 0 : p, 1, rows));
         if (p >= 1) {
             LinArgs h;
-            h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
+            h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X + (size_t)(rows - 1) * CH; h.ldx = rows * CH;
+            h.norm_w = m->cp_norm; h.eps = c.rms_eps;
             h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
             HIPC(run_linear(s, h));
         }
@@ -1112,20 +1132,21 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     const int B = batch, H = c.hidden, CH = c.cp_hidden;
     auto alloc_lm = [&](LmBuf& b, const LmDims& d, int nsplit) -> hipError_t {
         const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM;
+        const size_t R = 16;     // rows: up to 16 (multi-row steps), >= B
         hipError_t e;
-        if ((e = s->pool.alloc(&b.X, (size_t)B * d.H)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.SUM, (size_t)B * d.H)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.QKV, (size_t)B * (QD + 2 * KD))) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.Q, (size_t)B * QD)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.ATT, (size_t)B * QD)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.ACT, (size_t)B * d.I)) != hipSuccess) return e;
-        return s->pool.alloc(&b.PART, (size_t)B * d.nh * nsplit * PART_STRIDE);
+        if ((e = s->pool.alloc(&b.X, R * d.H)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.SUM, R * d.H)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.QKV, R * (QD + 2 * KD))) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.Q, R * QD)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.ATT, R * QD)) != hipSuccess) return e;
+        if ((e = s->pool.alloc(&b.ACT, R * d.I)) != hipSuccess) return e;
+        return s->pool.alloc(&b.PART, R * d.nh * nsplit * PART_STRIDE);
     };
     HIPC(alloc_lm(s->tb, talker_dims(c), s->n_splits));
     HIPC(alloc_lm(s->cb, cp_dims(c), 1));
     HIPC(s->pool.alloc(&s->LASTH, (size_t)B * H));
     HIPC(s->pool.alloc(&s->LOGITS, (size_t)B * c.codec_vocab));
-    HIPC(s->pool.alloc(&s->CP_IN, (size_t)B * H));
+    HIPC(s->pool.alloc(&s->CP_IN, (size_t)16 * H));
     HIPC(s->pool.alloc(&s->CP_LOGITS, (size_t)15 * B * c.cp_vocab));
     s->kv_layer_stride = (size_t)B * c.n_kv_heads * s->max_seq * HEAD_DIM;
     HIPC(s->pool.alloc(&s->kcache, s->kv_layer_stride * c.n_layers));
@@ -1283,9 +1304,15 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     hipFree(ids_dev); hipFree(tr_dev); hipFree(ci_dev);
     Q3C(st);
     // 2. run_prefill_layers (talker.rs:823-841): causal attention ⇒ token-by-token decode steps
-    for (int t = 0; t < S; ++t) {
-        HIPC(launch_copy_rows(s->embeds + (size_t)t * H, S * H, s->tb.X, H, B, H, s->stream));
-        Q3C(talker_step(s, nullptr, t, t == S - 1));
+    //    and the GEMV kernels take up to 16 rows for the price of one, so each weight pass carries a CHUNK of
+    //    16/B consecutive positions per sequence (q3_kernels.h AttnArgs::rows_per_seq). Bit-identical to the
+    //    one-position-at-a-time schedule (rows are independent in the GEMV; attention sees the same K/V).
+    const int chunk = s->no_chunk ? 1 : (16 / B > 0 ? 16 / B : 1);
+    for (int t0 = 0; t0 < S; t0 += chunk) {
+        const int ch = (S - t0) < chunk ? (S - t0) : chunk;
+        for (int b = 0; b < B; ++b)
+            HIPC(launch_copy_rows(s->embeds + ((size_t)b * S + t0) * H, H, s->tb.X + (size_t)b * ch * H, H, ch, H, s->stream));
+        Q3C(talker_step(s, nullptr, t0, t0 + ch >= S, ch));
     }
     // 3. first sampling decision (lib.rs:558-571)
     std::vector<int> posv(B, S), zero(B, 0);

@@ -53,6 +53,9 @@ struct AttnArgs {
     float* part;                            // [B][nh][n_splits][PART_STRIDE]
     float* out; int ld_out;                 // [B][nh*128]
     int B, nh, nkv, n_splits;
+    // multi-row steps (chunked prefill, 2-token code-predictor pass): B counts ROWS; row r belongs to sequence
+    // r / rows_per_seq and sits at position base_pos(sequence) + r % rows_per_seq. 0/1 = one row per sequence.
+    int rows_per_seq;
 };
 hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);

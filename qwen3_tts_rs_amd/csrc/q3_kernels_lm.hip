@@ -340,7 +340,9 @@ hipError_t launch_fused_residual_rmsnorm_bf16(const uint16_t* x, const uint16_t*
 __global__ __launch_bounds__(64) void k_qknorm_rope_kv(AttnArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
-    const int pos = a.pos_dev ? a.pos_dev[b] : a.pos_static;
+    const int rps = a.rows_per_seq > 1 ? a.rows_per_seq : 1;
+    const int seq = b / rps;
+    const int pos = (a.pos_dev ? a.pos_dev[seq] : a.pos_static) + (b - seq * rps);
     const bool is_q = h < a.nh;
     const float* src = a.qkv + (size_t)b * a.ld_qkv + (is_q ? h * HEAD_DIM : QD + (h - a.nh) * HEAD_DIM);
     float x1 = src[lane], x2 = src[lane + 64];
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(64) void k_qknorm_rope_kv(AttnArgs a) {
         q[lane] = o1; q[lane + 64] = o2;
     } else {
         const int kvh = h - a.nh;
-        const size_t slot = (((size_t)b * a.nkv + kvh) * a.max_seq + pos) * HEAD_DIM;
+        const size_t slot = (((size_t)seq * a.nkv + kvh) * a.max_seq + pos) * HEAD_DIM;
         a.kcache[slot + lane] = o1; a.kcache[slot + lane + 64] = o2;
         const float* vs = a.qkv + (size_t)b * a.ld_qkv + QD + KD + kvh * HEAD_DIM;
         a.vcache[slot + lane] = vs[lane]; a.vcache[slot + lane + 64] = vs[lane + 64];
@@ -381,7 +383,9 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float sm_acc[NREP][8][HEAD_DIM];
     const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, grp = tid >> 5, li = tid & 31;
-    const int pos = a.pos_dev ? a.pos_dev[b] : a.pos_static;
+    const int rps = a.rows_per_seq > 1 ? a.rows_per_seq : 1;
+    const int seq = b / rps;
+    const int pos = (a.pos_dev ? a.pos_dev[seq] : a.pos_static) + (b - seq * rps);
     const int len = pos + 1;
     const int chunk = (len + a.n_splits - 1) / a.n_splits;
     const int start = split * chunk;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
 
-    const size_t base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM + li * 4;
+    const size_t base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM + li * 4;
     for (int p = start + grp; p < end; p += 8) {
         const float4 kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
         const float4 vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
