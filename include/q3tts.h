@@ -104,6 +104,14 @@ typedef struct q3_request {
     uint32_t language_id;         /* Language::token_id (talker.rs:94-107) */
     const float* xvector;         /* [hidden] speaker embedding (voice clone) or NULL */
     q3_options opts;
+    /* ICL voice clone (VoiceClonePrompt.ref_codes / ref_text_ids, lib.rs:127-134, 897-1046): reference codec
+     * frames [n_ref][16] (from the caller's speech encoder) and the reference transcript's token ids. With
+     * both present (mode = voice clone) the talker prefill is extended by the ICL block of
+     * build_icl_prompt (talker.rs:646-710, streaming overlay), repetition_penalty is floored at 1.5 and
+     * max_length capped at max(75, 6·n_text) (lib.rs:913-929), and the full-utterance decode prepends the
+     * reference frames and cuts them off again (lib.rs:1022-1041). */
+    const uint32_t* ref_codes;    int32_t n_ref;
+    const uint32_t* ref_text_ids; int32_t n_ref_text;
 } q3_request;
 
 /* SynthesisTiming (lib.rs:138-147) */

@@ -599,7 +599,7 @@ static void text_project(const q3o_model* m, const uint32_t* ids, int n, float* 
 struct q3o_session {
     q3o_model* m;
     q3o_request req;
-    uint32_t* text_ids; uint32_t* instruct_ids; float* xvector;
+    uint32_t* text_ids; uint32_t* instruct_ids; float* xvector; uint32_t* ref_codes; uint32_t* ref_text_ids;
     kvc_t* kv;           /* talker caches */
     kvc_t* cpkv;         /* code predictor caches */
     int prefill_len, offset;
@@ -632,7 +632,18 @@ q3o_session* q3o_session_new(q3o_model* m, const q3o_request* req) {
     if (req->n_text > 0) { s->text_ids = (uint32_t*)malloc((size_t)req->n_text * 4); memcpy(s->text_ids, req->text_ids, (size_t)req->n_text * 4); }
     if (req->n_instruct > 0) { s->instruct_ids = (uint32_t*)malloc((size_t)req->n_instruct * 4); memcpy(s->instruct_ids, req->instruct_ids, (size_t)req->n_instruct * 4); }
     if (req->xvector) { s->xvector = fmalloc((size_t)H); memcpy(s->xvector, req->xvector, (size_t)H * sizeof(float)); }
+    const int icl = req->mode == Q3O_MODE_VOICE_CLONE && req->n_ref > 0 && req->ref_codes && req->ref_text_ids;
+    if (icl) {
+        s->ref_codes = (uint32_t*)malloc((size_t)req->n_ref * 16 * 4); memcpy(s->ref_codes, req->ref_codes, (size_t)req->n_ref * 16 * 4);
+        s->ref_text_ids = (uint32_t*)malloc((size_t)(req->n_ref_text > 0 ? req->n_ref_text : 1) * 4);
+        if (req->n_ref_text > 0) memcpy(s->ref_text_ids, req->ref_text_ids, (size_t)req->n_ref_text * 4);
+        /* lib.rs:913-929: ICL floors the repetition penalty at 1.5 and caps max_new_tokens */
+        if (s->req.opts.repetition_penalty < 1.5) s->req.opts.repetition_penalty = 1.5;
+        int cap = 6 * req->n_text; if (cap < 75) cap = 75;
+        if (s->req.opts.max_length > cap) s->req.opts.max_length = cap;
+    }
     s->req.text_ids = s->text_ids; s->req.instruct_ids = s->instruct_ids; s->req.xvector = s->xvector;
+    s->req.ref_codes = s->ref_codes; s->req.ref_text_ids = s->ref_text_ids;
     s->kv = (kvc_t*)calloc((size_t)c->n_layers, sizeof(kvc_t));
     for (int i = 0; i < c->n_layers; ++i) kvc_init(&s->kv[i], c->n_kv_heads, c->head_dim, 64);
     s->cpkv = (kvc_t*)calloc((size_t)c->cp_layers, sizeof(kvc_t));
@@ -658,8 +669,9 @@ q3o_session* q3o_session_new(q3o_model* m, const q3o_request* req) {
     int mode = req->mode;
     int n_ins = mode == Q3O_MODE_VOICE_DESIGN ? req->n_instruct : 0;
     int n_codec_overlay = mode == Q3O_MODE_VOICE_DESIGN ? 5 : 6;
-    int has_first = req->n_text > 0;
-    int S = n_ins + 3 + n_codec_overlay + (has_first ? 1 : 0);
+    int has_first = req->n_text > 0 && !icl;            /* icl_mode omits first_text + codec_bos (talker.rs:555-561) */
+    int n_icl = icl ? req->n_ref + 1 : 0;                /* streaming overlay: icl_len = n_codec (talker.rs:690-709) */
+    int S = n_ins + 3 + n_codec_overlay + (has_first ? 1 : 0) + n_icl;
     float* emb = fmalloc((size_t)S * H);
     float* row = emb;
     if (n_ins > 0) { text_project(m, s->instruct_ids, n_ins, row); row += (size_t)n_ins * H; }
@@ -686,6 +698,46 @@ q3o_session* q3o_session_new(q3o_model* m, const q3o_request* req) {
         add_rows(row, ft, m->codec_emb + (size_t)codec_ids[n_codec - 1] * H, H);
         free(ft);
     }
+    if (icl) {
+        /* build_icl_prompt, streaming mode (talker.rs:646-709): text = proj([ref_text, target_text, tts_eos]);
+         * codec = [codec_emb[BOS]; Σ16 ref embeddings per frame (lib.rs:1239-1257)]; overlay element-wise */
+        if (has_first) row += H;
+        else if (req->n_text > 0) { /* nothing: position 9 skipped */ }
+        int n_text_all = req->n_ref_text + req->n_text + 1;
+        uint32_t* ids = (uint32_t*)malloc((size_t)n_text_all * 4);
+        memcpy(ids, s->ref_text_ids, (size_t)req->n_ref_text * 4);
+        memcpy(ids + req->n_ref_text, s->text_ids, (size_t)req->n_text * 4);
+        ids[n_text_all - 1] = TTS_EOS;
+        float* tproj = fmalloc((size_t)n_text_all * H);
+        text_project(m, ids, n_text_all, tproj);
+        float* cod = fmalloc((size_t)H);
+        float* icl_row = emb + (size_t)(S - n_icl) * H;
+        for (int i = 0; i < n_icl; ++i) {
+            if (i == 0) memcpy(cod, m->codec_emb + (size_t)CODEC_BOS * H, (size_t)H * sizeof(float));
+            else {
+                const uint32_t* fr = s->ref_codes + (size_t)(i - 1) * 16;
+                memcpy(cod, m->codec_emb + (size_t)fr[0] * H, (size_t)H * sizeof(float));
+                for (int g = 1; g < 16; ++g) {
+                    const float* e = m->cp_emb[g - 1] + (size_t)fr[g] * H;
+                    for (int k = 0; k < H; ++k) cod[k] = cod[k] + e[k];
+                }
+            }
+            const float* txt = i < n_text_all ? tproj + (size_t)i * H : pad_proj;
+            add_rows(icl_row + (size_t)i * H, txt, cod, H);
+        }
+        /* trailing text: remaining text rows, or tts_pad (talker.rs:692-708) */
+        free(s->trailing);
+        if (n_text_all > n_icl) {
+            s->trailing_len = n_text_all - n_icl;
+            s->trailing = fmalloc((size_t)s->trailing_len * H);
+            memcpy(s->trailing, tproj + (size_t)n_icl * H, (size_t)s->trailing_len * H * sizeof(float));
+        } else {
+            s->trailing_len = 1;
+            s->trailing = fmalloc((size_t)H);
+            memcpy(s->trailing, pad_proj, (size_t)H * sizeof(float));
+        }
+        free(ids); free(tproj); free(cod);
+    }
     free(pad_proj); free(bos_proj);
     s->prefill_len = S;
     s->prefill_embeds = fmalloc((size_t)S * H);
@@ -701,11 +753,12 @@ void q3o_session_free(q3o_session* s) {
     const q3o_config* c = &s->m->cfg;
     for (int i = 0; i < c->n_layers; ++i) kvc_free(&s->kv[i]);
     for (int i = 0; i < c->cp_layers; ++i) kvc_free(&s->cpkv[i]);
-    free(s->kv); free(s->cpkv); free(s->text_ids); free(s->instruct_ids); free(s->xvector);
+    free(s->kv); free(s->cpkv); free(s->text_ids); free(s->instruct_ids); free(s->xvector); free(s->ref_codes); free(s->ref_text_ids);
     free(s->prefill_embeds); free(s->last_hidden); free(s->logits); free(s->trailing); free(s->pad_embed);
     free(s);
 }
 int q3o_session_prefill_len(const q3o_session* s) { return s->prefill_len; }
+void q3o_session_effective(const q3o_session* s, double* rp, int* ml) { if (rp) *rp = s->req.opts.repetition_penalty; if (ml) *ml = s->req.opts.max_length; }
 void q3o_session_prefill_out(const q3o_session* s, float* last_hidden, float* logits) {
     memcpy(last_hidden, s->last_hidden, (size_t)s->m->cfg.hidden * sizeof(float));
     memcpy(logits, s->logits, (size_t)s->m->cfg.codec_vocab * sizeof(float));

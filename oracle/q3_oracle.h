@@ -86,8 +86,11 @@ typedef struct q3o_request {
     const uint32_t* instruct_ids; int32_t n_instruct;   /* voice design */
     uint32_t speaker_id;          /* codec id of the speaker token (custom voice) */
     uint32_t language_id;         /* codec id of the language token */
-    const float* xvector;         /* [hidden] speaker embedding (voice clone, x-vector-only) */
+    const float* xvector;         /* [hidden] speaker embedding (voice clone) */
     q3o_options opts;
+    /* ICL voice clone (lib.rs:897-1046): reference codec frames [n_ref][16] + reference text ids */
+    const uint32_t* ref_codes;    int32_t n_ref;
+    const uint32_t* ref_text_ids; int32_t n_ref_text;
 } q3o_request;
 
 typedef struct q3o_model q3o_model;
@@ -124,6 +127,8 @@ void q3o_codes_to_tensor(const uint32_t* frames, int n_frames, int64_t* out /*[1
 q3o_session* q3o_session_new(q3o_model* m, const q3o_request* req);
 void q3o_session_free(q3o_session* s);
 int q3o_session_prefill_len(const q3o_session* s);
+/* options actually used by generate (ICL adjusts repetition_penalty / max_length, lib.rs:913-929) */
+void q3o_session_effective(const q3o_session* s, double* repetition_penalty, int* max_length);
 /* state right after prefill: normed last hidden [hidden], logits [codec_vocab] */
 void q3o_session_prefill_out(const q3o_session* s, float* last_hidden, float* logits);
 /* prefill input embeddings [prefill_len][hidden] (for stage tests) */

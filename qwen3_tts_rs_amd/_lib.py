@@ -33,6 +33,8 @@ class CRequest(ctypes.Structure):
         ("speaker_id", ctypes.c_uint32), ("language_id", ctypes.c_uint32),
         ("xvector", ctypes.POINTER(ctypes.c_float)),
         ("opts", COptions),
+        ("ref_codes", ctypes.POINTER(ctypes.c_uint32)), ("n_ref", ctypes.c_int32),
+        ("ref_text_ids", ctypes.POINTER(ctypes.c_uint32)), ("n_ref_text", ctypes.c_int32),
     ]
 
 

@@ -135,7 +135,9 @@ class Utterance:
     speaker: Speaker = Speaker.Ryan
     language: Language = Language.English
     instruct_ids: Optional[Sequence[int]] = None     # voice design
-    xvector: Optional[np.ndarray] = None             # voice clone (x-vector only)
+    xvector: Optional[np.ndarray] = None             # voice clone: speaker embedding (x-vector)
+    ref_codes: Optional[np.ndarray] = None           # ICL voice clone: reference codec frames [n_ref][16]
+    ref_text_ids: Optional[Sequence[int]] = None     # ICL voice clone: reference transcript token ids
     seed: Optional[int] = None                       # overrides options.seed for this sequence
 
     def mode(self) -> int:
@@ -154,6 +156,7 @@ class Session:
         self.B = len(utts)
         self.options = options
         self._keep = []
+        self._ref_frames = [0 if u.ref_codes is None else int(np.asarray(u.ref_codes).reshape(-1, 16).shape[0]) for u in utts]
         reqs = (CRequest * self.B)()
         for i, u in enumerate(utts):
             r = reqs[i]
@@ -167,6 +170,11 @@ class Session:
             if u.xvector is not None:
                 xv = np.ascontiguousarray(u.xvector, dtype=np.float32); self._keep.append(xv)
                 r.xvector = xv.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            if u.ref_codes is not None and u.ref_text_ids is not None:
+                rc = np.ascontiguousarray(u.ref_codes, dtype=np.uint32).reshape(-1, 16); self._keep.append(rc)
+                rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); self._keep.append(rt)
+                r.ref_codes = rc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref = rc.shape[0]
+                r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
             o = options.to_c()
             if u.seed is not None:
                 o.seed = int(u.seed); o.has_seed = 1
@@ -205,7 +213,8 @@ class Session:
         n, _ = self.frames(b)
         f1 = n if f1 is None else f1
         spf = self.model.config.samples_per_frame
-        out = np.zeros(max((f1 - f0) * spf, 1), dtype=np.float32)
+        extra = 0 if self._ref_frames is None else self._ref_frames[b]
+        out = np.zeros(max((f1 - f0 + extra) * spf, 1), dtype=np.float32)
         got = ctypes.c_size_t()
         check(lib.q3_session_decode(self._h, b, f0, f1, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(got)))
         return out[:got.value]
@@ -388,6 +397,16 @@ class Qwen3TTS:
         finally:
             s.close()
         return audio[0]
+
+    def synthesize_voice_clone(self, text_ids, xvector, language: Language, options=None, ref_codes=None, ref_text_ids=None):
+        """synthesize_voice_clone_debug (lib.rs:897-1046): x-vector-only, or ICL when ref_codes + ref_text_ids are given.
+        Returns (AudioBuffer, codes)."""
+        s = self.session([Utterance(text_ids, language=language, xvector=xvector, ref_codes=ref_codes, ref_text_ids=ref_text_ids)], options)
+        try:
+            s.prefill(); s.generate(s.options.max_length)
+            return AudioBuffer(s.decode(0)), s.codes(0)
+        finally:
+            s.close()
 
     def synthesize_batch(self, utts: Sequence[Utterance], options=None):
         s = self.session(utts, options)

@@ -875,7 +875,7 @@ struct LmBuf { float *X, *SUM, *QKV, *Q, *ATT, *ACT, *PART; };
 struct LmDims { int H, I, nh, nkv, layers; float eps; };
 
 struct SeqInfo {
-    q3_request req; std::vector<uint32_t> text, instruct; std::vector<float> xvec;
+    q3_request req; std::vector<uint32_t> text, instruct, ref_codes, ref_text; std::vector<float> xvec; bool icl = false;
     int prefill_len = 0, trailing_len = 0, row_base = 0, n_rows = 0, trail_base = 0, pad_row = 0;
     int n_frames = 0; bool done = false;
 };
@@ -894,6 +894,7 @@ struct q3_session {
     float *kcache = nullptr, *vcache = nullptr, *ckcache = nullptr, *cvcache = nullptr;
     size_t kv_layer_stride = 0, ckv_layer_stride = 0;
     float *rows = nullptr, *embeds = nullptr, *xvec = nullptr; int n_rows_total = 0;
+    uint32_t* ref_codes_dev = nullptr;
     int *trail_base = nullptr, *trail_len = nullptr, *pad_row = nullptr;
     uint32_t* tok = nullptr; uint8_t* seen = nullptr; int *frame_idx = nullptr, *pos = nullptr, *token_count = nullptr;
     float* U = nullptr; uint32_t* codes = nullptr;
@@ -1097,7 +1098,8 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     int rows = 0;
     for (int b = 0; b < batch; ++b) {
         const q3_request& r = reqs[b];
-        if (!opts_equal_sampling(r.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "all requests of a batch must share sampling options (seed may differ)");
+        const bool icl_req = r.mode == Q3_MODE_VOICE_CLONE && r.n_ref > 0 && r.ref_codes && r.ref_text_ids;
+        if (!icl_req && !opts_equal_sampling(r.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "all requests of a batch must share sampling options (seed may differ)");
         if (r.mode < 0 || r.mode > 2) return set_err(Q3_INVALID_ARG, "bad mode %d", r.mode);
         if (r.n_text < 0 || r.n_instruct < 0 || (r.n_text > 0 && !r.text_ids) || (r.n_instruct > 0 && !r.instruct_ids))
             return set_err(Q3_INVALID_ARG, "bad token id arrays");
@@ -1111,12 +1113,31 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
         if (r.language_id >= (uint32_t)c.codec_vocab || (r.mode == Q3_MODE_CUSTOM_VOICE && r.speaker_id >= (uint32_t)c.codec_vocab))
             return set_err(Q3_INVALID_ARG, "speaker/language id out of range");
         if (r.xvector) q.xvec.assign(r.xvector, r.xvector + c.hidden);
+        q.icl = r.mode == Q3_MODE_VOICE_CLONE && r.n_ref > 0 && r.ref_codes && r.ref_text_ids;
+        if (q.icl) {
+            if (r.n_ref_text < 0) return set_err(Q3_INVALID_ARG, "bad reference text");
+            q.ref_codes.assign(r.ref_codes, r.ref_codes + (size_t)r.n_ref * 16);
+            q.ref_text.assign(r.ref_text_ids, r.ref_text_ids + r.n_ref_text);
+            for (int f = 0; f < r.n_ref; ++f) {
+                if (q.ref_codes[(size_t)f * 16] >= (uint32_t)c.codec_vocab) return set_err(Q3_INVALID_ARG, "reference semantic code out of range");
+                for (int g = 1; g < 16; ++g) if (q.ref_codes[(size_t)f * 16 + g] >= (uint32_t)c.cp_vocab) return set_err(Q3_INVALID_ARG, "reference acoustic code out of range");
+            }
+            for (uint32_t id : q.ref_text) if (id >= (uint32_t)c.text_vocab) return set_err(Q3_INVALID_ARG, "reference text id %u out of range", id);
+            // lib.rs:913-929 (must be identical for every sequence of the batch, checked below through s->opts)
+            q.req.opts.repetition_penalty = r.opts.repetition_penalty < 1.5 ? 1.5 : r.opts.repetition_penalty;
+            int cap = 6 * r.n_text; if (cap < 75) cap = 75;
+            if (q.req.opts.max_length > cap) q.req.opts.max_length = cap;
+            if (b == 0) s->opts = q.req.opts;
+            else if (!opts_equal_sampling(q.req.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "ICL sequences of a batch must resolve to the same max_length / repetition_penalty");
+        }
         const int n_ins = (int)q.instruct.size();
         const int overlay = r.mode == Q3_MODE_VOICE_DESIGN ? 5 : 6;
-        q.prefill_len = n_ins + 3 + overlay + (r.n_text > 0 ? 1 : 0);
-        q.trailing_len = (r.n_text > 1 ? r.n_text - 1 : 0) + 1;
+        const int n_icl = q.icl ? r.n_ref + 1 : 0;                              // streaming overlay: icl_len = n_codec
+        const int n_text_all = q.icl ? r.n_ref_text + r.n_text + 1 : 0;         // [ref_text, text, tts_eos]
+        q.prefill_len = n_ins + 3 + overlay + ((r.n_text > 0 && !q.icl) ? 1 : 0) + n_icl;
+        q.trailing_len = q.icl ? (n_text_all > n_icl ? n_text_all - n_icl : 1) : (r.n_text > 1 ? r.n_text - 1 : 0) + 1;
         q.row_base = rows;
-        q.n_rows = n_ins + 5 + r.n_text + 1;     // instruct, role×3, pad, bos, text…, eos
+        q.n_rows = n_ins + 5 + (q.icl ? r.n_ref_text : 0) + r.n_text + 1;     // instruct, role×3, pad, bos, [ref_text…], text…, eos
         rows += q.n_rows;
         if (q.prefill_len != s->seq[0].prefill_len)
             return set_err(Q3_UNSUPPORTED, "all sequences of a batch must have the same prefill length (%d vs %d)", q.prefill_len, s->seq[0].prefill_len);
@@ -1258,11 +1279,15 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
         const int n_ins = (int)q.instruct.size(), n_text = (int)q.text.size(), base = q.row_base;
         for (uint32_t id : q.instruct) ids.push_back(id);
         ids.push_back(IM_START); ids.push_back(ASSISTANT); ids.push_back(NEWLINE); ids.push_back(TTS_PAD); ids.push_back(TTS_BOS);
+        if (q.icl) for (uint32_t id : q.ref_text) ids.push_back(id);       // ICL: [ref_text, target_text, tts_eos] (talker.rs:656-663)
         for (uint32_t id : q.text) ids.push_back(id);
         ids.push_back(TTS_EOS);
-        const int r_role = base + n_ins, r_pad = r_role + 3, r_bos = r_pad + 1, r_text = r_bos + 1, r_eos = r_text + n_text;
+        const int n_ref_text = q.icl ? (int)q.ref_text.size() : 0;
+        const int r_role = base + n_ins, r_pad = r_role + 3, r_bos = r_pad + 1, r_text = r_bos + 1, r_eos = r_text + n_ref_text + n_text;
+        const int n_icl = q.icl ? (int)(q.ref_codes.size() / 16) + 1 : 0, n_text_all = n_ref_text + n_text + 1;
         q.pad_row = r_pad;
-        q.trail_base = n_text > 1 ? r_text + 1 : r_eos;          // build_trailing_text (lib.rs:508-519)
+        if (q.icl) q.trail_base = n_text_all > n_icl ? r_text + n_icl : r_pad;       // talker.rs:692-708
+        else q.trail_base = n_text > 1 ? r_text + 1 : r_eos;          // build_trailing_text (lib.rs:508-519)
         trail_base[b] = q.trail_base; trail_len[b] = q.trailing_len; pad_row[b] = q.pad_row;
         // prefill positions (talker.rs:451-491 / 511-564 / 585-627)
         int* tr = &text_row[(size_t)b * S]; int* ci = &codec_id[(size_t)b * S];
@@ -1279,10 +1304,24 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
             ci[p] = (q.req.mode == Q3_MODE_VOICE_CLONE && i == 4) ? -2 : codec[i];
             ++p;
         }
-        if (n_text > 0) { tr[p] = r_text; ci[p] = codec[nc - 1]; ++p; }
+        if (n_text > 0 && !q.icl) { tr[p] = r_text; ci[p] = codec[nc - 1]; ++p; }
+        for (int i = 0; i < n_icl; ++i) {      // ICL block: text (or tts_pad) row + codec_bos / Σ16 reference-frame embeddings
+            tr[p] = i < n_text_all ? r_text + i : r_pad;
+            ci[p] = i == 0 ? CODEC_BOS : -3 - (i - 1);
+            ++p;
+        }
         if (!q.xvec.empty()) memcpy(&xv[(size_t)b * H], q.xvec.data(), (size_t)H * 4);
     }
     uint32_t* ids_dev = nullptr; int *tr_dev = nullptr, *ci_dev = nullptr;
+    // reference frames of ICL sequences (also needed later by the ICL decode)
+    std::vector<size_t> ref_off(B, 0); size_t ref_total = 0;
+    for (int b = 0; b < B; ++b) { ref_off[b] = ref_total; ref_total += s->seq[b].ref_codes.size(); }
+    if (ref_total && !s->ref_codes_dev) {
+        HIPC(s->pool.alloc(&s->ref_codes_dev, ref_total));
+        for (int b = 0; b < B; ++b)
+            if (!s->seq[b].ref_codes.empty())
+                HIPC(hipMemcpy(s->ref_codes_dev + ref_off[b], s->seq[b].ref_codes.data(), s->seq[b].ref_codes.size() * 4, hipMemcpyHostToDevice));
+    }
     HIPC(hipMalloc((void**)&ids_dev, ids.size() * 4));
     HIPC(hipMalloc((void**)&tr_dev, text_row.size() * 4)); HIPC(hipMalloc((void**)&ci_dev, codec_id.size() * 4));
     HIPC(hipMemcpy(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
@@ -1297,7 +1336,8 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
         hipError_t e = hipSuccess;
         for (int b = 0; b < B && e == hipSuccess; ++b)
             e = launch_assemble_rows(s->rows, tr_dev + (size_t)b * S, m->codec_emb, ci_dev + (size_t)b * S, s->xvec + (size_t)b * H,
-                                     s->embeds + (size_t)b * S * H, S, H, s->stream);
+                                     s->embeds + (size_t)b * S * H, S, H, s->stream,
+                                     s->ref_codes_dev ? s->ref_codes_dev + ref_off[b] : nullptr, m->cp_embs_dev);
         if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
         if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "prefill assembly: %s", hipGetErrorString(e));
     }
@@ -1423,6 +1463,25 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
     Q3C(refresh_codes(s));
     if (f0 < 0 || f1 < f0 || f1 > s->seq[b].n_frames) return set_err(Q3_INVALID_ARG, "bad frame range [%d,%d) of %d", f0, f1, s->seq[b].n_frames);
     const int T = f1 - f0, spf = samples_per_frame(s->m->cfg);
+    const SeqInfo& q = s->seq[b];
+    if (q.icl && f0 == 0 && f1 == q.n_frames) {
+        // ICL full-utterance decode (lib.rs:1022-1041): decode [ref_frames ; generated], then cut the first
+        // ref_len * samples / total_frames samples
+        const int n_ref = (int)(q.ref_codes.size() / 16), total = n_ref + T;
+        const size_t all = (size_t)total * spf, cut = (size_t)n_ref * all / (size_t)(total > 0 ? total : 1);
+        if (n_samples) *n_samples = all - cut;
+        Q3C(codec_reserve(s->m, s->cws, total));
+        size_t roff = 0; for (int i = 0; i < b; ++i) roff += s->seq[i].ref_codes.size();
+        HIPC(hipMemcpyAsync(s->cws.frames, s->ref_codes_dev + roff, (size_t)n_ref * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
+        if (T > 0) HIPC(hipMemcpyAsync(s->cws.frames + (size_t)n_ref * 16, s->codes + (size_t)b * s->max_frames * 16, (size_t)T * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
+        Q3C(codec_decode_dev(s->m, s->cws, total, s->stream, nullptr));
+        HIPC(hipStreamSynchronize(s->stream));
+        if (pcm_host) {
+            if (cap < all - cut) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+            HIPC(hipMemcpy(pcm_host, s->cws.pcm + cut, (all - cut) * 4, hipMemcpyDeviceToHost));
+        }
+        return Q3_OK;
+    }
     if (n_samples) *n_samples = (size_t)T * spf;
     if (T == 0) return Q3_OK;
     Q3C(codec_reserve(s->m, s->cws, T));

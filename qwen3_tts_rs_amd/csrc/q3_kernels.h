@@ -70,7 +70,8 @@ hipError_t launch_gather_rows_bf16(const uint16_t* table, const uint32_t* ids, f
 // prefill assembly: out[i] = (text_row[i] >= 0 ? rows[text_row[i]] : 0) + (codec_id[i] >= 0 ? codec_emb[codec_id[i]]
 //                   : codec_id[i] == -2 ? xvec : 0)
 hipError_t launch_assemble_rows(const float* rows, const int* text_row, const uint16_t* codec_emb, const int* codec_id,
-                                const float* xvec, float* out, int n, int H, hipStream_t st);
+                                const float* xvec, float* out, int n, int H, hipStream_t st,
+                                const uint32_t* ref_codes = nullptr, const uint16_t* const* cp_embs = nullptr);   // codec_id <= -3: ICL ref frame -3-id
 hipError_t launch_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t st);
 
 struct CpGatherArgs {

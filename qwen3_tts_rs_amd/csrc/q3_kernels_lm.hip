@@ -622,22 +622,31 @@ hipError_t launch_gather_rows_bf16(const uint16_t* table, const uint32_t* ids, f
 }
 
 __global__ __launch_bounds__(256) void k_assemble_rows(const float* rows, const int* text_row, const uint16_t* codec_emb,
-                                                       const int* codec_id, const float* xvec, float* out, int H) {
+                                                       const int* codec_id, const float* xvec, float* out, int H,
+                                                       const uint32_t* ref_codes, const uint16_t* const* cp_embs) {
     const size_t i = blockIdx.x;
     const int tr = text_row[i], cid = codec_id[i];
     for (int c = threadIdx.x; c < H; c += 256) {
-        float v;
-        const float cv = cid >= 0 ? bf16_to_f32(codec_emb[(size_t)cid * H + c]) : (cid == -2 ? xvec[c] : 0.0f);
-        if (tr >= 0 && cid != -1) v = rows[(size_t)tr * H + c] + cv;       // text.add(codec)  (talker.rs:480, 782)
+        float v, cv;
+        if (cid >= 0) cv = bf16_to_f32(codec_emb[(size_t)cid * H + c]);
+        else if (cid == -2) cv = xvec[c];
+        else if (cid <= -3) {
+            // ICL reference frame: codec_emb[c0] + e0[c1] + … + e14[c15], left to right (lib.rs:1239-1257)
+            const uint32_t* fr = ref_codes + (size_t)(-3 - cid) * 16;
+            cv = bf16_to_f32(codec_emb[(size_t)fr[0] * H + c]);
+            for (int g = 1; g < 16; ++g) cv = __fadd_rn(cv, bf16_to_f32(cp_embs[g - 1][(size_t)fr[g] * H + c]));
+        } else cv = 0.0f;
+        if (tr >= 0 && cid != -1) v = rows[(size_t)tr * H + c] + cv;       // text.add(codec)  (talker.rs:480, 694, 706, 782)
         else if (tr >= 0) v = rows[(size_t)tr * H + c];
         else v = cv;
         out[i * H + c] = v;
     }
 }
 hipError_t launch_assemble_rows(const float* rows, const int* text_row, const uint16_t* codec_emb, const int* codec_id,
-                                const float* xvec, float* out, int n, int H, hipStream_t st) {
+                                const float* xvec, float* out, int n, int H, hipStream_t st, const uint32_t* ref_codes,
+                                const uint16_t* const* cp_embs) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_assemble_rows, dim3(n), dim3(256), 0, st, rows, text_row, codec_emb, codec_id, xvec, out, H);
+    hipLaunchKernelGGL(k_assemble_rows, dim3(n), dim3(256), 0, st, rows, text_row, codec_emb, codec_id, xvec, out, H, ref_codes, cp_embs);
     return hipGetLastError();
 }
 

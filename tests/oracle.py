@@ -54,6 +54,8 @@ class ORequest(ctypes.Structure):
         ("speaker_id", ctypes.c_uint32), ("language_id", ctypes.c_uint32),
         ("xvector", ctypes.POINTER(ctypes.c_float)),
         ("opts", OOptions),
+        ("ref_codes", ctypes.POINTER(ctypes.c_uint32)), ("n_ref", ctypes.c_int32),
+        ("ref_text_ids", ctypes.POINTER(ctypes.c_uint32)), ("n_ref_text", ctypes.c_int32),
     ]
 
 
@@ -80,6 +82,7 @@ olib.q3o_codes_to_tensor.argtypes = [vp, ci, vp]
 olib.q3o_session_new.restype = vp; olib.q3o_session_new.argtypes = [vp, ctypes.POINTER(ORequest)]
 olib.q3o_session_free.argtypes = [vp]
 olib.q3o_session_prefill_len.argtypes = [vp]
+olib.q3o_session_effective.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
 olib.q3o_session_prefill_out.argtypes = [vp, vp, vp]
 olib.q3o_session_prefill_embeds.argtypes = [vp, vp]
 olib.q3o_session_trailing_len.argtypes = [vp]
@@ -207,6 +210,11 @@ class OracleSession:
         if utt.xvector is not None:
             self._x = np.ascontiguousarray(utt.xvector, dtype=np.float32)
             r.xvector = self._x.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        if getattr(utt, "ref_codes", None) is not None:
+            self._rc = np.ascontiguousarray(utt.ref_codes, dtype=np.uint32).reshape(-1, 16)
+            self._rt = np.ascontiguousarray(utt.ref_text_ids, dtype=np.uint32)
+            r.ref_codes = self._rc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref = self._rc.shape[0]
+            r.ref_text_ids = self._rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(self._rt)
         o = to_ooptions(options)
         if utt.seed is not None:
             o.seed = int(utt.seed); o.has_seed = 1
@@ -223,6 +231,11 @@ class OracleSession:
 
     def prefill_len(self):
         return olib.q3o_session_prefill_len(self.h)
+
+    def effective(self):
+        rp = ctypes.c_double(); ml = ctypes.c_int()
+        olib.q3o_session_effective(self.h, ctypes.byref(rp), ctypes.byref(ml))
+        return rp.value, ml.value
 
     def prefill_out(self):
         hid = np.zeros(self.cfg.hidden, dtype=np.float32); lg = np.zeros(self.cfg.codec_vocab, dtype=np.float32)
@@ -241,7 +254,7 @@ class OracleSession:
         return tr, pad
 
     def generate(self, capture=False):
-        ml = self.options.max_length
+        ml = self.effective()[1]
         codes = np.zeros((ml, 16), dtype=np.uint32)
         tl = np.zeros((ml + 1, self.cfg.codec_vocab), dtype=np.float32) if capture else None
         cl = np.zeros((ml, 15, self.cfg.cp_vocab), dtype=np.float32) if capture else None

@@ -317,3 +317,32 @@ def test_full_size_frames(size):
         rms = float(np.sqrt(np.mean((pcm - opcm) ** 2)))
         assert rms <= 1e-3, rms
     gm.close(); om.close()
+
+
+@pytest.mark.parametrize("n_text,n_ref_text,n_ref", [(6, 4, 3), (2, 1, 8)])
+def test_icl_voice_clone(pair, n_text, n_ref_text, n_ref):
+    """ICL voice clone (lib.rs:897-1046): prompt, adjusted options, codes, and the ref-prepended / cut decode."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(n_text * 100 + n_ref)
+    ref_codes = rng.integers(0, 2048, size=(n_ref, 16)).astype(np.uint32); ref_codes[:, 0] = rng.integers(0, 3072, n_ref)
+    utt = q.Utterance(synthetic_prompt(n_text, 3), language=q.Language.Korean, xvector=rng.standard_normal(cfg.hidden).astype(np.float32),
+                      ref_codes=ref_codes, ref_text_ids=synthetic_prompt(n_ref_text, 4), seed=5)
+    opts = q.SynthesisOptions(max_length=200, seed=5, eos_token_id=None)
+    s = gm.session([utt], opts); s.prefill()
+    osess = O.OracleSession(om, utt, opts)
+    S, Ttr = s.prefill_len(0)
+    assert S == osess.prefill_len() == 9 + n_ref + 1
+    emb = s.get(0, (S, cfg.hidden)); oemb = osess.prefill_embeds()
+    assert np.abs(emb - oemb).max() <= 2e-5 * max(1.0, np.abs(oemb).max())
+    hid = s.get(1, (cfg.hidden,)); ohid, olg = osess.prefill_out()
+    assert np.abs(hid - ohid).max() <= 1e-4
+    s.generate(200)
+    codes = s.codes(0); ocodes = osess.generate()
+    assert len(ocodes) == max(75, 6 * n_text) == len(codes)
+    assert (codes == ocodes).all()
+    pcm = s.decode(0)
+    full = om.decode(np.concatenate([ref_codes, ocodes], 0))
+    cut = n_ref * len(full) // (n_ref + len(ocodes))
+    ref = full[cut:]
+    assert pcm.shape == ref.shape and float(np.sqrt(np.mean((pcm - ref) ** 2))) <= 1e-3
+    s.close(); osess.close()

@@ -83,3 +83,43 @@ def test_vocoder(models, T):
     ref = npm.decode(codes)
     assert pcm.shape[0] == T * 1920
     assert np.sqrt(np.mean((pcm - ref) ** 2)) < 1e-4
+
+
+@pytest.mark.parametrize("n_text,n_ref_text,n_ref", [(6, 4, 3), (2, 1, 8), (0, 3, 2)])
+def test_icl_prompt(models, n_text, n_ref_text, n_ref):
+    """ICL voice-clone prompt (talker.rs:511-564 icl_mode, 646-709 streaming overlay; lib.rs:913-929, 1239-1257)."""
+    cfg, om, npm = models
+    rng = np.random.default_rng(n_text * 100 + n_ref)
+    text = synthetic_prompt(n_text, 3); ref_text = synthetic_prompt(n_ref_text, 4)
+    ref_codes = rng.integers(0, 2048, size=(n_ref, 16)).astype(np.uint32); ref_codes[:, 0] = rng.integers(0, 3072, n_ref)
+    xv = rng.standard_normal(cfg.hidden).astype(np.float32)
+    utt = q.Utterance(text, language=q.Language.Korean, xvector=xv, ref_codes=ref_codes, ref_text_ids=ref_text)
+    s = O.OracleSession(om, utt, q.SynthesisOptions(max_length=200, seed=1))
+    rp, ml = s.effective()
+    assert rp == 1.5 and ml == max(75, 6 * n_text)                      # lib.rs:913-929
+    assert s.prefill_len() == 9 + n_ref + 1
+    emb = s.prefill_embeds()
+    w = npm.w; H = cfg.hidden
+    role = npm.text_proj([NP.IM_START, NP.ASSISTANT, NP.NEWLINE])
+    pad = npm.text_proj([NP.TTS_PAD]); bos = npm.text_proj([NP.TTS_BOS])
+    cod = npm.codec_emb([NP.CODEC_THINK, NP.CODEC_THINK_BOS, q.Language.Korean.token_id(), NP.CODEC_THINK_EOS])
+    cod6 = np.concatenate([cod, xv[None].astype(np.float64), npm.codec_emb([NP.CODEC_PAD])], 0)
+    ref = np.concatenate([role, np.concatenate([np.repeat(pad, 5, 0), bos], 0) + cod6], 0)
+    all_text = npm.text_proj(list(ref_text) + list(text) + [NP.TTS_EOS])
+    n_codec = n_ref + 1
+    frames = [npm.codec_emb([NP.CODEC_BOS])[0]]
+    for f in range(n_ref):
+        e = npm.codec_emb([ref_codes[f, 0]])[0]
+        for g in range(1, 16):
+            e = e + w.g(f"talker.code_predictor.model.codec_embedding.{g - 1}.weight", cfg.cp_vocab, H)[ref_codes[f, g]]
+        frames.append(e)
+    codec = np.stack(frames)
+    if len(all_text) > n_codec:
+        icl = all_text[:n_codec] + codec; trailing = all_text[n_codec:]
+    else:
+        icl = np.concatenate([all_text, np.repeat(pad, n_codec - len(all_text), 0)], 0) + codec; trailing = pad
+    ref = np.concatenate([ref, icl], 0)
+    assert np.abs(emb - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    tr, _ = s.trailing()
+    assert tr.shape[0] == trailing.shape[0] and np.abs(tr - trailing).max() < 2e-4
+    s.close()
