@@ -124,23 +124,30 @@ def main():
     H, I, CH, CI = cfg.hidden, cfg.inter, cfg.cp_hidden, cfg.cp_inter
     QD, KD = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
     CQD, CKD = cfg.cp_heads * cfg.head_dim, cfg.cp_kv_heads * cfg.head_dim
-    n_pass = cfg.n_groups
-    inventory = [  # (name, N, K, epi, rms, launches per frame)
-        ("talker qkv", QD + 2 * KD, H, 0, True, cfg.n_layers), ("talker o", H, QD, 1, False, cfg.n_layers),
-        ("talker gate/up", I, H, 3, True, cfg.n_layers), ("talker down", H, I, 1, False, cfg.n_layers),
-        ("codec head", cfg.codec_vocab, H, 0, False, 1),
-        ("cp qkv", CQD + 2 * CKD, CH, 0, True, cfg.cp_layers * n_pass), ("cp o", CH, CQD, 1, False, cfg.cp_layers * n_pass),
-        ("cp gate/up", CI, CH, 3, True, cfg.cp_layers * n_pass), ("cp down", CH, CI, 1, False, cfg.cp_layers * n_pass),
-        ("cp lm_head", cfg.cp_vocab, CH, 0, True, n_pass - 1),
+    # code-predictor passes per frame: the first pass carries two rows per sequence (talker hidden + semantic
+    # embedding, code_predictor.rs:340-362) when 2·B fits the 16-row MFMA tile, then 14 single-row passes;
+    # otherwise 16 single-row passes. (M, launches) pairs below follow the engine's cp_run exactly.
+    Mb = min(B, 16)
+    cp_passes = [(2 * Mb, 1), (Mb, 14)] if 2 * Mb <= 16 else [(Mb, 16)]
+    inventory = [  # (name, N, K, epi, rms, [(M, launches per frame)])
+        ("talker qkv", QD + 2 * KD, H, 0, True, [(Mb, cfg.n_layers)]), ("talker o", H, QD, 1, False, [(Mb, cfg.n_layers)]),
+        ("talker gate/up", I, H, 3, True, [(Mb, cfg.n_layers)]), ("talker down", H, I, 1, False, [(Mb, cfg.n_layers)]),
+        ("codec head", cfg.codec_vocab, H, 0, False, [(Mb, 1)]),
+        ("cp qkv", CQD + 2 * CKD, CH, 0, True, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
+        ("cp o", CH, CQD, 1, False, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
+        ("cp gate/up", CI, CH, 3, True, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
+        ("cp down", CH, CI, 1, False, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
+        ("cp lm_head", cfg.cp_vocab, CH, 0, True, [(Mb, cfg.n_groups - 1)]),
     ]
     if H != CH:
-        inventory.append(("cp mtp proj", CH, H, 0, False, n_pass))
+        inventory.append(("cp mtp proj", CH, H, 0, False, cp_passes))
     tot_bytes = tot_us = 0.0; launches = 0; per_shape = {}
-    for name, N, K, epi, rms, cnt in inventory:
-        us = bench_linear(min(B, 16), N, K, epi, rms, device=dev)
+    for name, N, K, epi, rms, ms in inventory:
         nb = N * K * 2 * (2 if epi == 3 else 1)
-        per_shape[name] = {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
-        tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
+        for Mrows, cnt in ms:
+            us = bench_linear(Mrows, N, K, epi, rms, device=dev)
+            per_shape[f"{name} M={Mrows}"] = {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
+            tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
     s = model.session(utts, q.SynthesisOptions(max_length=4, eos_token_id=None, seed=42))
     wbytes, kvbytes = s.frame_bytes(10 + args.frames // 2)
     s.close()
@@ -153,7 +160,8 @@ def main():
         pmc = json.load(open(pmc_path))["shapes"]
         key = lambda n: n.replace(" ", "_").replace("/", "")
         if all(key(n) in pmc for n, *_ in inventory):
-            traffic = sum((pmc[key(n)]["fetch_bytes_corrected"] + pmc[key(n)]["write_bytes"]) * cnt for n, _, _, _, _, cnt in inventory) / launches
+            traffic = sum((pmc[key(n)]["fetch_bytes_corrected"] + pmc[key(n)]["write_bytes"]) * sum(c for _, c in ms)
+                          for n, _, _, _, _, ms in inventory) / launches
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": os.path.basename(pmc_path) if traffic else None,
                 "kernel": "k_gemv_mfma / k_gemv_mfma4 (bf16-weight MFMA GEMV family, M = batch)",

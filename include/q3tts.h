@@ -136,6 +136,8 @@ void      q3_model_free(q3_model* m);
  * SOURCE dtype; talker/code-predictor matrices are stored bf16 in HBM (the checkpoint's native
  * dtype, lib.rs:1394-1396), norms/biases and all decoder tensors f32 (lib.rs:344-353). */
 q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtype, const void* data_host, int64_t n);
+/* the shape constants the handle was built with (talker.config(), talker.rs:843-846) */
+q3_status q3_model_config(const q3_model* m, q3_config* out);
 /* Names the model expects: i in [0, q3_model_n_tensors); returns name, element count, stored dtype */
 int       q3_model_n_tensors(const q3_model* m);
 q3_status q3_model_tensor_info(const q3_model* m, int i, const char** name, int64_t* n, int* stored_dtype);
@@ -252,6 +254,36 @@ q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int
 q3_status q3_session_stream(q3_session* s, void** stream);
 /* Algorithmic HBM bytes of one frame for this session's batch at KV length L */
 q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes);
+
+/* ---------------- on-disk formats (q3_io.cpp) ----------------
+ * ModelType (config.rs:176-194); UNKNOWN = loaded without a usable config.json (lib.rs:383-389) */
+enum { Q3_MODEL_UNKNOWN = -1, Q3_MODEL_BASE = 0, Q3_MODEL_CUSTOM_VOICE = 1, Q3_MODEL_VOICE_DESIGN = 2 };
+/* TalkerConfig::default / ::custom_voice + CodePredictorConfig::default + Decoder12HzConfig::default
+ * (talker.rs:176-290, code_predictor.rs:48-113, decoder_12hz.rs:14-67): variant 0 = 0.6B, 1 = 1.7B */
+q3_status q3_config_default(int variant, q3_config* out);
+/* ParsedModelConfig::from_file (config.rs:238-336): same keys, same unwrap_or defaults; decoder fields
+ * are Decoder12HzConfig::default (the reference does not read them from config.json either, lib.rs:345) */
+q3_status q3_config_from_json(const char* path, q3_config* out, int* model_type);
+/* Qwen3TTS::from_pretrained minus the tokenizer (lib.rs:180-262): <dir>/config.json (optional; weight
+ * inspection fallback of lib.rs:371-381), <dir>/model.safetensors, <dir>/speech_tokenizer/model.safetensors
+ * (or the parent directory's), every expected tensor uploaded, q3_model_finalize run. Tensors the hot
+ * path does not use (speaker_encoder.*, encoder.*) are skipped. device = -1: manifest-only handle. */
+q3_status q3_model_load(const char* model_dir, int device, q3_model** out, int* model_type);
+/* load_weights (lib.rs:1390-1396) into an existing handle: uploads every tensor of the file the model
+ * expects (BF16 / F32 / F16 / F64 sources); n_loaded may be NULL */
+q3_status q3_model_load_safetensors(q3_model* m, const char* path, int* n_loaded);
+/* header lookup of one tensor: stored dtype (Q3_DTYPE_* or -1), rank and up to cap_dims dims */
+q3_status q3_safetensors_info(const char* path, const char* name, int* dtype, int64_t* shape, int cap_dims, int* n_dims);
+/* save_wav (audio/io.rs:143-165): mono PCM16, `(clamp(x,-1,1) * 32767) as i16` */
+q3_status q3_pcm16_from_f32(const float* samples_host, int64_t n, int16_t* out_host);
+q3_status q3_wav_write_pcm16(const char* path, const float* samples_host, int64_t n, uint32_t sample_rate);
+/* load_wav (audio/io.rs:106-141): int PCM scaled by 2^(bits-1), float as is, channels averaged to mono.
+ * out_host = NULL queries *n_samples / *sample_rate only */
+q3_status q3_wav_read(const char* path, float* out_host, int64_t cap, int64_t* n_samples, uint32_t* sample_rate);
+/* save_codes_binary / save_audio_binary (bin/generate_audio.rs:788-813): i64 LE frame-major codes, f32 LE samples */
+q3_status q3_codes_write_bin(const char* path, const uint32_t* codes_host, int n_frames, int n_groups);
+q3_status q3_codes_read_bin(const char* path, uint32_t* codes_host, int cap_frames, int n_groups, int* n_frames);
+q3_status q3_audio_write_bin(const char* path, const float* samples_host, int64_t n);
 
 #ifdef __cplusplus
 }

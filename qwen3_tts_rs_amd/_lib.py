@@ -6,7 +6,7 @@ import os
 from .config import CConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libq3tts.so")
+LIB_PATH = os.environ.get("Q3TTS_LIB") or os.path.join(_HERE, "libq3tts.so")   # env override: kernel-ablation builds (dev aid)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -87,6 +87,18 @@ SYMBOLS = {
     "q3_bench_linear": (c_int, [c_int] * 9 + [P(ctypes.c_double)]),
     "q3_session_stream": (c_int, [c_void_p, P(c_void_p)]),
     "q3_session_frame_bytes": (c_int, [c_void_p, c_int, P(ctypes.c_double), P(ctypes.c_double)]),
+    "q3_model_config": (c_int, [c_void_p, P(CConfig)]),
+    "q3_config_default": (c_int, [c_int, P(CConfig)]),
+    "q3_config_from_json": (c_int, [c_char_p, P(CConfig), P(c_int)]),
+    "q3_model_load": (c_int, [c_char_p, c_int, P(c_void_p), P(c_int)]),
+    "q3_model_load_safetensors": (c_int, [c_void_p, c_char_p, P(c_int)]),
+    "q3_safetensors_info": (c_int, [c_char_p, c_char_p, P(c_int), P(ctypes.c_int64), c_int, P(c_int)]),
+    "q3_pcm16_from_f32": (c_int, [c_void_p, ctypes.c_int64, c_void_p]),
+    "q3_wav_write_pcm16": (c_int, [c_char_p, c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "q3_wav_read": (c_int, [c_char_p, c_void_p, ctypes.c_int64, P(ctypes.c_int64), P(ctypes.c_uint32)]),
+    "q3_codes_write_bin": (c_int, [c_char_p, c_void_p, c_int, c_int]),
+    "q3_codes_read_bin": (c_int, [c_char_p, c_void_p, c_int, c_int, P(c_int)]),
+    "q3_audio_write_bin": (c_int, [c_char_p, c_void_p, ctypes.c_int64]),
 }
 
 for _name, (_res, _args) in SYMBOLS.items():

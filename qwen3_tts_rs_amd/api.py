@@ -127,6 +127,13 @@ class AudioBuffer:             # audio/io.rs:28-34
     def duration(self) -> float:
         return len(self) / float(self.sample_rate)
 
+    def save(self, path: str):                       # AudioBuffer::save → save_wav (audio/io.rs:143-165)
+        save_wav(path, self.samples, self.sample_rate)
+
+    @classmethod
+    def load(cls, path: str) -> "AudioBuffer":       # AudioBuffer::load → load_wav (audio/io.rs:106-141)
+        return load_wav(path)
+
 
 @dataclass
 class Utterance:
@@ -318,17 +325,47 @@ class StreamingSession:
         return c
 
 
-class Qwen3TTS:
-    """Qwen3TTS facade (lib.rs:154-173). Construct with `from_tensors` (name → array, the
-    from_weights path, lib.rs:267) or `from_synthetic`."""
+class ModelType(enum.Enum):    # config.rs:176-194
+    Base = 0
+    CustomVoice = 1
+    VoiceDesign = 2
 
-    def __init__(self, config: Q3Config, device: int = 0):
+
+class Qwen3TTS:
+    """Qwen3TTS facade (lib.rs:154-173). Construct with `from_pretrained` (model directory: config.json +
+    safetensors, lib.rs:180-262), `from_tensors` (name → array, the from_weights path, lib.rs:267) or
+    `from_synthetic`."""
+
+    def __init__(self, config: Q3Config, device: int = 0, _handle=None):
         self.config = config
         self.device_index = device
+        self.model_type: Optional[ModelType] = None     # None = loaded without config.json (lib.rs:383-386)
+        if _handle is not None:
+            self._h = _handle
+            return
         h = ctypes.c_void_p()
         c = config.to_c()
         check(lib.q3_model_create(ctypes.byref(c), device, ctypes.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_pretrained(cls, model_dir: str, device: int = 0) -> "Qwen3TTS":
+        """Load `<dir>/config.json`, `<dir>/model.safetensors` and `<dir>/speech_tokenizer/model.safetensors`
+        (lib.rs:180-262) through the C++ loader (q3_model_load). Tokenization stays with the caller."""
+        h = ctypes.c_void_p(); mt = ctypes.c_int(-1)
+        check(lib.q3_model_load(str(model_dir).encode(), device, ctypes.byref(h), ctypes.byref(mt)))
+        from .config import CConfig
+        c = CConfig()
+        check(lib.q3_model_config(h, ctypes.byref(c)))
+        m = cls(Q3Config.from_c(c), device, _handle=h)
+        m.model_type = ModelType(mt.value) if mt.value >= 0 else None
+        return m
+
+    def supports_preset_speakers(self) -> bool:        # lib.rs:398-404 (permissive when unknown)
+        return self.model_type in (None, ModelType.CustomVoice)
+
+    def supports_voice_design(self) -> bool:           # lib.rs:409-411
+        return self.model_type == ModelType.VoiceDesign
 
     def close(self):
         if getattr(self, "_h", None):
@@ -434,6 +471,50 @@ class Qwen3TTS:
         check(lib.q3_frame_embed(self._h, int(sem_token), c.ctypes.data_as(ctypes.c_void_p), t.ctypes.data_as(ctypes.c_void_p),
                                  out.ctypes.data_as(ctypes.c_void_p)))
         return out
+
+
+def pcm16(samples: np.ndarray) -> np.ndarray:
+    """`(clamp(x, -1, 1) * 32767) as i16` (audio/io.rs:158-160)."""
+    a = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    out = np.empty(a.size, dtype=np.int16)
+    check(lib.q3_pcm16_from_f32(a.ctypes.data_as(ctypes.c_void_p), a.size, out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def save_wav(path: str, samples: np.ndarray, sample_rate: int = 24000):
+    """save_wav (audio/io.rs:143-165): mono PCM16."""
+    a = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    check(lib.q3_wav_write_pcm16(str(path).encode(), a.ctypes.data_as(ctypes.c_void_p), a.size, int(sample_rate)))
+
+
+def load_wav(path: str) -> AudioBuffer:
+    """load_wav (audio/io.rs:106-141): PCM/float WAV → mono f32."""
+    n = ctypes.c_int64(); rate = ctypes.c_uint32()
+    check(lib.q3_wav_read(str(path).encode(), None, 0, ctypes.byref(n), ctypes.byref(rate)))
+    out = np.empty(n.value, dtype=np.float32)
+    check(lib.q3_wav_read(str(path).encode(), out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(n), ctypes.byref(rate)))
+    return AudioBuffer(out, int(rate.value))
+
+
+def save_codes_binary(path: str, codes: np.ndarray):
+    """save_codes_binary (bin/generate_audio.rs:788-801): [n_frames][16] codes as i64 LE, frame-major."""
+    a = np.ascontiguousarray(codes, dtype=np.uint32)
+    assert a.ndim == 2
+    check(lib.q3_codes_write_bin(str(path).encode(), a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1]))
+
+
+def load_codes_binary(path: str, n_groups: int = 16) -> np.ndarray:
+    n = ctypes.c_int()
+    check(lib.q3_codes_read_bin(str(path).encode(), None, 0, n_groups, ctypes.byref(n)))
+    out = np.empty((n.value, n_groups), dtype=np.uint32)
+    check(lib.q3_codes_read_bin(str(path).encode(), out.ctypes.data_as(ctypes.c_void_p), n.value, n_groups, ctypes.byref(n)))
+    return out
+
+
+def save_audio_binary(path: str, samples: np.ndarray):
+    """save_audio_binary (bin/generate_audio.rs:804-813): f32 LE."""
+    a = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    check(lib.q3_audio_write_bin(str(path).encode(), a.ctypes.data_as(ctypes.c_void_p), a.size))
 
 
 def codes_to_tensor(codes: np.ndarray) -> np.ndarray:

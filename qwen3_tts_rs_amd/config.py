@@ -72,6 +72,24 @@ class Q3Config:
                 setattr(c, f, v)
         return c
 
+    @classmethod
+    def from_c(cls, c: CConfig, name: str = "") -> "Q3Config":
+        kw = {}
+        for f, _ in CConfig._fields_:
+            v = getattr(c, f)
+            kw[f] = list(v) if f in ("dec_up_ratios", "dec_up_rates") else v
+        if not name:
+            name = "qwen3-tts-1.7b" if kw["hidden"] == 2048 else ("qwen3-tts-0.6b" if kw["hidden"] == 1024 else "custom")
+        return cls(name=name, **kw)
+
+    @classmethod
+    def from_json(cls, path: str):
+        """ParsedModelConfig::from_file (config.rs:238-336) → (Q3Config, model_type); parsed by the C++ loader."""
+        from . import _lib
+        c = CConfig(); mt = ctypes.c_int(-1)
+        _lib.check(_lib.lib.q3_config_from_json(str(path).encode(), ctypes.byref(c), ctypes.byref(mt)))
+        return cls.from_c(c), mt.value
+
     @property
     def samples_per_frame(self) -> int:
         n = 1

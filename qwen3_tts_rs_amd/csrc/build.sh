@@ -14,6 +14,10 @@ for f in q3_kernels_lm q3_kernels_gemv q3_kernels_codec q3_engine; do
     pids+=($!)
   fi
 done
+if [ ! -f "$BUILD/q3_io.o" ] || [ "$HERE/q3_io.cpp" -nt "$BUILD/q3_io.o" ] || [ "$HERE/q3_internal.h" -nt "$BUILD/q3_io.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/q3_io.o" ]; then
+  $HIPCC -O2 -std=c++17 -fPIC -Wall -c "$HERE/q3_io.cpp" -o "$BUILD/q3_io.o" &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_gemv.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_engine.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_gemv.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_engine.o" "$BUILD/q3_io.o"
 echo "built $OUT"

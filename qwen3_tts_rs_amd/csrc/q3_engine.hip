@@ -22,6 +22,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "q3_internal.h"
 using namespace q3;
 
 // ------------------------------------------------------------------------------------------------
@@ -29,6 +30,10 @@ using namespace q3;
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
 static q3_status set_err(q3_status st, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return st;
+}
+extern "C" q3_status q3i_set_err(q3_status st, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return st;
 }
@@ -395,6 +400,11 @@ extern "C" void q3_model_free(q3_model* m) {
     delete m;
 }
 
+extern "C" q3_status q3_model_config(const q3_model* m, q3_config* out) {
+    if (!m || !out) return set_err(Q3_INVALID_ARG, "q3_model_config: null argument");
+    *out = m->cfg;
+    return Q3_OK;
+}
 extern "C" int q3_model_n_tensors(const q3_model* m) { return m ? (int)m->slots.size() : 0; }
 extern "C" q3_status q3_model_tensor_info(const q3_model* m, int i, const char** name, int64_t* n, int* stored_dtype) {
     if (!m || i < 0 || i >= (int)m->slots.size()) return set_err(Q3_INVALID_ARG, "tensor index out of range");

@@ -40,9 +40,21 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 
 struct Split3 { u32x4_t hi, mid, lo; };
 
+// Development aid (never defined in product builds): -DQ3_ABLATE=n removes one ingredient of the GEMV kernels to
+// price it — 1: bf16x3 split → hi only, 2: + no x loads, 3: no cross-wave reduction, 4: no weight loads. Results
+// are wrong by construction.
+#ifndef Q3_ABLATE
+#define Q3_ABLATE 0
+#endif
+
 // exact 3-way bf16 split of 8 floats (packed pairs: element 2i in the low half of word i)
 __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
     Split3 s;
+#if Q3_ABLATE == 1 || Q3_ABLATE == 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s.hi[i] = cvt_pk_bf16(x[2 * i], x[2 * i + 1]); s.mid[i] = 0; s.lo[i] = 0; }
+    return s;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float a = x[2 * i], b = x[2 * i + 1];
@@ -63,11 +75,16 @@ __device__ __forceinline__ f32x4_t mfma3(const u32x4_t& w, const Split3& s, f32x
     return acc;
 }
 
-// One k-step for this lane: finish the B operand (mask, Σx², norm weight, bf16x3 split) and run the MFMAs.
-template <int NW, bool RMS>
-__device__ __forceinline__ void gemv_step(bool valid, const float4& x0, const float4& x1, const float4& n0, const float4& n1,
-                                          const u32x4_t& wa, const u32x4_t& wb, f32x4_t& acc0, f32x4_t& acc1, float& ss) {
+// B operand of one k-step for this lane: mask, Σx², norm weight, exact bf16x3 split. Needs only x / norm weight
+// (L2-resident), so it runs while the weight tiles of the group are still in flight from HBM.
+template <bool RMS>
+__device__ __forceinline__ Split3 gemv_prep(bool valid, const float4& x0, const float4& x1, const float4& n0, const float4& n1, float& ss) {
+#if Q3_ABLATE == 2
+    float xv[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+    { const Split3 r = split3(xv); ss += valid ? 1.f : 0.f; return r; }
+#else
     float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#endif
 #pragma unroll
     for (int e = 0; e < 8; ++e) xv[e] = valid ? xv[e] : 0.0f;
     if constexpr (RMS) {
@@ -75,9 +92,7 @@ __device__ __forceinline__ void gemv_step(bool valid, const float4& x0, const fl
         for (int e = 0; e < 8; ++e) ss = fmaf(xv[e], xv[e], ss);
         xv[0] *= n0.x; xv[1] *= n0.y; xv[2] *= n0.z; xv[3] *= n0.w; xv[4] *= n1.x; xv[5] *= n1.y; xv[6] *= n1.z; xv[7] *= n1.w;
     }
-    const Split3 sp = split3(xv);
-    acc0 = mfma3(wa, sp, acc0);
-    if constexpr (NW == 2) acc1 = mfma3(wb, sp, acc1);
+    return split3(xv);
 }
 
 // NWAVES waves split K; weights for up to G k-steps are requested up front (G KiB per wave in flight per
@@ -99,35 +114,99 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     const float* __restrict__ xr = a.x + (size_t)(act ? m : 0) * a.ldx + kg * 8;
     const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 : nullptr;
 
+    // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
+    float pre_b = 0.0f, pre_r = 0.0f;
+    {
+        const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
+        if (tid < 256 && col < a.M && n < a.N) {
+            if (a.bias) pre_b = a.bias[n];
+            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
+        }
+    }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.0f;
+    // Two schedules. HOIST (8-wave workgroups, 256 VGPRs per lane available): VMEM returns are counted in issue
+    // order, so x / norm weight (L2 hits) are requested FIRST and the HBM weight tiles after them; the bf16x3 split
+    // (the VALU-heavy part) of the whole group then runs under the weight latency and only the MFMAs wait for HBM.
+    // 16-wave workgroups have 128 VGPRs per lane — not enough to hold a group's splits — and keep the interleaved
+    // per-step order.
+    constexpr bool HOIST = NWAVES == 8;
     for (int sb = s0; sb < s1; sb += G) {
-        // every load of the group (weights from HBM, x / norm weight from L2) is issued before any is consumed
         u32x4_t wa[G], wb[G];
         float4 xa[G], xb[G], na[G], nb[G];
+        if constexpr (HOIST) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);      // clamp: duplicate load, masked below
-            wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-            if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
-            const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;    // K tail (K % 32 != 0): clamp, masked below
-            xa[i] = *reinterpret_cast<const float4*>(xr + ko);
-            xb[i] = *reinterpret_cast<const float4*>(xr + ko + 4);
-            if constexpr (RMS) {
-                na[i] = *reinterpret_cast<const float4*>(nwp + ko);
-                nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
+            for (int i = 0; i < G; ++i) {
+                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);      // clamp: duplicate load, masked below
+                const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;    // K tail (K % 32 != 0): clamp, masked below
+                // lanes of unused batch columns (m >= M) issue no request: at M = 8 that halves the L2 -> L1 x traffic,
+                // which is as large as the weight stream itself (x is f32 x M rows, a tile is bf16 x 16 rows)
+                xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (RMS) {
+                    na[i] = *reinterpret_cast<const float4*>(nwp + ko);
+                    nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
+                }
             }
-        }
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int s = sb + i;
-            if (s < s1) {
-                const bool valid = act && (s * 32 + kg * 8) < a.K;
-                gemv_step<NW, RMS>(valid, xa[i], xb[i], RMS ? na[i] : xa[i], RMS ? nb[i] : xb[i], wa[i], NW == 2 ? wb[i] : wa[i],
-                                   acc0, acc1, ss);
+            for (int i = 0; i < G; ++i) {
+                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+#if Q3_ABLATE == 4
+                wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; wb[i] = wa[i];
+#else
+                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep every load of the group issued before the first use
+            Split3 sp[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = sb + i;      // s >= s1 (ragged last group): zero operand, its MFMAs add nothing — no branch,
+                const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;   // so the group stays one scheduling region
+                sp[i] = gemv_prep<RMS>(valid, xa[i], xb[i], RMS ? na[i] : xa[i], RMS ? nb[i] : xb[i], ss);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // all splits done before the first wait on a weight tile
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                acc0 = mfma3(wa[i], sp[i], acc0);
+                if constexpr (NW == 2) acc1 = mfma3(wb[i], sp[i], acc1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+                const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;
+                // lanes of unused batch columns (m >= M) issue no request: at M = 8 that halves the L2 -> L1 x traffic,
+                // which is as large as the weight stream itself (x is f32 x M rows, a tile is bf16 x 16 rows)
+                xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (RMS) {
+                    na[i] = *reinterpret_cast<const float4*>(nwp + ko);
+                    nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = sb + i;
+                if (s < s1) {
+                    const bool valid = act && (s * 32 + kg * 8) < a.K;
+                    const Split3 sp = gemv_prep<RMS>(valid, xa[i], xb[i], RMS ? na[i] : xa[i], RMS ? nb[i] : xb[i], ss);
+                    acc0 = mfma3(wa[i], sp, acc0);
+                    if constexpr (NW == 2) acc1 = mfma3(wb[i], sp, acc1);
+                }
             }
         }
     }
+#if Q3_ABLATE == 3
+    if (wave == 0 && act) {
+        float* yo = a.y + (size_t)m * a.ldy + blockIdx.x * 16 + kg * 4;
+        yo[0] = acc0[0] + acc1[0] + ss; yo[1] = acc0[1]; yo[2] = acc0[2]; yo[3] = acc0[3];
+    }
+    return;
+#endif
     // partial tile → LDS, layout [col m][row]: lane (m, kg) owns rows kg*4 .. kg*4+3
     *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = acc0;
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = acc1;
@@ -154,8 +233,192 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
             }
             const int n = blockIdx.x * 16 + row;
             if (n < a.N) {
-                if (a.bias) v = v + a.bias[n];
-                if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)col * a.ldr + n] + v;
+                if (a.bias) v = v + pre_b;
+                if constexpr (EPI == EPI_RESID) v = pre_r + v;
+                if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+                if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+                a.y[(size_t)col * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Third generation of the 16-row-tile kernel: x goes through a wave-private LDS staging buffer.
+//
+// Measured on MI355X (tests/bench_kernels.py with the -DQ3_ABLATE builds): in k_gemv_mfma the B-operand loads — two
+// 16-B x loads and two 16-B norm-weight loads per lane per k-step, against ONE weight load — take 30-45 % of the
+// kernel (removing them: qkv 7.8 -> 4.7 us, down 12.3 -> 6.6 us at M = 8) although they hit L2: every 64-lane
+// dwordx4 load costs the CU's vector-memory pipe the same ~16 clocks whether it brings 1 KiB of fresh weights or
+// 16 half-used cache lines of x, so 4 of every 5 VMEM instructions moved activations.
+// Here a wave brings the x rows of a 128-float k-group in with row-contiguous loads (one instruction = two rows x
+// 512 B, only rows < M), applies the norm weight and accumulates sum(x^2) on that coalesced form, parks the
+// result in its own 8.25 KiB LDS buffer and reads the MFMA B operand back with two ds_read_b128 per k-step — the
+// LDS pipe is separate from VMEM. Per 4 k-steps at M = 8: 4 (x) + 1 (norm) + 4 (weights) VMEM instructions
+// instead of 20. Weight tiles and the next group's x are requested one group ahead (double buffered), so a wave
+// keeps 8 KiB of weights in flight however long its K slice is, and one geometry (8 waves) serves every shape.
+// ------------------------------------------------------------------------------------------------
+constexpr int ZS = 132;              // staging row stride in floats: 128 + 4 pad → the 16 rows of one ds_read_b128
+                                     // phase land on 16 distinct 4-bank groups
+constexpr int ZB = 16 * ZS;          // floats per wave
+
+struct XGroup { float4 x[8]; float4 nw; };    // rows (2r + lane/32), floats (lane%32)*4 .. +3 of the k-group
+
+template <bool RMS>
+__device__ __forceinline__ void xg_load(XGroup& g, const float* __restrict__ x, int ldx, const float* __restrict__ norm_w,
+                                        int M, int K, int k0, int lane) {
+    const int half = lane >> 5, c = k0 + (lane & 31) * 4;
+    const bool kok = c < K;                                    // K % 4 == 0: a float4 is all in or all out
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (2 * r < M) {                                       // wave-uniform
+            const int row = 2 * r + half;
+            g.x[r] = (kok && row < M) ? *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if constexpr (RMS) g.nw = kok ? *reinterpret_cast<const float4*>(norm_w + c) : float4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <bool RMS>
+__device__ __forceinline__ void xg_stage(const XGroup& g, float* __restrict__ zb, float (&ss)[8], int M, int lane) {
+    const int half = lane >> 5, c4 = (lane & 31) * 4;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (2 * r < M) {
+            float4 v = g.x[r];
+            if constexpr (RMS) {
+                ss[r] = fmaf(v.x, v.x, ss[r]); ss[r] = fmaf(v.y, v.y, ss[r]); ss[r] = fmaf(v.z, v.z, ss[r]); ss[r] = fmaf(v.w, v.w, ss[r]);
+                v.x *= g.nw.x; v.y *= g.nw.y; v.z *= g.nw.z; v.w *= g.nw.w;
+            }
+            *reinterpret_cast<float4*>(zb + (2 * r + half) * ZS + c4) = v;
+        }
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void wg_load(u32x4_t (&wa)[4], u32x4_t (&wb)[4], const u32x4_t* __restrict__ wp,
+                                        const u32x4_t* __restrict__ wp2, int sb, int s1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);     // ragged last group: duplicate load, never consumed
+        wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+        if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void g_compute(const u32x4_t (&wa)[4], const u32x4_t (&wb)[4], const float* __restrict__ zrow,
+                                          bool act, int sb, int s1, f32x4_t& acc0, f32x4_t& acc1) {
+    Split3 sp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a0 = *reinterpret_cast<const float4*>(zrow + i * 32);
+        const float4 a1 = *reinterpret_cast<const float4*>(zrow + i * 32 + 4);
+        float xv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = act ? xv[e] : 0.0f;     // columns >= M read rows nobody staged
+        sp[i] = split3(xv);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the splits (LDS + VALU) run under the weight latency; only the MFMAs wait on HBM
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (sb + i < s1) {                  // wave-uniform
+            acc0 = mfma3(wa[i], sp[i], acc0);
+            if constexpr (NW == 2) acc1 = mfma3(wb[i], sp[i], acc1);
+        }
+    }
+}
+
+template <int EPI, bool RMS>
+__global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
+    constexpr int NWAVES = 8, G = 4;
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float lds[NWAVES * ZB + NWAVES * 16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int S = a.Kpad >> 5;                       // k-steps of 32
+    const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
+    const size_t tile_base = (size_t)blockIdx.x * S * 64 + lane;
+    const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + tile_base;
+    const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : wp;
+    const bool act = m < a.M;
+    float* __restrict__ zb = lds + wave * ZB;
+    const float* __restrict__ zrow = zb + m * ZS + kg * 8;
+    float* __restrict__ ssq = lds + NWAVES * ZB;      // [NWAVES][16], outside the area `red` aliases
+
+    // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
+    float pre_b = 0.0f, pre_r = 0.0f;
+    {
+        const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
+        if (tid < 256 && col < a.M && n < a.N) {
+            if (a.bias) pre_b = a.bias[n];
+            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
+        }
+    }
+
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float ss[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    XGroup X0, X1;
+    u32x4_t wa0[G], wb0[G], wa1[G], wb1[G];
+    if (s0 < s1) {
+        // x first, weights second: VMEM returns are counted in issue order, the staging must not wait for HBM.
+        // (Requesting weights two groups ahead instead of one measured 5-10 % slower: more live registers, same latency.)
+        xg_load<RMS>(X0, a.x, a.ldx, a.norm_w, a.M, a.K, s0 * 32, lane);
+        wg_load<NW>(wa0, wb0, wp, wp2, s0, s1);
+        for (int sb = s0; sb < s1; sb += 2 * G) {
+            xg_stage<RMS>(X0, zb, ss, a.M, lane);
+            const bool more1 = sb + G < s1;
+            if (more1) {
+                xg_load<RMS>(X1, a.x, a.ldx, a.norm_w, a.M, a.K, (sb + G) * 32, lane);
+                wg_load<NW>(wa1, wb1, wp, wp2, sb + G, s1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            g_compute<NW>(wa0, wb0, zrow, act, sb, s1, acc0, acc1);
+            if (!more1) break;
+            xg_stage<RMS>(X1, zb, ss, a.M, lane);
+            if (sb + 2 * G < s1) {
+                xg_load<RMS>(X0, a.x, a.ldx, a.norm_w, a.M, a.K, (sb + 2 * G) * 32, lane);
+                wg_load<NW>(wa0, wb0, wp, wp2, sb + 2 * G, s1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            g_compute<NW>(wa1, wb1, zrow, act, sb + G, s1, acc0, acc1);
+        }
+    }
+    if constexpr (RMS) {
+        // per-row sum(x^2) of this wave's K slice: lanes 0-31 hold row 2r, lanes 32-63 row 2r+1
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float v = ss[r];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            if ((lane & 31) == 0) ssq[wave * 16 + 2 * r + (lane >> 5)] = v;
+        }
+    }
+    __syncthreads();                                  // every wave is done with its staging buffer: `red` may alias it
+    float* __restrict__ red = lds;                    // [NWAVES][NW][256], layout [col m][row]
+    *reinterpret_cast<f32x4_t*>(&red[(wave * NW + 0) * 256 + m * 16 + kg * 4]) = acc0;
+    if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[(wave * NW + 1) * 256 + m * 16 + kg * 4]) = acc1;
+    __syncthreads();
+    if (tid < 256) {
+        const int col = tid >> 4, row = tid & 15;
+        if (col < a.M) {
+            float v = 0.0f, v2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) {
+                v += red[(w * NW + 0) * 256 + tid];
+                if constexpr (NW == 2) v2 += red[(w * NW + 1) * 256 + tid];
+            }
+            if constexpr (RMS) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NWAVES; ++w) tot += ssq[w * 16 + col];
+                const float den = sqrtf(tot / (float)a.K + a.eps);
+                v = v / den;
+                if constexpr (NW == 2) v2 = v2 / den;
+            }
+            const int n = blockIdx.x * 16 + row;
+            if (n < a.N) {
+                if (a.bias) v = v + pre_b;
+                if constexpr (EPI == EPI_RESID) v = pre_r + v;
                 if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
                 if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
                 a.y[(size_t)col * a.ldy + n] = v;
@@ -171,6 +434,16 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     // 16 waves per tile when the tile count alone cannot fill the chip or the per-wave slice gets long
     bool big = (tiles < 256 && S >= 32) || S >= 128;
     static const int force = [] { const char* e = getenv("Q3_GEMV_WAVES"); return e ? atoi(e) : 0; }();   // tuning aid
+    // Kernel choice, from tests/bench_kernels.py on MI355X (profiles/r1_gemv_microbench_lds.log): the LDS-staged
+    // generation wins where the tile count leaves CUs idle (latency-bound launches: o-proj, codec head, code-predictor
+    // gate/up and lm_head: 6.6 -> 5.9, 6.9 -> 6.2, 7.6 -> 6.5, 6.4 -> 5.1 us at M = 8) and is flat in M; with >= 256
+    // tiles or a long K slice the register-direct kernels stream better (qkv 7.5 vs 8.4, gate/up 13.7 vs 17.8 us).
+    // Q3_GEMV_WAVES = 8 / 16 forces the register-direct kernels, 1 forces the LDS-staged one (tuning aid).
+    const bool lds_ok = a.K % 4 == 0 && S >= 8;
+    if (lds_ok && (force == 1 || (force == 0 && tiles < 256 && S <= 64))) {
+        hipLaunchKernelGGL((k_gemv_lds<EPI, RMS>), dim3(tiles), dim3(512), 0, st, a);
+        return hipGetLastError();
+    }
     if (force == 8) big = false; else if (force == 16) big = true;
     if (big) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16>), dim3(tiles), dim3(16 * 64), 0, st, a);
     else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8>), dim3(tiles), dim3(8 * 64), 0, st, a);
@@ -203,10 +476,9 @@ __device__ __forceinline__ float sum_over_blocks(float v) {   // lanes 4b+j, all
     return v;
 }
 
-template <int EPI, bool RMS, int MG>
+template <int EPI, bool RMS, int MG, int G = 2>
 __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr int G = 2;
     __shared__ float red[8][NW][MG][4][4];
     __shared__ float ssq[8][MG][4];
     const int nwv = blockDim.x >> 6;
@@ -226,6 +498,14 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     }
     const float* __restrict__ nwp = RMS ? a.norm_w + kb * 8 : nullptr;
 
+    float pre_b = 0.0f, pre_r = 0.0f;     // epilogue operands requested up front (see k_gemv_mfma)
+    if (tid < 16 * MG) {
+        const int m = tid >> 2, n = blockIdx.x * 4 + (tid & 3);
+        if (m < a.M && n < a.N) {
+            if (a.bias) pre_b = a.bias[n];
+            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)m * a.ldr + n];
+        }
+    }
     f32x4_t acc[NW][MG];
     float ss[MG];
 #pragma unroll
@@ -236,18 +516,17 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     for (int g = 0; g < MG; ++g) ss[g] = 0.0f;
 
     for (int sb = s0; sb < s1; sb += G) {
+        // x / norm weight first, weight tiles second (see k_gemv_mfma): the split runs under the HBM latency
         u32x4_t wa[G], wb[G];
         float4 xa[G][MG], xb[G][MG], na[G], nb[G];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
-            wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-            if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
             const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
 #pragma unroll
             for (int g = 0; g < MG; ++g) {
-                xa[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko);
-                xb[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko + 4);
+                xa[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko) : float4{0.f, 0.f, 0.f, 0.f};     // unused columns: no request
+                xb[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (RMS) {
                 na[i] = *reinterpret_cast<const float4*>(nwp + ko);
@@ -256,28 +535,44 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const int s = sb + i;
-            if (s < s1) {
-                const bool kok = (s * 128 + kb * 8) < a.K;
-#pragma unroll
-                for (int g = 0; g < MG; ++g) {
-                    const bool valid = act[g] && kok;
-                    float xv[8] = {xa[i][g].x, xa[i][g].y, xa[i][g].z, xa[i][g].w, xb[i][g].x, xb[i][g].y, xb[i][g].z, xb[i][g].w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[e] = valid ? xv[e] : 0.0f;
-                    if constexpr (RMS) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ss[g] = fmaf(xv[e], xv[e], ss[g]);
-                        xv[0] *= na[i].x; xv[1] *= na[i].y; xv[2] *= na[i].z; xv[3] *= na[i].w;
-                        xv[4] *= nb[i].x; xv[5] *= nb[i].y; xv[6] *= nb[i].z; xv[7] *= nb[i].w;
-                    }
-                    const Split3 sp = split3(xv);
-                    acc[0][g] = mfma4_tile(wa[i], sp, acc[0][g]);
-                    if constexpr (NW == 2) acc[1][g] = mfma4_tile(wb[i], sp, acc[1][g]);
-                }
-            }
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+#if Q3_ABLATE == 4
+            wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; wb[i] = wa[i];
+#else
+            wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+            if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+#endif
         }
+        __builtin_amdgcn_sched_barrier(0);
+        Split3 sp[G][MG];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = sb + i;
+            const bool kok = s < s1 && (s * 128 + kb * 8) < a.K;     // ragged last group: zero operand, no branch
+#pragma unroll
+            for (int g = 0; g < MG; ++g)
+                sp[i][g] = gemv_prep<RMS>(act[g] && kok, xa[i][g], xb[i][g], RMS ? na[i] : xa[i][g], RMS ? nb[i] : xb[i][g], ss[g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int g = 0; g < MG; ++g) {
+                acc[0][g] = mfma4_tile(wa[i], sp[i][g], acc[0][g]);
+                if constexpr (NW == 2) acc[1][g] = mfma4_tile(wb[i], sp[i][g], acc[1][g]);
+            }
     }
+#if Q3_ABLATE == 3
+    if (wave == 0 && lane < 4 && act[0]) {
+        float v = ss[0];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int g = 0; g < MG; ++g) v += acc[w][g][0] + acc[w][g][1] + acc[w][g][2] + acc[w][g][3];
+        a.y[(size_t)lane * a.ldy + blockIdx.x * 4] = v;
+    }
+    return;
+#endif
     // sum the 16 k-blocks across lanes; lanes 0..3 (block 0) then hold D[i][j = lane] in acc[.][.][i]
 #pragma unroll
     for (int w = 0; w < NW; ++w)
@@ -312,8 +607,8 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
                 v = v / den;
                 if constexpr (NW == 2) v2 = v2 / den;
             }
-            if (a.bias) v = v + a.bias[n];
-            if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n] + v;
+            if (a.bias) v = v + pre_b;
+            if constexpr (EPI == EPI_RESID) v = pre_r + v;
             if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
             if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
             a.y[(size_t)m * a.ldy + n] = v;
@@ -327,9 +622,16 @@ static hipError_t launch_gemv4_t(const LinArgs& a, hipStream_t st) {
     const int S = a.Kpad >> 7;
     const int nwv = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 1));
     const int mg = (a.M + 3) / 4;
-    if (mg <= 1) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1>), dim3(tiles), dim3(nwv * 64), 0, st, a);
-    else if (mg == 2) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2>), dim3(tiles), dim3(nwv * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 4>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+    // groups of 3 k-steps when a wave's slice is a multiple of 3 (K = 3072: 24 steps over 8 waves), so that no
+    // group is ragged (a ragged group still pays its split + MFMAs on a zero operand)
+    const bool g3 = (S % nwv == 0) && ((S / nwv) % 3 == 0) && !RMS && EPI != EPI_SWIGLU;
+    if (mg <= 1) {
+        if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1, 3>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+        else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+    } else if (mg == 2) {
+        if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2, 3>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+        else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+    } else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 4>), dim3(tiles), dim3(nwv * 64), 0, st, a);
     return hipGetLastError();
 }
 

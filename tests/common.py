@@ -57,3 +57,59 @@ def top2_margin(logits):
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def write_checkpoint_dir(cfg, root, seed=synth.DEFAULT_SEED, with_config=True, model_type="custom_voice",
+                         f16_names=(), extra=True):
+    """Write a synthetic checkpoint in the reference's on-disk layout (lib.rs:180-262) with the independent
+    `safetensors` package: <root>/config.json, <root>/model.safetensors (bf16 talker + code predictor),
+    <root>/speech_tokenizer/model.safetensors (f32 decoder). Tensors named in `f16_names` are stored as F16
+    (values rounded to f16 first, so they survive exactly); `extra` adds tensors the hot path must skip."""
+    import json, os
+    import torch
+    from safetensors.torch import save_file
+    os.makedirs(os.path.join(root, "speech_tokenizer"), exist_ok=True)
+    h = manifest_handle(cfg)
+    main, dec, raw = {}, {}, {}
+    for name, arr, dt in synth.synthetic_checkpoint(cfg, h, seed):
+        if dt == synth.BF16:
+            t = torch.from_numpy(arr.view(np.int16).copy()).view(torch.bfloat16)
+            fan = synth._fan_in(cfg, name, arr.size)
+            if fan > 1 and arr.size % fan == 0:
+                t = t.reshape(arr.size // fan, fan)
+        else:
+            t = torch.from_numpy(arr.copy())
+        if name in f16_names:
+            t = t.float().half()
+            arr = t.float().numpy().reshape(-1)
+            dt = synth.F32
+        raw[name] = (arr, dt)
+        (dec if name.startswith("decoder.") else main)[name] = t
+    _lib.lib.q3_model_free(h)
+    if extra:
+        main["speaker_encoder.blocks.0.conv.weight"] = torch.zeros(4, 3, 5)
+        dec["encoder.downsample.conv.weight"] = torch.ones(2, 2, dtype=torch.float64)
+    save_file(main, os.path.join(root, "model.safetensors"), metadata={"format": "pt"})
+    save_file(dec, os.path.join(root, "speech_tokenizer", "model.safetensors"))
+    if with_config:
+        conf = {
+            "architectures": ["Qwen3TTSForConditionalGeneration"], "model_type": "qwen3_tts",
+            "tts_model_type": model_type, "tts_model_size": "1b7" if cfg.hidden == 2048 else "0b6",
+            "talker_config": {
+                "hidden_size": cfg.hidden, "intermediate_size": cfg.inter, "num_hidden_layers": cfg.n_layers,
+                "num_attention_heads": cfg.n_heads, "num_key_value_heads": cfg.n_kv_heads, "head_dim": cfg.head_dim,
+                "vocab_size": cfg.codec_vocab, "text_vocab_size": cfg.text_vocab, "text_hidden_size": cfg.text_dim,
+                "rms_norm_eps": 1e-06, "rope_theta": 1000000, "max_position_embeddings": 32768,
+                "rope_scaling": {"mrope_section": [24, 20, 20], "interleaved": True, "type": "default"},
+                "spk_id": {"ryan": 3061, "中文": 1}, "hidden_act": "silu", "use_cache": True,
+                "code_predictor_config": {
+                    "hidden_size": cfg.cp_hidden, "intermediate_size": cfg.cp_inter, "num_hidden_layers": cfg.cp_layers,
+                    "num_attention_heads": cfg.cp_heads, "num_key_value_heads": cfg.cp_kv_heads, "head_dim": cfg.head_dim,
+                    "vocab_size": cfg.cp_vocab, "num_code_groups": cfg.n_groups, "rms_norm_eps": 1e-06,
+                    "rope_theta": 1000000.0, "tie_word_embeddings": False, "sliding_window": None,
+                },
+            },
+        }
+        with open(os.path.join(root, "config.json"), "w") as f:
+            json.dump(conf, f, indent=2)
+    return raw

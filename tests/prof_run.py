@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: F401 — loads torch's bundled HIP runtime first: rocprofv3 + hipGraph segfaults with /opt/rocm's (ROCm 7.2)
 import qwen3_tts_rs_amd as q
 from common import synthetic_prompt
 
@@ -11,7 +12,7 @@ frames = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 graph = (sys.argv[4] != "eager") if len(sys.argv) > 4 else True
 cfg = {"1.7b": q.qwen3_tts_1_7b, "0.6b": q.qwen3_tts_0_6b, "tiny": q.tiny}[model]()
 m = q.Qwen3TTS.from_synthetic(cfg)
-utts = [q.Utterance(synthetic_prompt(512, i), seed=42 + i) for i in range(B)]
+utts = [q.Utterance(synthetic_prompt(int(os.environ.get("Q3_PROMPT", "512")), i), seed=42 + i) for i in range(B)]
 opts = q.SynthesisOptions(max_length=frames, eos_token_id=None, seed=42)
 s = m.session(utts, opts)
 t0 = time.time(); s.prefill(); t1 = time.time()

@@ -7,8 +7,10 @@ import os
 import numpy as np
 import pytest
 
+import ctypes
+
 import qwen3_tts_rs_amd as q
-from qwen3_tts_rs_amd import synth
+from qwen3_tts_rs_amd import synth, api, _lib
 import oracle as O
 from common import model_pair, synthetic_prompt, top2_margin, rel_err
 
@@ -346,3 +348,84 @@ def test_icl_voice_clone(pair, n_text, n_ref_text, n_ref):
     ref = full[cut:]
     assert pcm.shape == ref.shape and float(np.sqrt(np.mean((pcm - ref) ** 2))) <= 1e-3
     s.close(); osess.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["tiny", "tiny_same_width"])
+def test_from_pretrained_matches_from_tensors(tmp_path, variant):
+    """On-disk formats (lib.rs:180-262): a checkpoint directory written by the `safetensors` package (bf16 talker,
+    f32 decoder, two tensors stored F16, unrelated speaker_encoder.* / encoder.* tensors present) loaded by the C++
+    loader gives the same codes and PCM as the same tensors pushed through q3_model_set_tensor; then the WAV / dump
+    writers round-trip the result."""
+    from common import write_checkpoint_dir
+    base = getattr(q, variant)()
+    f16 = ("talker.model.norm.weight", "decoder.pre_conv.conv.bias")
+    raw = write_checkpoint_dir(base, str(tmp_path), f16_names=f16)
+    # config.json carries no decoder shapes (Decoder12HzConfig::default in the reference, lib.rs:345) and the tiny
+    # decoder is smaller than that, so load file by file into a handle built for the tiny config; the directory-level
+    # entry point is exercised by test_from_pretrained_directory below
+    m = q.Qwen3TTS(base, 0)
+    n = ctypes.c_int()
+    _lib.check(_lib.lib.q3_model_load_safetensors(m._h, str(tmp_path / "model.safetensors").encode(), ctypes.byref(n)))
+    n_main = n.value
+    _lib.check(_lib.lib.q3_model_load_safetensors(m._h, str(tmp_path / "speech_tokenizer" / "model.safetensors").encode(), ctypes.byref(n)))
+    assert n_main + n.value == len(raw)
+    m.finalize()
+    ref = q.Qwen3TTS.from_tensors(base, raw, 0)
+    opts = q.SynthesisOptions(max_length=12, seed=9, eos_token_id=None)
+    utt = q.Utterance(synthetic_prompt(7, 1), seed=9)
+    outs = []
+    for mm in (m, ref):
+        s = mm.session([utt], opts); s.prefill(); s.generate(12)
+        outs.append((s.codes(0).copy(), s.decode(0).copy())); s.close()
+    assert (outs[0][0] == outs[1][0]).all() and outs[0][0].shape == (12, 16)
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    api.save_codes_binary(str(tmp_path / "codes.bin"), outs[0][0])
+    np.testing.assert_array_equal(api.load_codes_binary(str(tmp_path / "codes.bin")), outs[0][0])
+    q.AudioBuffer(outs[0][1], 24000).save(str(tmp_path / "o.wav"))
+    back = api.load_wav(str(tmp_path / "o.wav"))
+    assert len(back) == 12 * 1920
+    np.testing.assert_array_equal(back.samples, api.pcm16(outs[0][1]).astype(np.float32) / np.float32(32768.0))
+    m.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_from_pretrained_directory(tmp_path):
+    """q3_model_load end to end: tiny talker / code predictor shapes from config.json + the full-size 12 Hz decoder
+    (its shapes are compiled-in defaults, as in the reference)."""
+    from common import write_checkpoint_dir
+    t = q.tiny()
+    cfg = q.Q3Config(text_dim=t.text_dim, hidden=t.hidden, inter=t.inter, n_layers=t.n_layers, n_heads=t.n_heads,
+                     n_kv_heads=t.n_kv_heads, cp_hidden=t.cp_hidden, cp_inter=t.cp_inter, cp_layers=t.cp_layers,
+                     cp_heads=t.cp_heads, cp_kv_heads=t.cp_kv_heads, name="tiny-lm-full-decoder")
+    raw = write_checkpoint_dir(cfg, str(tmp_path), model_type="voice_design")
+    m = q.Qwen3TTS.from_pretrained(str(tmp_path), 0)
+    assert m.model_type == api.ModelType.VoiceDesign and not m.supports_preset_speakers() and m.supports_voice_design()
+    assert bytes(m.config.to_c()) == bytes(cfg.to_c())
+    ref = q.Qwen3TTS.from_tensors(cfg, raw, 0)
+    opts = q.SynthesisOptions(max_length=4, seed=2, eos_token_id=None)
+    utt = q.Utterance(synthetic_prompt(5, 2), seed=2)
+    outs = []
+    for mm in (m, ref):
+        s = mm.session([utt], opts); s.prefill(); s.generate(4)
+        outs.append((s.codes(0).copy(), s.decode(0).copy())); s.close()
+    assert (outs[0][0] == outs[1][0]).all()
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    m.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_model_load_reports_missing_weight(tmp_path):
+    """finalize's "Missing weight: <name>" (decoder_12hz.rs:176-181) surfaces through q3_model_load."""
+    import torch
+    from safetensors.torch import save_file
+    (tmp_path / "speech_tokenizer").mkdir()
+    save_file({"talker.model.norm.weight": torch.ones(1024)}, str(tmp_path / "model.safetensors"))
+    save_file({"decoder.x": torch.ones(1)}, str(tmp_path / "speech_tokenizer" / "model.safetensors"))
+    with pytest.raises(_lib.Q3Error, match="Missing weight"):
+        q.Qwen3TTS.from_pretrained(str(tmp_path), 0)
+    # wrong element count → shape error naming the tensor
+    save_file({"talker.model.norm.weight": torch.ones(1000)}, str(tmp_path / "model.safetensors"))
+    (tmp_path / "config.json").write_text("{}")
+    with pytest.raises(_lib.Q3Error, match="talker.model.norm.weight has 1000 elements, expected 1024"):
+        q.Qwen3TTS.from_pretrained(str(tmp_path), 0)
