@@ -682,19 +682,30 @@ struct DevPool {
 // ------------------------------------------------------------------------------------------------
 // codec decoder pipeline
 // ------------------------------------------------------------------------------------------------
+// Left context (frames) the convolutional stack needs for its output to be independent of where it was started:
+// propagating the causal receptive field back from the PCM (final k7: 6 samples; per block 6*(1+3+9) = 78 samples
+// of residual units + 1 input sample of the 2-tap polyphase transposed conv; decoder.0 k7; two ConvNeXt dwconv7
+// + 1-tap transposed convs) gives 29 @640/frame -> 28 @160 -> 23 @32 -> 14 @4 -> 20 -> 26 @4 -> 13 @2 -> 19 -> 10 frames.
+constexpr int CODEC_CTX_FRAMES = 12;
+
 struct CodecWS {
-    int cap_frames = 0;
+    int cap_frames = 0;        // frames the convolutional stack can take in one call
+    int cap_front = 0;         // frames the quantiser / pre-transformer front can take (>= cap_frames)
     float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufF = nullptr, *bufD = nullptr, *bufE = nullptr;
     float *cs = nullptr, *sn = nullptr;
     uint32_t* frames = nullptr; float* pcm = nullptr;
     void release() {
         hipFree(bufA); hipFree(bufB); hipFree(bufC); hipFree(bufF); hipFree(bufD); hipFree(bufE); hipFree(cs); hipFree(sn); hipFree(frames); hipFree(pcm);
-        bufA = bufB = bufC = bufF = bufD = bufE = cs = sn = pcm = nullptr; frames = nullptr; cap_frames = 0;
+        bufA = bufB = bufC = bufF = bufD = bufE = cs = sn = pcm = nullptr; frames = nullptr; cap_frames = 0; cap_front = 0;
     }
 };
 
-static q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T) {
-    if (T <= ws.cap_frames) return Q3_OK;
+// T = frames through the convolutional stack in one call, Tf = frames through the front (Tf >= T)
+static q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T, int Tf = 0) {
+    if (Tf < T) Tf = T;
+    if (T <= ws.cap_frames && Tf <= ws.cap_front) return Q3_OK;
+    if (T < ws.cap_frames) T = ws.cap_frames;
+    if (Tf < ws.cap_front) Tf = ws.cap_front;
     ws.release();
     const q3_config& c = m->cfg;
     int up = 1; for (int i = 0; i < 2; ++i) up *= c.dec_up_ratios[i];
@@ -702,24 +713,32 @@ static q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T) {
     size_t per = (size_t)4 * c.dec_latent * up;                 // ConvNeXt hidden 4*LAT × (T*up)
     { size_t L = up; int C = c.dec_dim; per = per > (size_t)C * L ? per : (size_t)C * L;
       for (int b = 0; b < 4; ++b) { L *= c.dec_up_rates[b]; C /= 2; if ((size_t)C * L > per) per = (size_t)C * L; } }
-    const size_t n = per * (size_t)T;
+    const int QDm = c.dec_heads * c.dec_head_dim;
+    // front: A holds q|k|v|attn-out (4*QD rows), B gate|up (2*DI) or the quantiser output, C the latent — per front frame
+    size_t per_front = (size_t)4 * QDm;
+    if ((size_t)2 * c.dec_inter > per_front) per_front = (size_t)2 * c.dec_inter;
+    if ((size_t)2 * c.dec_cb_dim > per_front) per_front = (size_t)2 * c.dec_cb_dim;
+    if ((size_t)c.dec_latent > per_front) per_front = (size_t)c.dec_latent;
+    if ((size_t)c.dec_q_dim > per_front) per_front = (size_t)c.dec_q_dim;
+    size_t n = per * (size_t)T;
+    if (per_front * (size_t)Tf > n) n = per_front * (size_t)Tf;
     HIPC(hipMalloc((void**)&ws.bufA, n * 4)); HIPC(hipMalloc((void**)&ws.bufB, n * 4)); HIPC(hipMalloc((void**)&ws.bufC, n * 4));
     HIPC(hipMalloc((void**)&ws.bufF, n * 4));
-    const size_t small = (size_t)T * (size_t)(c.dec_heads * c.dec_head_dim > c.dec_latent ? c.dec_heads * c.dec_head_dim : c.dec_latent);
+    const size_t small = (size_t)Tf * (size_t)(QDm > c.dec_latent ? QDm : c.dec_latent);
     HIPC(hipMalloc((void**)&ws.bufD, small * 4)); HIPC(hipMalloc((void**)&ws.bufE, small * 4));
-    HIPC(hipMalloc((void**)&ws.cs, (size_t)T * 32 * 4)); HIPC(hipMalloc((void**)&ws.sn, (size_t)T * 32 * 4));
-    HIPC(hipMalloc((void**)&ws.frames, (size_t)T * 16 * 4));
+    HIPC(hipMalloc((void**)&ws.cs, (size_t)Tf * 32 * 4)); HIPC(hipMalloc((void**)&ws.sn, (size_t)Tf * 32 * 4));
+    HIPC(hipMalloc((void**)&ws.frames, (size_t)Tf * 16 * 4));
     size_t total_up = up; for (int b = 0; b < 4; ++b) total_up *= c.dec_up_rates[b];
     HIPC(hipMalloc((void**)&ws.pcm, (size_t)T * total_up * 4));
     // RoPE table of the pre-transformer (decoder_12hz.rs:541-553), host libm
-    std::vector<float> cs((size_t)T * 32), sn((size_t)T * 32);
+    std::vector<float> cs((size_t)Tf * 32), sn((size_t)Tf * 32);
     for (int i = 0; i < 32; ++i) {
         const float inv = 1.0f / powf(c.dec_theta, (float)(2 * i) / (float)c.dec_head_dim);
-        for (int t = 0; t < T; ++t) { const float f = (float)t * inv; cs[(size_t)t * 32 + i] = cosf(f); sn[(size_t)t * 32 + i] = sinf(f); }
+        for (int t = 0; t < Tf; ++t) { const float f = (float)t * inv; cs[(size_t)t * 32 + i] = cosf(f); sn[(size_t)t * 32 + i] = sinf(f); }
     }
     HIPC(hipMemcpy(ws.cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(ws.sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
-    ws.cap_frames = T;
+    ws.cap_frames = T; ws.cap_front = Tf;
     return Q3_OK;
 }
 
@@ -742,8 +761,12 @@ static hipError_t convk(const float* x, const float* w, const float* b, float* y
     return launch_conv1d(a, st);
 }
 
-// frames already on device in ws.frames; result in ws.pcm ([T*spf]). taps: host pointers or nullptr.
-static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStream_t st, float** taps) {
+// frames already on device in ws.frames; result in ws.pcm. taps: host pointers or nullptr.
+// c0 = 0: whole-utterance decode, ws.pcm = [T*spf]. c0 > 0 (segment decode): the front (quantiser, pre_conv,
+// pre-transformer: everything with unbounded left context, and cheap) runs over all T frames, the convolutional
+// stack only over frames [c0, T), and ws.pcm = [(T-c0)*spf]; samples of frames >= c0 + CODEC_CTX_FRAMES are
+// identical to the whole-utterance decode (every kernel sums each output in a position-independent order).
+static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStream_t st, float** taps, int c0 = 0) {
     const q3_config& c = m->cfg;
     const int CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden, QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
     auto TAP = [&](int id, const float* dev, size_t n) -> q3_status {
@@ -785,9 +808,13 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
     HIPC(launch_rmsnorm_c(Hd, m->dec_norm, Nn, DH, T, c.dec_eps, st));
     HIPC(conv1(Nn, m->outp_w, m->outp_b, C, DH, LAT, T, st));      // C [LAT][T]
     Q3C(TAP(Q3_DEC_PRETRANS, C, (size_t)LAT * T));
-    // D4 upsample stages: cur in C
+    // D4 upsample stages: cur in C (segment decode: the latent columns [c0, T) copied out to F)
     float* cur = C; float* o1 = A; float* o2 = B;
     int L = T;
+    if (c0 > 0) {
+        HIPC(launch_copy_rows(C + c0, T, ws.bufF, T - c0, LAT, T - c0, st));
+        cur = ws.bufF; L = T - c0;
+    }
     for (int i = 0; i < 2; ++i) {
         const UpW& U = m->up[i];
         float* upo = (cur == C) ? A : C;            // transconv output [LAT][L*r]
@@ -912,6 +939,9 @@ struct q3_session {
     bool prefilled = false; int frames_run = 0;
     hipGraphExec_t graph_exec = nullptr; hipGraph_t graph = nullptr;
     CodecWS cws;
+    // overlapped segment decode (q3_session_run): vocoder segments run on their own stream while the frame loop continues
+    hipStream_t dec_stream = nullptr; hipEvent_t dec_ev = nullptr;
+    CodecWS seg_ws; float* pcm_all = nullptr; size_t pcm_all_floats = 0;
     std::vector<uint32_t> codes_host; bool codes_host_valid = false;
     int stream_pos = 0;    // streaming: frames already decoded
     bool profile = false; ProfAcc prof_linear;
@@ -1159,7 +1189,12 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     s->max_seq = s->prefill_len + s->max_frames + 1;
     if (s->max_seq > m->rope_len) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds the RoPE table (%d)", s->max_seq, m->rope_len);
     { int ns = 256 / (batch * c.n_kv_heads); if (ns < 1) ns = 1; if (ns > MAX_SPLITS) ns = MAX_SPLITS; s->n_splits = ns; }
-    HIPC(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    {   // the frame loop is a chain of ~600 short dependent kernels per frame: give its queue the highest priority so
+        // that its workgroups are dispatched ahead of the vocoder segments running beside it (q3_session_run)
+        int least = 0, greatest = 0;
+        HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPC(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
+    }
     const int B = batch, H = c.hidden, CH = c.cp_hidden;
     auto alloc_lm = [&](LmBuf& b, const LmDims& d, int nsplit) -> hipError_t {
         const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM;
@@ -1215,7 +1250,10 @@ extern "C" void q3_session_free(q3_session* s) {
     if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
     if (s->graph) hipGraphDestroy(s->graph);
     for (auto& ev : s->prof_pool) hipEventDestroy(ev);
-    s->cws.release();
+    s->cws.release(); s->seg_ws.release();
+    if (s->pcm_all) hipFree(s->pcm_all);
+    if (s->dec_ev) hipEventDestroy(s->dec_ev);
+    if (s->dec_stream) hipStreamDestroy(s->dec_stream);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1505,6 +1543,24 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
     return Q3_OK;
 }
 
+// Enqueue (no host sync) the vocoder for frames [a, e) of sequence b on the decode stream; PCM lands in s->pcm_all.
+static q3_status seg_decode_enqueue(q3_session* s, int b, int a, int e) {
+    const int spf = samples_per_frame(s->m->cfg);
+    const int c0 = a > CODEC_CTX_FRAMES ? a - CODEC_CTX_FRAMES : 0;
+    HIPC(hipMemcpyAsync(s->seg_ws.frames, s->codes + (size_t)b * s->max_frames * 16, (size_t)e * 16 * 4, hipMemcpyDeviceToDevice, s->dec_stream));
+    Q3C(codec_decode_dev(s->m, s->seg_ws, e, s->dec_stream, nullptr, c0));
+    HIPC(hipMemcpyAsync(s->pcm_all + ((size_t)b * s->max_frames + a) * spf, s->seg_ws.pcm + (size_t)(a - c0) * spf,
+                        (size_t)(e - a) * spf * 4, hipMemcpyDeviceToDevice, s->dec_stream));
+    return Q3_OK;
+}
+
+// synthesize_with_timing for the whole batch. With Q3_DECODE_OVERLAP=1 (and no ICL sequence) the vocoder does not
+// wait for the last frame: every Q3_DECODE_SEG (default 128) generated frames a helper thread enqueues the segment's
+// decode (exact: CODEC_CTX_FRAMES of left context re-run, see codec_decode_dev) on a second stream beside the frame
+// loop. OFF by default: measured on MI355X (1.7B, 8 x 640 frames) the frame loop slows from 2785 to 3308 ms while the
+// decode tail only shrinks from 639 to 289 ms (3444 -> 3620 ms per step) — the frame loop's workgroups need a whole
+// CU's registers, so vocoder waves already resident on a CU block them, and neither stream priorities nor a CU mask
+// on the decode stream (32 / 64 / 96 / 128 CUs: 5624 / 3949 / 3757 / 3607 ms) recover it.
 extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_host, const size_t* cap, size_t* n_samples, q3_timing* timing) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     using clk = std::chrono::steady_clock;
@@ -1512,14 +1568,94 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
     const auto t0 = clk::now();
     Q3C(q3_session_prefill(s));
     const auto t1 = clk::now();
-    Q3C(q3_session_generate(s, s->max_frames, use_graph));
-    Q3C(refresh_codes(s));
+    static const int overlap_env = [] { const char* e = getenv("Q3_DECODE_OVERLAP"); return e ? atoi(e) : 0; }();
+    static const int seg_env = [] { const char* e = getenv("Q3_DECODE_SEG"); const int v = e ? atoi(e) : 128; return v < 16 ? 16 : v; }();
+    bool overlap = overlap_env != 0 && !s->debug && !s->profile && s->max_frames > seg_env;
+    for (auto& q : s->seq) if (q.icl) overlap = false;
+    const int spf = samples_per_frame(s->m->cfg);
+    if (!overlap) {
+        Q3C(q3_session_generate(s, s->max_frames, use_graph));
+        Q3C(refresh_codes(s));
+        const auto t2 = clk::now();
+        int total = 0;
+        for (int b = 0; b < s->B; ++b) {
+            size_t n = 0;
+            Q3C(q3_session_decode(s, b, 0, s->seq[b].n_frames, pcm_host ? pcm_host[b] : nullptr, cap ? cap[b] : 0, &n));
+            if (n_samples) n_samples[b] = n;
+            total += s->seq[b].n_frames;
+        }
+        const auto t3 = clk::now();
+        if (timing) { timing->prefill_ms = ms(t0, t1); timing->generation_ms = ms(t1, t2); timing->decode_ms = ms(t2, t3); timing->generation_frames = total; }
+        return Q3_OK;
+    }
+    HIPC(hipSetDevice(s->m->device));
+    if (!s->dec_stream) {
+        static const int cus = [] { const char* e = getenv("Q3_DECODE_CUS"); return e ? atoi(e) : 0; }();   // tuning aid
+        int least = 0, greatest = 0;
+        HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (cus > 0) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < cus && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+            HIPC(hipExtStreamCreateWithCUMask(&s->dec_stream, 8, mask));
+        } else {
+            HIPC(hipStreamCreateWithPriority(&s->dec_stream, hipStreamNonBlocking, least));
+        }
+    }
+    Q3C(codec_reserve(s->m, s->seg_ws, seg_env + CODEC_CTX_FRAMES, s->max_frames));
+    if (s->pcm_all_floats < (size_t)s->B * s->max_frames * spf) {
+        if (s->pcm_all) HIPC(hipFree(s->pcm_all));
+        s->pcm_all_floats = (size_t)s->B * s->max_frames * spf;
+        HIPC(hipMalloc((void**)&s->pcm_all, s->pcm_all_floats * 4));
+    }
+    std::vector<int> dec_pos((size_t)s->B, 0);
+    std::thread worker; q3_status wst = Q3_OK; std::string werr;
+    auto join = [&]() -> q3_status {
+        if (worker.joinable()) worker.join();
+        if (wst != Q3_OK) return set_err(wst, "%s", werr.c_str());
+        return Q3_OK;
+    };
+    struct Job { int b, a, e; };
+    auto dispatch = [&](bool final_pass) -> q3_status {
+        std::vector<Job> jobs;
+        for (int b = 0; b < s->B; ++b) {
+            const SeqInfo& q = s->seq[b];
+            const int e = (q.done || final_pass) ? q.n_frames : (q.n_frames < s->frames_run ? q.n_frames : s->frames_run);
+            if (e > dec_pos[(size_t)b] && (final_pass || q.done || e - dec_pos[(size_t)b] >= 16)) {
+                // keep every call within the workspace: at most seg_env new frames per job
+                for (int a = dec_pos[(size_t)b]; a < e; a += seg_env) jobs.push_back({b, a, a + seg_env < e ? a + seg_env : e});
+                dec_pos[(size_t)b] = e;
+            }
+        }
+        if (jobs.empty()) return Q3_OK;
+        Q3C(join());
+        worker = std::thread([s, jobs, &wst, &werr]() {
+            if (hipSetDevice(s->m->device) != hipSuccess) { wst = Q3_HIP_ERROR; werr = "hipSetDevice failed in the decode thread"; return; }
+            for (const Job& j : jobs) {
+                const q3_status st = seg_decode_enqueue(s, j.b, j.a, j.e);
+                if (st != Q3_OK) { wst = st; werr = q3_last_error(); return; }
+            }
+        });
+        return Q3_OK;
+    };
+    q3_status st = Q3_OK;
+    while (st == Q3_OK && s->frames_run < s->max_frames && !all_done(s)) {
+        st = q3_session_generate(s, seg_env, use_graph);
+        if (st == Q3_OK) st = refresh_codes(s);
+        if (st == Q3_OK && s->frames_run < s->max_frames && !all_done(s)) st = dispatch(false);
+    }
     const auto t2 = clk::now();
+    if (st == Q3_OK) st = dispatch(true);
+    { const q3_status js = join(); if (st == Q3_OK) st = js; }
+    if (st != Q3_OK) { hipStreamSynchronize(s->dec_stream); return st; }
+    HIPC(hipStreamSynchronize(s->dec_stream));
     int total = 0;
     for (int b = 0; b < s->B; ++b) {
-        size_t n = 0;
-        Q3C(q3_session_decode(s, b, 0, s->seq[b].n_frames, pcm_host ? pcm_host[b] : nullptr, cap ? cap[b] : 0, &n));
+        const size_t n = (size_t)s->seq[b].n_frames * spf;
         if (n_samples) n_samples[b] = n;
+        if (pcm_host && pcm_host[b] && n) {
+            if (!cap || cap[b] < n) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+            HIPC(hipMemcpy(pcm_host[b], s->pcm_all + (size_t)b * s->max_frames * spf, n * 4, hipMemcpyDeviceToHost));
+        }
         total += s->seq[b].n_frames;
     }
     const auto t3 = clk::now();

@@ -139,10 +139,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
             for (int i = 0; i < G; ++i) {
                 const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);      // clamp: duplicate load, masked below
                 const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;    // K tail (K % 32 != 0): clamp, masked below
-                // lanes of unused batch columns (m >= M) issue no request: at M = 8 that halves the L2 -> L1 x traffic,
-                // which is as large as the weight stream itself (x is f32 x M rows, a tile is bf16 x 16 rows)
-                xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                // lanes of unused batch columns (m >= M) issue no request — measured per variant: qkv 7.8 -> 7.4 us,
+                // code-predictor qkv 5.2 -> 4.6 us at M = 8, but the SwiGLU pair loses (13.7 -> 15.7 us) and stays unmasked
+                const bool ld = NW == 2 || act;
+                xa[i] = ld ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                xb[i] = ld ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (RMS) {
                     na[i] = *reinterpret_cast<const float4*>(nwp + ko);
                     nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
@@ -179,8 +180,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
                 wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
                 if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
                 const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;
-                // lanes of unused batch columns (m >= M) issue no request: at M = 8 that halves the L2 -> L1 x traffic,
-                // which is as large as the weight stream itself (x is f32 x M rows, a tile is bf16 x 16 rows)
+                // lanes of unused batch columns (m >= M) issue no request (down-proj at M = 8: 12.3 -> 11.5 us)
                 xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
                 xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (RMS) {
@@ -515,52 +515,87 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
 #pragma unroll
     for (int g = 0; g < MG; ++g) ss[g] = 0.0f;
 
+    // Non-RMS variants hoist the x loads and the split ahead of the weight wait (see k_gemv_mfma); the RMS variants
+    // (norm-weight loads on top: the M <= 2 gate/up, lm_head path) keep the interleaved per-step order — hoisting
+    // measured 15-40 % slower there (register pressure).
     for (int sb = s0; sb < s1; sb += G) {
-        // x / norm weight first, weight tiles second (see k_gemv_mfma): the split runs under the HBM latency
-        u32x4_t wa[G], wb[G];
-        float4 xa[G][MG], xb[G][MG], na[G], nb[G];
+        if constexpr (!RMS) {
+            // x / norm weight first, weight tiles second (see k_gemv_mfma): the split runs under the HBM latency
+            u32x4_t wa[G], wb[G];
+            float4 xa[G][MG], xb[G][MG], na[G], nb[G];
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
-            const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
+            for (int i = 0; i < G; ++i) {
+                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+                const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
 #pragma unroll
-            for (int g = 0; g < MG; ++g) {
-                xa[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko) : float4{0.f, 0.f, 0.f, 0.f};     // unused columns: no request
-                xb[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < MG; ++g) {
+                    xa[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko) : float4{0.f, 0.f, 0.f, 0.f};     // unused columns: no request
+                    xb[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                }
+                if constexpr (RMS) {
+                    na[i] = *reinterpret_cast<const float4*>(nwp + ko);
+                    nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
+                }
             }
-            if constexpr (RMS) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+#if Q3_ABLATE == 4
+                wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; wb[i] = wa[i];
+#else
+                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            Split3 sp[G][MG];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = sb + i;
+                const bool kok = s < s1 && (s * 128 + kb * 8) < a.K;     // ragged last group: zero operand, no branch
+#pragma unroll
+                for (int g = 0; g < MG; ++g)
+                    sp[i][g] = gemv_prep<RMS>(act[g] && kok, xa[i][g], xb[i][g], RMS ? na[i] : xa[i][g], RMS ? nb[i] : xb[i][g], ss[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int g = 0; g < MG; ++g) {
+                    acc[0][g] = mfma4_tile(wa[i], sp[i][g], acc[0][g]);
+                    if constexpr (NW == 2) acc[1][g] = mfma4_tile(wb[i], sp[i][g], acc[1][g]);
+                }
+        } else {
+            u32x4_t wa[G], wb[G];
+            float4 xa[G][MG], xb[G][MG], na[G], nb[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+                const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
+#pragma unroll
+                for (int g = 0; g < MG; ++g) {
+                    xa[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko);
+                    xb[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko + 4);
+                }
                 na[i] = *reinterpret_cast<const float4*>(nwp + ko);
                 nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
-#if Q3_ABLATE == 4
-            wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; wb[i] = wa[i];
-#else
-            wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-            if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
-#endif
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        Split3 sp[G][MG];
+            for (int i = 0; i < G; ++i) {
+                const int s = sb + i;
+                if (s < s1) {
+                    const bool kok = (s * 128 + kb * 8) < a.K;
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int s = sb + i;
-            const bool kok = s < s1 && (s * 128 + kb * 8) < a.K;     // ragged last group: zero operand, no branch
-#pragma unroll
-            for (int g = 0; g < MG; ++g)
-                sp[i][g] = gemv_prep<RMS>(act[g] && kok, xa[i][g], xb[i][g], RMS ? na[i] : xa[i][g], RMS ? nb[i] : xb[i][g], ss[g]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-#pragma unroll
-            for (int g = 0; g < MG; ++g) {
-                acc[0][g] = mfma4_tile(wa[i], sp[i][g], acc[0][g]);
-                if constexpr (NW == 2) acc[1][g] = mfma4_tile(wb[i], sp[i][g], acc[1][g]);
+                    for (int g = 0; g < MG; ++g) {
+                        const Split3 sp = gemv_prep<RMS>(act[g] && kok, xa[i][g], xb[i][g], na[i], nb[i], ss[g]);
+                        acc[0][g] = mfma4_tile(wa[i], sp, acc[0][g]);
+                        if constexpr (NW == 2) acc[1][g] = mfma4_tile(wb[i], sp, acc[1][g]);
+                    }
+                }
             }
+        }
     }
 #if Q3_ABLATE == 3
     if (wave == 0 && lane < 4 && act[0]) {

@@ -429,3 +429,34 @@ def test_model_load_reports_missing_weight(tmp_path):
     (tmp_path / "config.json").write_text("{}")
     with pytest.raises(_lib.Q3Error, match="talker.model.norm.weight has 1000 elements, expected 1024"):
         q.Qwen3TTS.from_pretrained(str(tmp_path), 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eos", [False, True])
+def test_run_overlapped_segment_decode_is_exact(pair, eos):
+    """With Q3_DECODE_OVERLAP=1 q3_session_run decodes 128-frame segments on a second stream while the frame loop
+    continues (12 frames of left context re-run per segment). The PCM must equal the whole-utterance decode of the
+    same codes bit for bit — with EOS off (all sequences 300 frames) and with sequences that end at different frames."""
+    cfg, gm, om = pair
+    assert os.environ.get("Q3_DECODE_OVERLAP") == "1"      # set in conftest.py before the library reads it
+    utts = [_utts("custom", 4 + i, index=i, hidden=cfg.hidden) for i in range(3)]
+    if eos:
+        opts = q.SynthesisOptions(max_length=300, temperature=1.3, top_k=0, top_p=1.0, seed=11, min_new_tokens=2)
+    else:
+        opts = q.SynthesisOptions(max_length=300, seed=11, eos_token_id=None)
+    s = gm.session(utts, opts)
+    audio, timing = s.run()
+    lens = [len(s.codes(b)) for b in range(3)]
+    assert timing.generation_frames == sum(lens)
+    if not eos:
+        assert lens == [300, 300, 300]
+    for b in range(3):
+        full = s.decode(b)                       # whole-utterance path (q3_session_decode)
+        assert audio[b].samples.shape == full.shape == (lens[b] * 1920,)
+        np.testing.assert_array_equal(audio[b].samples, full)
+    s.close()
+    # the oracle agrees on the first sequence (whole-utterance CPU decode)
+    s2 = gm.session([utts[0]], opts); s2.prefill(); s2.generate(300); c = s2.codes(0); s2.close()
+    if len(c):
+        ref = om.decode(c)
+        assert float(np.sqrt(np.mean((audio[0].samples - ref) ** 2))) <= 1e-3
