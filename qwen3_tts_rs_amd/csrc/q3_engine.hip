@@ -160,6 +160,9 @@ struct q3_model {
     // derived device buffers
     float *rope_cos = nullptr, *rope_sin = nullptr; int rope_len = 0;      // talker/CP (theta, hd 128)
     float* derived = nullptr;                                              // codebooks + snake tables
+    // bf16x3-packed copies of the vocoder's conv / linear weights (launch_pack_conv_w), keyed by the f32 pointer
+    std::unordered_map<const float*, const void*> wpk; void* wpk_arena = nullptr;
+    const void* pk(const float* w) const { auto it = wpk.find(w); return it == wpk.end() ? nullptr : it->second; }
     const float* first_cb = nullptr; const float** rest_cbs_dev = nullptr; // device array of 15 pointers
     const uint16_t** cp_embs_dev = nullptr;                                // device array of 15 pointers
     // resolved pointers
@@ -395,7 +398,7 @@ extern "C" void q3_model_free(q3_model* m) {
     if (!m) return;
     if (m->device < 0) { delete m; return; }
     hipSetDevice(m->device);
-    hipFree(m->arena); hipFree(m->rope_cos); hipFree(m->rope_sin); hipFree(m->derived);
+    hipFree(m->arena); hipFree(m->rope_cos); hipFree(m->rope_sin); hipFree(m->derived); hipFree(m->wpk_arena);
     hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev);
     delete m;
 }
@@ -658,6 +661,46 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
     }
     SNAKE("decoder.decoder.5.alpha", "decoder.decoder.5.beta", cin, m->fin_a, m->fin_ib);
     m->fin_w = P<float>(m, "decoder.decoder.6.conv.weight"); m->fin_b = P<float>(m, "decoder.decoder.6.conv.bias");
+    // bf16x3 copies of every vocoder conv / linear weight the matrix-core kernel can take (cout % 32 == 0, cin % 16 == 0):
+    // (pointer, cout, cin, taps, phases); transposed convs are already stored per phase [stride][cout][cin][taps]
+    {
+        struct PW { const float* w; int cout, cin, k, phases; };
+        std::vector<PW> list;
+        const int CDm = c.dec_cb_dim, Qm = c.dec_q_dim, LATm = c.dec_latent, DHm = c.dec_hidden, QDm = c.dec_heads * c.dec_head_dim, DIm = c.dec_inter;
+        list.push_back({m->first_proj, Qm, CDm, 1, 1}); list.push_back({m->rest_proj, Qm, CDm, 1, 1});
+        list.push_back({m->pre_w, LATm, Qm, 3, 1});
+        list.push_back({m->inp_w, DHm, LATm, 1, 1}); list.push_back({m->outp_w, LATm, DHm, 1, 1});
+        for (auto& L : m->dl) {
+            list.push_back({L.q, QDm, DHm, 1, 1}); list.push_back({L.k, QDm, DHm, 1, 1}); list.push_back({L.v, QDm, DHm, 1, 1});
+            list.push_back({L.o, DHm, QDm, 1, 1}); list.push_back({L.gate, DIm, DHm, 1, 1}); list.push_back({L.up, DIm, DHm, 1, 1});
+            list.push_back({L.down, DHm, DIm, 1, 1});
+        }
+        for (int i = 0; i < 2; ++i) {
+            list.push_back({m->up[i].tw, LATm, LATm, 1, m->up[i].ratio});
+            list.push_back({m->up[i].p1w, 4 * LATm, LATm, 1, 1}); list.push_back({m->up[i].p2w, LATm, 4 * LATm, 1, 1});
+        }
+        list.push_back({m->init_w, c.dec_dim, LATm, 7, 1});
+        for (int b = 0; b < 4; ++b) {
+            const DecBlockW& B = m->blk[b];
+            list.push_back({B.tw, B.cout, B.cin, 2, B.rate});
+            for (int u = 0; u < 3; ++u) { list.push_back({B.res[u].c1w, B.cout, B.cout, 7, 1}); list.push_back({B.res[u].c2w, B.cout, B.cout, 1, 1}); }
+        }
+        size_t total = 0;
+        for (auto& e : list) if (e.cout % 32 == 0 && e.cin % 16 == 0) total += packed_conv_w_bytes(e.cout, e.cin, e.k) * (size_t)e.phases;
+        m->wpk.clear();
+        if (total) {
+            if (!m->wpk_arena) HIPC(hipMalloc(&m->wpk_arena, total));
+            char* cur = (char*)m->wpk_arena;
+            for (auto& e : list) {
+                if (e.cout % 32 || e.cin % 16) continue;
+                const size_t per = packed_conv_w_bytes(e.cout, e.cin, e.k);
+                m->wpk[e.w] = cur;
+                for (int ph = 0; ph < e.phases; ++ph)
+                    HIPC(launch_pack_conv_w(e.w + (size_t)ph * e.cout * e.cin * e.k, cur + (size_t)ph * per, e.cout, e.cin, e.k, 0));
+                cur += per * (size_t)e.phases;
+            }
+        }
+    }
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     m->finalized = true;
@@ -747,17 +790,19 @@ static int samples_per_frame(const q3_config& c) {
     return u;
 }
 
+static thread_local const q3_model* tl_codec_model = nullptr;     // set by codec_decode_dev: packed-weight lookup of the helpers below
+static const void* packed_of(const float* w) { return tl_codec_model ? tl_codec_model->pk(w) : nullptr; }
 static hipError_t conv1(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L, hipStream_t st,
                         const float* resid = nullptr, const float* scale = nullptr, int act = 0,
                         const float* sa = nullptr, const float* sib = nullptr) {
     ConvArgs a; a.x = x; a.w = w; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = 1; a.dil = 1;
-    a.resid = resid; a.scale = scale; a.act = act; a.snake_a = sa; a.snake_b = sib;
+    a.resid = resid; a.scale = scale; a.act = act; a.snake_a = sa; a.snake_b = sib; a.wpk = packed_of(w);
     return launch_conv1d(a, st);
 }
 static hipError_t convk(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L, int k, int dil,
                         hipStream_t st, const float* sa = nullptr, const float* sib = nullptr, int act = 0) {
     ConvArgs a; a.x = x; a.w = w; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = k; a.dil = dil;
-    a.snake_a = sa; a.snake_b = sib; a.act = act;
+    a.snake_a = sa; a.snake_b = sib; a.act = act; a.wpk = packed_of(w);
     return launch_conv1d(a, st);
 }
 
@@ -768,6 +813,7 @@ static hipError_t convk(const float* x, const float* w, const float* b, float* y
 // identical to the whole-utterance decode (every kernel sums each output in a position-independent order).
 static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStream_t st, float** taps, int c0 = 0) {
     const q3_config& c = m->cfg;
+    tl_codec_model = m;
     const int CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden, QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
     auto TAP = [&](int id, const float* dev, size_t n) -> q3_status {
         if (taps && taps[id]) { HIPC(hipStreamSynchronize(st)); HIPC(hipMemcpy(taps[id], dev, n * 4, hipMemcpyDeviceToHost)); }
@@ -818,7 +864,7 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
     for (int i = 0; i < 2; ++i) {
         const UpW& U = m->up[i];
         float* upo = (cur == C) ? A : C;            // transconv output [LAT][L*r]
-        HIPC(launch_transconv1d_taps(cur, U.tw, U.tb, upo, LAT, LAT, L, U.ratio, 1, nullptr, nullptr, st));
+        HIPC(launch_transconv1d_taps(cur, U.tw, U.tb, upo, LAT, LAT, L, U.ratio, 1, nullptr, nullptr, st, nullptr, nullptr, nullptr, m->pk(U.tw)));
         L *= U.ratio;
         // dwconv → LN → pw1+GELU → pw2·gamma + residual (in place into upo)
         float* dw = (upo == A) ? C : A;             // [LAT][L]
@@ -843,7 +889,7 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
     // decoder.0 (k=7): raw only if tapped; activated with block 0's snake
     float* xact = other({cur});
     {
-        ConvArgs a; a.x = cur; a.w = m->init_w; a.b = m->init_b; a.cin = LAT; a.cout = Cc; a.L = L; a.k = 7; a.dil = 1;
+        ConvArgs a; a.x = cur; a.w = m->init_w; a.wpk = m->pk(m->init_w); a.b = m->init_b; a.cin = LAT; a.cout = Cc; a.L = L; a.k = 7; a.dil = 1;
         a.post_a = m->blk[0].a; a.post_ib = m->blk[0].ib;
         if (taps && taps[Q3_DEC_INIT]) { float* raw = other({cur, xact}); a.y = raw; a.y2 = xact; HIPC(launch_conv1d(a, st)); Q3C(TAP(Q3_DEC_INIT, raw, (size_t)Cc * L)); }
         else { a.y = xact; HIPC(launch_conv1d(a, st)); }
@@ -854,18 +900,18 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
         // transposed conv: raw Y (residual of unit 0) + YA = snake(act1 of unit 0)
         float* Y = other({xact});
         float* YA = other({xact, Y});
-        HIPC(launch_transconv1d_taps(xact, Bk.tw, Bk.tb, Y, Bk.cin, Bk.cout, L, Bk.rate, 2, nullptr, nullptr, st, Bk.res[0].a1, Bk.res[0].ib1, YA));
+        HIPC(launch_transconv1d_taps(xact, Bk.tw, Bk.tb, Y, Bk.cin, Bk.cout, L, Bk.rate, 2, nullptr, nullptr, st, Bk.res[0].a1, Bk.res[0].ib1, YA, m->pk(Bk.tw)));
         L *= Bk.rate; Cc = Bk.cout;
         float* T2 = other({Y, YA});
         for (int uu = 0; uu < 3; ++uu) {
             const ResUnitW& R = Bk.res[uu];
             {   // conv7 (dilated) on the activated input; output activated with act2
-                ConvArgs a; a.x = YA; a.w = R.c1w; a.b = R.c1b; a.y = T2; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 7; a.dil = dils[uu];
+                ConvArgs a; a.x = YA; a.w = R.c1w; a.wpk = m->pk(R.c1w); a.b = R.c1b; a.y = T2; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 7; a.dil = dils[uu];
                 a.post_a = R.a2; a.post_ib = R.ib2;
                 HIPC(launch_conv1d(a, st));
             }
             {   // conv1 + residual: raw → Y (in place), activated → YA for the next consumer
-                ConvArgs a; a.x = T2; a.w = R.c2w; a.b = R.c2b; a.y = Y; a.y2 = YA; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 1; a.dil = 1; a.resid = Y;
+                ConvArgs a; a.x = T2; a.w = R.c2w; a.wpk = m->pk(R.c2w); a.b = R.c2b; a.y = Y; a.y2 = YA; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 1; a.dil = 1; a.resid = Y;
                 if (uu < 2) { a.post_a = Bk.res[uu + 1].a1; a.post_ib = Bk.res[uu + 1].ib1; }
                 else if (b < 3) { a.post_a = m->blk[b + 1].a; a.post_ib = m->blk[b + 1].ib; }
                 else { a.post_a = m->fin_a; a.post_ib = m->fin_ib; }

@@ -14,10 +14,25 @@
 
 namespace q3 {
 
-__device__ __forceinline__ float snake_f(float x, float a, float ib) {
-    const float s = sinf(x * a);
-    return x + (s * s) * ib;
+// sin(x)^2 for SnakeBeta. libm-grade sinf costs ~200 lane-operations here (the vocoder evaluates it 1.8e9 times per
+// 640 frames: 10 of 50 ms); only the square is needed, so the quadrant sign drops out: k = rint(x/pi), r = x - k*pi by a
+// three-term Cody-Waite reduction (exact FMAs; k*PI_A exact for |k| < 2^13), r in [-pi/2, pi/2], odd Taylor polynomial
+// to r^11 (truncation 6e-8 at the end points). |x| >= 8192 falls back to sinf.
+__device__ __forceinline__ float sin_sq(float x) {
+    if (fabsf(x) >= 8192.0f) { const float s = sinf(x); return s * s; }
+    const float k = rintf(x * 0.31830988618379067154f);
+    float r = fmaf(-k, 3.140625f, x);
+    r = fmaf(-k, 9.67502593994140625e-4f, r);
+    r = fmaf(-k, 1.509957990978376432e-7f, r);
+    const float z = r * r;
+    float p = fmaf(z, -2.50521083854417188e-8f, 2.75573192239858907e-6f);
+    p = fmaf(z, p, -1.98412698412698413e-4f);
+    p = fmaf(z, p, 8.33333333333333333e-3f);
+    p = fmaf(z, p, -1.66666666666666667e-1f);
+    const float s = fmaf(r * z, p, r);
+    return s * s;
 }
+__device__ __forceinline__ float snake_f(float x, float a, float ib) { return __fadd_rn(x, __fmul_rn(sin_sq(x * a), ib)); }   // unfused, as the reference
 
 // ------------------------------------------------------------------------------------------------
 // Generic causal conv1d:  y[co][t*ostride + ooff] = epi( b[co] + Σ_ci Σ_kk w[co][ci][kk] · f(x[ci][t-(k-1-kk)·dil]) )
@@ -37,6 +52,8 @@ struct ConvDev {
     int ooff_phase;               // output offset added per blockIdx.z
     const float* post_a; const float* post_ib;   // SnakeBeta applied to the OUTPUT (the consumer's activation)
     float* y2;                    // if set: y gets the raw value, y2 the activated one; else y gets the activated value
+    const void* wpk;              // bf16x3-packed weights (launch_pack_conv_w) or nullptr
+    size_t wpk_phase_stride;      // 16-byte units per blockIdx.z
 };
 
 __global__ __launch_bounds__(256) void k_conv1d(ConvDev a) {
@@ -232,6 +249,228 @@ static hipError_t launch_conv_mfma(const ConvDev& a, int phases, hipStream_t st)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third generation: implicit GEMM on the bf16 matrix cores at f32-equivalent accuracy ("bf16x3").
+// Weights AND activations are split exactly into three bf16 terms (w = wh + wm + wl, x = xh + xm + xl, 24 mantissa
+// bits each); a product w·x is formed by six v_mfma_f32_32x32x16_bf16 — hh, hm, mh, hl, lh, mm; the dropped
+// ml / lm / ll terms are below 2^-24 relative — with bf16·bf16 products exact in the f32 accumulator. Six bf16 MFMAs
+// cost 6/16 of one f32 MFMA per FLOP: 417 TF/s f32-equivalent peak against 157 TF/s of v_mfma_f32_32x32x2_f32.
+//   * weights: split once at model finalize (launch_pack_conv_w) into MFMA A-operand tiles, order
+//     [co/32][kk][ci/16][plane][lane]: slot `lane` (row i = lane%32, k-group = lane/32) = 8 bf16 of
+//     W[co0+i][ci0 + 8·(lane/32) .. +8][kk] — one coalesced 16-B load per lane per plane;
+//   * activations: split once per workgroup at LDS staging (SnakeBeta applied there too) into three planes laid out
+//     [t][32 ci] bf16 with an 80-byte row pitch, so the B operand of column t (8 consecutive ci) is one 16-byte
+//     aligned ds_read_b128 and a tap is just a row offset kk·dil;
+//   * reduction order per output: ci chunks of 16 ascending, taps ascending inside a 32-channel stage — fixed and
+//     independent of the output position (the segment-exact decode of the engine relies on that).
+// Workgroup = WCO x WT waves; wave tile = (32·CO_M) co x (32·T_M) t.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 cbf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int cu32x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 cbf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float cf32x2_t;
+constexpr int XP = 80;               // LDS bytes per time row per plane: 32 ci x 2 B + 16 pad
+
+__device__ __forceinline__ uint32_t cpk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32, RNE (builtin: see gemv file)
+    const cf32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, cbf16x2_t));
+}
+// exact 3-way split of a pair: returns packed (a | b << 16) per plane
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cpk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = cpk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = cpk_bf16(sa, sb);
+}
+
+// pack f32 conv weights [cout][cin][K] (one phase) into bf16x3 A-operand tiles; one thread per (tile, lane)
+__global__ __launch_bounds__(256) void k_pack_conv_w(const float* __restrict__ w, cu32x4_t* __restrict__ out, int cout, int cin, int K) {
+    const int nc16 = cin >> 4;
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;        // ((co32*K + kk)*nc16 + c16)*64 + lane
+    const size_t n_slots = (size_t)(cout >> 5) * K * nc16 * 64;
+    if (slot >= n_slots) return;
+    const int lane = (int)(slot & 63);
+    size_t tile = slot >> 6;
+    const int c16 = (int)(tile % nc16); tile /= nc16;
+    const int kk = (int)(tile % K); const int co32 = (int)(tile / K);
+    const int co = co32 * 32 + (lane & 31), ci = c16 * 16 + (lane >> 5) * 8;
+    cu32x4_t h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = w[((size_t)co * cin + ci + 2 * e) * K + kk], b = w[((size_t)co * cin + ci + 2 * e + 1) * K + kk];
+        uint32_t hh, mm, ll; split3_pair(a, b, hh, mm, ll);
+        h[e] = hh; m[e] = mm; l[e] = ll;
+    }
+    cu32x4_t* o = out + ((slot >> 6) * 3) * 64 + lane;
+    o[0] = h; o[64] = m; o[128] = l;
+}
+
+hipError_t launch_pack_conv_w(const float* w, void* out, int cout, int cin, int K, hipStream_t st) {
+    if (cout % 32 || cin % 16 || K < 1) return hipErrorInvalidValue;
+    const size_t n_slots = (size_t)(cout / 32) * K * (cin / 16) * 64;
+    hipLaunchKernelGGL(k_pack_conv_w, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, w, (cu32x4_t*)out, cout, cin, K);
+    return hipGetLastError();
+}
+size_t packed_conv_w_bytes(int cout, int cin, int K) { return (size_t)(cout / 32) * K * (cin / 16) * 3 * 1024; }
+
+__device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t (&B)[3], f32x16_t acc) {
+#define Q3_MF(ap, bp) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8_t, A[ap]), __builtin_bit_cast(cbf16x8_t, B[bp]), acc, 0, 0, 0)
+    Q3_MF(1, 1); Q3_MF(2, 0); Q3_MF(0, 2); Q3_MF(1, 0); Q3_MF(0, 1); Q3_MF(0, 0);     // small terms first
+#undef Q3_MF
+    return acc;
+}
+
+template <int K, int CO_M, int T_M, int WCO, int WT>
+__global__ __launch_bounds__(64 * WCO * WT, 3) void k_conv_bf16x3(ConvDev a) {     // 3 waves per SIMD: 2-3 workgroups per CU
+    constexpr int NT = 64 * WCO * WT;
+    constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [3 planes][W rows][XP bytes]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lk = lane >> 5;
+    const int wco = wave % WCO, wt = wave / WCO;
+    const int t0 = blockIdx.x * T_WG, co0 = blockIdx.y * CO_WG + wco * (32 * CO_M);
+    const int halo = (K - 1) * a.dil, W = T_WG + halo;
+    const size_t plane = (size_t)W * XP;
+    const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk) + (size_t)blockIdx.z * a.wpk_phase_stride;
+    const int ooff = a.ooff + (int)blockIdx.z * a.ooff_phase;
+    const int nc16 = a.cin >> 4;
+
+    f32x16_t acc[CO_M][T_M];
+#pragma unroll
+    for (int i = 0; i < CO_M; ++i)
+#pragma unroll
+        for (int j = 0; j < T_M; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto load_A = [&](cu32x4_t (&A)[CO_M][3], int ci0, int kk, int c16l) {
+#pragma unroll
+        for (int cm = 0; cm < CO_M; ++cm) {
+            const size_t tile = ((size_t)((co0 >> 5) + cm) * K + kk) * nc16 + (ci0 >> 4) + c16l;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) A[cm][pl] = wpk[(tile * 3 + pl) * 64 + lane];
+        }
+    };
+    for (int ci0 = 0; ci0 < a.cin; ci0 += 32) {
+        const int n16 = (a.cin - ci0) >= 32 ? 2 : 1;
+        // the first weight fragments of the stage do not depend on the staging: request them before the barrier
+        cu32x4_t A0[CO_M][3], A1[CO_M][3];
+        load_A(A0, ci0, 0, 0);
+        __syncthreads();
+        // stage [W rows][32 ci] of x. Work item = (time row, channel octet): consecutive threads take consecutive rows
+        // (coalesced global reads along t), 8 loads in flight, split, one 16-byte LDS store per plane.
+        for (int it = tid; it < W * 4; it += NT) {
+            const int q = it / W, tt = it - q * W;
+            const int t = t0 - halo + tt, ca = ci0 + q * 8;
+            float v[8];
+            if (t >= 0 && t < a.L && ca < a.cin) {             // cin % 8 == 0: the octet is all in or all out
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = a.x[(size_t)(ca + e) * a.L + t];
+                if (a.snake_a) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = snake_f(v[e], a.snake_a[ca + e], a.snake_ib[ca + e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            }
+            cu32x4_t h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; split3_pair(v[2 * e], v[2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+            unsigned char* row = smem + (size_t)tt * XP + q * 16;
+            *reinterpret_cast<cu32x4_t*>(row) = h;
+            *reinterpret_cast<cu32x4_t*>(row + plane) = m;
+            *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
+        }
+        __syncthreads();
+        // steps (kk, c16l) flattened; the weight fragments of step s+1 are requested before the MFMAs of step s
+        const int n_steps = K * n16;
+        auto do_step = [&](const cu32x4_t (&A)[CO_M][3], int s) {
+            const int kk = s / n16, c16l = s - kk * n16;
+            cu32x4_t B[T_M][3];
+#pragma unroll
+            for (int tm = 0; tm < T_M; ++tm) {
+                const unsigned char* bp = smem + (size_t)(wt * (32 * T_M) + tm * 32 + li + kk * a.dil) * XP + c16l * 32 + lk * 16;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) B[tm][pl] = *reinterpret_cast<const cu32x4_t*>(bp + pl * plane);
+            }
+#pragma unroll
+            for (int cm = 0; cm < CO_M; ++cm)
+#pragma unroll
+                for (int tm = 0; tm < T_M; ++tm) acc[cm][tm] = mfma6(A[cm], B[tm], acc[cm][tm]);
+        };
+        for (int s0 = 0; s0 < n_steps; s0 += 2) {
+            if (s0 + 1 < n_steps) { const int kk = (s0 + 1) / n16; load_A(A1, ci0, kk, (s0 + 1) - kk * n16); }
+            do_step(A0, s0);
+            if (s0 + 1 >= n_steps) break;
+            if (s0 + 2 < n_steps) { const int kk = (s0 + 2) / n16; load_A(A0, ci0, kk, (s0 + 2) - kk * n16); }
+            do_step(A1, s0 + 1);
+        }
+    }
+    // epilogue: lane (li, lk) holds column t = li of rows (reg&3) + 8*(reg>>2) + 4*lk; per-row operands are fetched once
+    // per row and reused by the T_M time tiles
+#pragma unroll
+    for (int cm = 0; cm < CO_M; ++cm) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int o = co0 + cm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            const bool ook = o < a.cout;
+            const float bias = (a.b && ook) ? a.b[o] : 0.0f;
+            const float sc = (a.scale && ook) ? a.scale[o] : 1.0f;
+            const float pa = (a.post_a && ook) ? a.post_a[o] : 0.0f, pib = (a.post_a && ook) ? a.post_ib[o] : 0.0f;
+#pragma unroll
+            for (int tm = 0; tm < T_M; ++tm) {
+                const int t = t0 + wt * (32 * T_M) + tm * 32 + li;
+                if (ook && t < a.L) {
+                    float v = acc[cm][tm][reg] + bias;
+                    if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (a.scale) v = v * sc;
+                    const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
+                    if (a.resid) v = a.resid[oi] + v;
+                    if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
+                    if (a.post_a) {
+                        const float va = snake_f(v, pa, pib);
+                        if (a.y2) { a.y[oi] = v; a.y2[oi] = va; } else a.y[oi] = va;
+                    } else {
+                        a.y[oi] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int K, int CO_M, int T_M, int WCO, int WT>
+static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
+    constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
+    const size_t lds = (size_t)3 * (T_WG + (K - 1) * a.dil) * XP;
+    dim3 grid((a.L + T_WG - 1) / T_WG, a.cout / CO_WG, phases);
+    hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, dim3(64 * WCO * WT), lds, st, a);
+    return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) {
+    const long big_tiles = (long)((a.L + 127) / 128) * (a.cout / 128) * phases;
+    if (a.cout % 128 == 0 && big_tiles >= 192) return launch_bf16x3_v<K, 2, 2, 2, 2>(a, phases, st);   // 128 co x 128 t
+    if (a.cout == 192) return launch_bf16x3_v<K, 2, 2, 3, 2>(a, phases, st);                            // 192 co x 128 t (x staged once)
+    if (a.cout == 96) return launch_bf16x3_v<K, 1, 2, 3, 2>(a, phases, st);                             //  96 co x 128 t
+    if (a.cout % 64 == 0) return launch_bf16x3_v<K, 1, 1, 2, 2>(a, phases, st);                         //  64 co x  64 t (small grids)
+    return hipErrorNotSupported;
+}
+// returns hipErrorNotSupported when the shape has no packed weights / unsupported geometry
+static hipError_t launch_conv_bf16x3(const ConvDev& a, int phases, hipStream_t st) {
+    static const bool off = getenv("Q3_CONV_F32") != nullptr;        // A/B aid: force the f32-MFMA generation
+    if (off || !a.wpk || a.cin % 16 || a.cout % 32) return hipErrorNotSupported;
+    switch (a.k) {
+        case 1: return launch_bf16x3_k<1>(a, phases, st);
+        case 2: return launch_bf16x3_k<2>(a, phases, st);
+        case 3: return launch_bf16x3_k<3>(a, phases, st);
+        case 7: return launch_bf16x3_k<7>(a, phases, st);
+        default: return hipErrorNotSupported;
+    }
+}
+
 // single-output-channel conv (final 96→1, k=7): one thread per time step
 __global__ __launch_bounds__(256) void k_conv_out1(ConvDev a) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -259,8 +498,11 @@ hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
     a.snake_a = c.snake_a; a.snake_ib = c.snake_b; a.resid = c.resid; a.scale = c.scale; a.act = c.act;
     a.ostride = 1; a.ooff = 0; a.oL = c.L; a.w_phase_stride = 0; a.ooff_phase = 0;
     a.post_a = c.post_a; a.post_ib = c.post_ib; a.y2 = c.y2;
+    a.wpk = c.wpk; a.wpk_phase_stride = 0;
     if (c.cout == 1) {
         hipLaunchKernelGGL(k_conv_out1, dim3((c.L + 255) / 256), dim3(256), 0, st, a);
+    } else if (hipError_t e = launch_conv_bf16x3(a, 1, st); e != hipErrorNotSupported) {
+        return e;
     } else if (hipError_t e = launch_conv_mfma(a, 1, st); e != hipErrorNotSupported) {
         return e;
     } else {
@@ -276,13 +518,15 @@ hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
 // t = j*stride + ph; the right-trim k - s of causal_trans_conv.rs:79 is implicit (length L*stride).
 hipError_t launch_transconv1d_taps(const float* x, const float* wp, const float* b, float* y, int cin, int cout, int L,
                                    int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st,
-                                   const float* post_a, const float* post_ib, float* y2) {
+                                   const float* post_a, const float* post_ib, float* y2, const void* wpk) {
     ConvDev a{};
+    a.wpk = wpk; a.wpk_phase_stride = packed_conv_w_bytes(cout, cin, taps) / 16;
     a.post_a = post_a; a.post_ib = post_ib; a.y2 = y2;
     a.x = x; a.w = wp; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = taps; a.dil = 1;
     a.snake_a = snake_a; a.snake_ib = snake_ib; a.resid = nullptr; a.scale = nullptr; a.act = 0;
     a.ostride = stride; a.ooff = 0; a.oL = L * stride;
     a.w_phase_stride = (size_t)cout * cin * taps; a.ooff_phase = 1;
+    if (hipError_t e = launch_conv_bf16x3(a, stride, st); e != hipErrorNotSupported) return e;
     if (hipError_t e = launch_conv_mfma(a, stride, st); e != hipErrorNotSupported) return e;
     dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO, stride);
     hipLaunchKernelGGL(k_conv1d, grid, dim3(256), 0, st, a);

@@ -460,3 +460,27 @@ def test_run_overlapped_segment_decode_is_exact(pair, eos):
     if len(c):
         ref = om.decode(c)
         assert float(np.sqrt(np.mean((audio[0].samples - ref) ** 2))) <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [3, 11])
+def test_full_size_decoder_stages(T):
+    """The production vocoder shapes (1024/1536/768/384/192/96 channels: the bf16x3 matrix-core conv kernel, all four
+    workgroup geometries, the polyphase transposed convs) against the oracle, stage by stage."""
+    t = q.tiny()
+    cfg = q.Q3Config(text_dim=t.text_dim, hidden=t.hidden, inter=t.inter, n_layers=t.n_layers, n_heads=t.n_heads,
+                     n_kv_heads=t.n_kv_heads, cp_hidden=t.cp_hidden, cp_inter=t.cp_inter, cp_layers=t.cp_layers,
+                     cp_heads=t.cp_heads, cp_kv_heads=t.cp_kv_heads, name="tiny-lm-full-decoder")
+    gm, om = model_pair(cfg, seed=synth.DEFAULT_SEED)
+    rng = np.random.default_rng(T)
+    codes = rng.integers(0, 2048, size=(T, 16)).astype(np.uint32)
+    opcm, otaps = om.decode(codes, taps=True)
+    taps = [np.zeros_like(x) for x in otaps]
+    pcm = gm.decode_codes(codes, taps=taps).samples
+    names = ["quant", "pre_conv", "pre_transformer", "up0", "up1", "init", "blk0", "blk1", "blk2", "blk3"]
+    for nme, a, b in zip(names, taps, otaps):
+        e = np.abs(a - b).max() / (np.abs(b).max() + 1e-9)
+        assert e <= 2e-4, (nme, e)
+    rms = float(np.sqrt(np.mean((pcm - opcm) ** 2)))
+    assert rms <= 1e-3, rms
+    gm.close(); om.close()
