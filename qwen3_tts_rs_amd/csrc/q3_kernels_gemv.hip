@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     // (the VALU-heavy part) of the whole group then runs under the weight latency and only the MFMAs wait for HBM.
     // 16-wave workgroups have 128 VGPRs per lane — not enough to hold a group's splits — and keep the interleaved
     // per-step order.
-    constexpr bool HOIST = NWAVES == 8;
+    constexpr bool HOIST = NWAVES <= 8;
     for (int sb = s0; sb < s1; sb += G) {
         u32x4_t wa[G], wb[G];
         float4 xa[G], xb[G], na[G], nb[G];
@@ -431,20 +431,24 @@ template <int EPI, bool RMS>
 static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     const int tiles = (a.N + 15) / 16;
     const int S = a.Kpad >> 5;
-    // 16 waves per tile when the tile count alone cannot fill the chip or the per-wave slice gets long
-    bool big = (tiles < 256 && S >= 32) || S >= 128;
+    // Kernel choice, from tests/bench_kernels.py on MI355X at M = 8 (profiles/r1_gemv_microbench_*.log; run-to-run noise
+    // is about +-0.5 us, so only consistent differences are encoded):
+    //   * K <= 1024 (a wave's slice is one 4-step group): 8 waves, register-direct, everything requested at kernel
+    //     start — code-predictor qkv 4.6, gate/up 5.4, lm_head 4.3 us (16 waves: 6.6 / 8.0 / 6.3; LDS-staged: 5.7 / 6.5 / 5.1);
+    //   * K = 2048 with fewer than 256 tiles (CUs idle, latency-bound): the LDS-staged generation, flat in M —
+    //     o-proj 5.9, codec head 6.2 us (register-direct 6.6 / 6.9);
+    //   * K = 2048 with >= 256 tiles: 8 waves register-direct — qkv 7.4, gate/up 13.7 us (LDS-staged 8.4 / 17.8);
+    //   * K >= 4096 (down-proj): 16 waves so that a wave's slice stays 12 steps — 11.5 us (8 waves 12.8, 4 waves 14.4).
+    // Q3_GEMV_WAVES = 4 / 8 / 16 forces a register-direct geometry, 1 forces the LDS-staged kernel (tuning aid).
+    bool big = S >= 96;
     static const int force = [] { const char* e = getenv("Q3_GEMV_WAVES"); return e ? atoi(e) : 0; }();   // tuning aid
-    // Kernel choice, from tests/bench_kernels.py on MI355X (profiles/r1_gemv_microbench_lds.log): the LDS-staged
-    // generation wins where the tile count leaves CUs idle (latency-bound launches: o-proj, codec head, code-predictor
-    // gate/up and lm_head: 6.6 -> 5.9, 6.9 -> 6.2, 7.6 -> 6.5, 6.4 -> 5.1 us at M = 8) and is flat in M; with >= 256
-    // tiles or a long K slice the register-direct kernels stream better (qkv 7.5 vs 8.4, gate/up 13.7 vs 17.8 us).
-    // Q3_GEMV_WAVES = 8 / 16 forces the register-direct kernels, 1 forces the LDS-staged one (tuning aid).
     const bool lds_ok = a.K % 4 == 0 && S >= 8;
-    if (lds_ok && (force == 1 || (force == 0 && tiles < 256 && S <= 64))) {
+    if (lds_ok && (force == 1 || (force == 0 && tiles < 256 && S > 32 && S <= 64))) {
         hipLaunchKernelGGL((k_gemv_lds<EPI, RMS>), dim3(tiles), dim3(512), 0, st, a);
         return hipGetLastError();
     }
     if (force == 8) big = false; else if (force == 16) big = true;
+    if (force == 4) { hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4>), dim3(tiles), dim3(4 * 64), 0, st, a); return hipGetLastError(); }
     if (big) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16>), dim3(tiles), dim3(16 * 64), 0, st, a);
     else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8>), dim3(tiles), dim3(8 * 64), 0, st, a);
     return hipGetLastError();

@@ -575,6 +575,10 @@ hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
 }
 
 // merge the split partials: out[b][h*128+d] = Σ_s A_s[d] e^{m_s-M} / Σ_s l_s e^{m_s-M}
+// A separate launch on purpose. Folding it into k_attn_fused as a "last split block to arrive merges" epilogue (release
+// fence + ticket atomic + acquire fence + agent-scope loads) was built and measured on MI355X: bit-identical output,
+// but the frame got 17 % SLOWER (1.7B, B = 8: 4.34 -> 5.07 ms) — device-scope fences write back / invalidate the XCD's
+// L2 under every later launch, while this kernel boundary costs 1.6 us.
 __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* rec = a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE;

@@ -21,8 +21,11 @@ busy = sum(e - s for s, e, *_ in seg)
 gaps = [seg[i + 1][0] - seg[i][1] for i in range(len(seg) - 1)]
 print(f"steady segment: {len(seg)} kernels, span {span/1e6:.2f} ms, busy {busy/1e6:.2f} ms ({100*busy/span:.1f}%), "
       f"mean gap {sum(gaps)/len(gaps)/1e3:.2f} us, median gap {sorted(gaps)[len(gaps)//2]/1e3:.2f} us")
+nsamp = sum(1 for r in seg if "k_sample" in r[2])
+if nsamp:
+    frames = nsamp          # one sampler launch per frame: the steady segment's true frame count
 if frames:
-    print(f"per frame: {len(seg)/frames:.1f} kernels, {span/frames/1e6:.3f} ms span, {busy/frames/1e6:.3f} ms busy")
+    print(f"per frame ({frames} frames in the segment): {len(seg)/frames:.1f} kernels, {span/frames/1e6:.3f} ms span, {busy/frames/1e6:.3f} ms busy")
 agg = collections.defaultdict(lambda: [0, 0, 0])
 for i, (s, e, name, g, w) in enumerate(seg):
     short = name.replace("void q3::", "").replace("q3::", "").split("(")[0]
