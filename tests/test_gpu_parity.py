@@ -484,3 +484,38 @@ def test_full_size_decoder_stages(T):
     rms = float(np.sqrt(np.mean((pcm - opcm) ** 2)))
     assert rms <= 1e-3, rms
     gm.close(); om.close()
+
+
+@pytest.mark.gpu
+def test_weight_arena_broadcast_plumbing(pair):
+    """The one data-parallel collective: the weight arena, wrapped without a copy as a torch tensor over
+    the library's device pointer, goes through a real RCCL broadcast (world size 1 here — the 8-GPU run is the driver's;
+    the 2-rank protocol itself is covered on gloo in test_dp_gloo.py) and the model still produces the same codes."""
+    import torch
+    import torch.distributed as dist
+    from qwen3_tts_rs_amd import dp
+    cfg, gm, om = pair
+    ptr, nbytes = gm.arena()
+    t = torch.as_tensor(dp._DevMem(ptr, nbytes), device="cuda:0")
+    assert t.data_ptr() == ptr and t.numel() == nbytes and t.dtype == torch.uint8
+    before = int(t[: 1 << 20].to(torch.int64).sum().item())
+    opts = q.SynthesisOptions(max_length=5, seed=3, eos_token_id=None)
+    utt = _utts("custom", 5)
+    s = gm.session([utt], opts); s.prefill(); s.generate(5); c0 = s.codes(0).copy(); s.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        for off in range(0, nbytes, 1 << 26):
+            dist.broadcast(t[off:off + (1 << 26)], src=0)
+        x = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize(0)
+        assert float(x.item()) == 1.5
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert int(t[: 1 << 20].to(torch.int64).sum().item()) == before
+    s = gm.session([utt], opts); s.prefill(); s.generate(5); c1 = s.codes(0).copy(); s.close()
+    assert (c0 == c1).all()
