@@ -184,6 +184,12 @@ q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_host, const s
  * up to chunk_frames frames, decodes them as an independent utterance; *done=1 with
  * *n_samples=0 when finished. */
 q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_t cap, size_t* n_samples, int* done);
+/* Chunk decode mode of q3_session_next_chunk. 0 (default) = each chunk decoded as an independent utterance, exactly
+ * as the reference does (lib.rs:1755-1758: audible seams, every chunk restarts from zero padding). 1 = continuous:
+ * the vocoder's front runs over all frames so far and its convolutional stack over the chunk plus 12 frames of left
+ * context, so the concatenated chunks are sample-identical to the non-streaming decode (SURVEY.md §8(f) rank 1,
+ * "improved overlap mode"). */
+q3_status q3_session_set_stream_mode(q3_session* s, int mode);
 
 /* ---------------- stage-level entry points (parity tests; the reference's
  * tests/reference_validation.rs stages) ---------------- */

@@ -291,8 +291,12 @@ class StreamingSession:
     """StreamingSession (lib.rs:1484-1782): iterate to receive AudioBuffer chunks of up to
     chunk_frames*1920 samples; each chunk is decoded as an independent utterance (lib.rs:1755-1758)."""
 
-    def __init__(self, model: "Qwen3TTS", utt: Utterance, options: SynthesisOptions):
+    def __init__(self, model: "Qwen3TTS", utt: Utterance, options: SynthesisOptions, continuous: bool = False):
+        """continuous=True: chunks are decoded with left context and concatenate to exactly the non-streaming audio
+        (q3_session_set_stream_mode 1); the default reproduces the reference's context-free chunk decode."""
         self._s = Session(model, [utt], options)
+        if continuous:
+            check(lib.q3_session_set_stream_mode(self._s._h, 1))
         self._done = False
         self._spf = model.config.samples_per_frame
         self._chunk = options.chunk_frames
@@ -452,8 +456,9 @@ class Qwen3TTS:
         finally:
             s.close()
 
-    def synthesize_streaming(self, text_ids, speaker: Speaker, language: Language, options=None) -> StreamingSession:
-        return StreamingSession(self, Utterance(text_ids, speaker, language), options or SynthesisOptions())
+    def synthesize_streaming(self, text_ids, speaker: Speaker, language: Language, options=None,
+                             continuous: bool = False) -> StreamingSession:
+        return StreamingSession(self, Utterance(text_ids, speaker, language), options or SynthesisOptions(), continuous)
 
     def decode_codes(self, codes: np.ndarray, taps=None) -> AudioBuffer:
         """decode_codes (lib.rs:881-890): codes [n][16] u32."""

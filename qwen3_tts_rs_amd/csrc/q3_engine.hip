@@ -990,6 +990,7 @@ struct q3_session {
     CodecWS seg_ws; float* pcm_all = nullptr; size_t pcm_all_floats = 0;
     std::vector<uint32_t> codes_host; bool codes_host_valid = false;
     int stream_pos = 0;    // streaming: frames already decoded
+    int stream_mode = 0;   // 0 = context-free chunk decode (reference behaviour), 1 = continuous (left context re-run: seamless)
     bool profile = false; ProfAcc prof_linear;
     bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
     bool no_chunk = getenv("Q3_NO_CHUNK") != nullptr;         // A/B aid: one position per prefill step, 16-pass code predictor
@@ -1709,6 +1710,12 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
     return Q3_OK;
 }
 
+extern "C" q3_status q3_session_set_stream_mode(q3_session* s, int mode) {
+    if (!s || (mode != 0 && mode != 1)) return set_err(Q3_INVALID_ARG, "q3_session_set_stream_mode: mode must be 0 (context-free) or 1 (continuous)");
+    s->stream_mode = mode;
+    return Q3_OK;
+}
+
 extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_t cap, size_t* n_samples, int* done) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     if (s->B != 1) return set_err(Q3_UNSUPPORTED, "streaming sessions are batch 1 (StreamingSession, lib.rs:1484)");
@@ -1725,7 +1732,23 @@ extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_
     int avail = q.n_frames - s->stream_pos;
     if (avail > chunk) avail = chunk;
     if (avail <= 0) { if (n_samples) *n_samples = 0; if (done) *done = 1; return Q3_OK; }
-    Q3C(q3_session_decode(s, 0, s->stream_pos, s->stream_pos + avail, pcm_host, cap, n_samples));
+    if (s->stream_mode == 1 && !q.icl) {
+        // continuous mode: the front runs over frames [0, end), the convolutional stack over [pos - CTX, end); the chunk's
+        // samples are identical to the same frames of a whole-utterance decode (codec_decode_dev)
+        const int spf = samples_per_frame(s->m->cfg), a0 = s->stream_pos, e = s->stream_pos + avail;
+        const int c0 = a0 > CODEC_CTX_FRAMES ? a0 - CODEC_CTX_FRAMES : 0;
+        if (n_samples) *n_samples = (size_t)avail * spf;
+        Q3C(codec_reserve(s->m, s->cws, chunk + CODEC_CTX_FRAMES, s->max_frames));
+        HIPC(hipMemcpyAsync(s->cws.frames, s->codes, (size_t)e * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
+        Q3C(codec_decode_dev(s->m, s->cws, e, s->stream, nullptr, c0));
+        HIPC(hipStreamSynchronize(s->stream));
+        if (pcm_host) {
+            if (cap < (size_t)avail * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+            HIPC(hipMemcpy(pcm_host, s->cws.pcm + (size_t)(a0 - c0) * spf, (size_t)avail * spf * 4, hipMemcpyDeviceToHost));
+        }
+    } else {
+        Q3C(q3_session_decode(s, 0, s->stream_pos, s->stream_pos + avail, pcm_host, cap, n_samples));
+    }
     s->stream_pos += avail;
     if (done) *done = (q.done && s->stream_pos >= q.n_frames) ? 1 : 0;
     return Q3_OK;
