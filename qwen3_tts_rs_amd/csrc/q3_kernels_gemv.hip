@@ -38,6 +38,12 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// weight-tile load policy: nontemporal (streamed once per launch) unless -DQ3_NO_NT (experiment: cacheable loads)
+#ifdef Q3_NO_NT
+#define Q3_WLOAD(p) (*(p))
+#else
+#define Q3_WLOAD(p) __builtin_nontemporal_load(p)
+#endif
 struct Split3 { u32x4_t hi, mid, lo; };
 
 // Development aid (never defined in product builds): -DQ3_ABLATE=n removes one ingredient of the GEMV kernels to
@@ -155,8 +161,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
 #if Q3_ABLATE == 4
                 wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; wb[i] = wa[i];
 #else
-                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+                wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);      // keep every load of the group issued before the first use
@@ -177,8 +183,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
-                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+                wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
                 const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;
                 // lanes of unused batch columns (m >= M) issue no request (down-proj at M = 8: 12.3 -> 11.5 us)
                 xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
@@ -301,8 +307,8 @@ __device__ __forceinline__ void wg_load(u32x4_t (&wa)[4], u32x4_t (&wb)[4], cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);     // ragged last group: duplicate load, never consumed
-        wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-        if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+        wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+        if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
     }
 }
 
@@ -547,8 +553,8 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
 #if Q3_ABLATE == 4
                 wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; wb[i] = wa[i];
 #else
-                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+                wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -575,8 +581,8 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
-                wa[i] = __builtin_nontemporal_load(wp + (size_t)s * 64);
-                if constexpr (NW == 2) wb[i] = __builtin_nontemporal_load(wp2 + (size_t)s * 64);
+                wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+                if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
                 const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
 #pragma unroll
                 for (int g = 0; g < MG; ++g) {
