@@ -1054,6 +1054,10 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     return Q3_OK;
 }
 
+static bool d_nh_ok(const q3_config& c) {     // GEMM prefill needs N % 64 == 0 for every projection and a 1- or 2-way GQA ratio
+    const int qkv = (c.n_heads + 2 * c.n_kv_heads) * HEAD_DIM, rep = c.n_heads / (c.n_kv_heads ? c.n_kv_heads : 1);
+    return qkv % 64 == 0 && c.hidden % 64 == 0 && c.inter % 64 == 0 && (rep == 1 || rep == 2);
+}
 static LmDims talker_dims(const q3_config& c) { return LmDims{c.hidden, c.inter, c.n_heads, c.n_kv_heads, c.n_layers, c.rms_eps}; }
 static LmDims cp_dims(const q3_config& c) { return LmDims{c.cp_hidden, c.cp_inter, c.cp_heads, c.cp_kv_heads, c.cp_layers, c.rms_eps}; }
 
@@ -1358,6 +1362,67 @@ static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, flo
     return st;
 }
 
+// run_prefill_layers (talker.rs:823-841) for long prompts: chunks of up to 128 positions per sequence go through every
+// layer as GEMMs over the decode path's tiled weight image + a query-blocked causal attention (q3_kernels_prefill.hip).
+// Leaves the KV cache filled for positions [0, S) and LASTH / LOGITS of the last position, like the chunked decode-step
+// schedule it replaces for S >= 48.
+static q3_status prefill_gemm(q3_session* s, int S) {
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    const LmDims d = talker_dims(c);
+    const int B = s->B, H = d.H, QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, I = d.I;
+    // positions per sequence per pass: about 2048 activation rows per GEMM launch (16 M-tiles x N/64 workgroups fill the
+    // chip; one 128-row tile per launch would leave 3/4 of the CUs idle), at least one 128-row tile per sequence
+    static const int rows_env = [] { const char* e = getenv("Q3_PREFILL_ROWS"); return e ? atoi(e) : 2048; }();
+    int C = rows_env / B; C = C < 128 ? 128 : (C / 128) * 128;
+    const int max_rows = B * (S < C ? S : C);
+    DevPool tmp;
+    float *X, *QKV, *Qb, *ATT, *SUM, *ACT, *DEN;
+    HIPC(tmp.alloc(&X, (size_t)max_rows * H)); HIPC(tmp.alloc(&QKV, (size_t)max_rows * (QD + 2 * KD)));
+    HIPC(tmp.alloc(&Qb, (size_t)max_rows * QD)); HIPC(tmp.alloc(&ATT, (size_t)max_rows * QD));
+    HIPC(tmp.alloc(&SUM, (size_t)max_rows * H)); HIPC(tmp.alloc(&ACT, (size_t)max_rows * I)); HIPC(tmp.alloc(&DEN, (size_t)max_rows));
+    auto kp = [](int K) { return (K + 31) / 32 * 32; };
+    int ch = 0;
+    for (int t0 = 0; t0 < S; t0 += C) {
+        ch = (S - t0) < C ? (S - t0) : C;
+        const int rows = B * ch;
+        for (int b = 0; b < B; ++b)
+            HIPC(launch_copy_rows(s->embeds + ((size_t)b * S + t0) * H, H, X + (size_t)b * ch * H, H, ch, H, s->stream));
+        for (int i = 0; i < d.layers; ++i) {
+            const LayerW& w = m->tl[i];
+            HIPC(launch_row_den(X, H, DEN, rows, H, d.eps, s->stream));
+            GemmArgs g; g.W = w.qkv.t1; g.x = X; g.ldx = H; g.norm_w = w.in_ln; g.den = DEN; g.y = QKV; g.ldy = QD + 2 * KD;
+            g.M = rows; g.N = QD + 2 * KD; g.K = H; g.Kpad = kp(H); g.epi = EPI_NONE;
+            HIPC(launch_lm_gemm(g, s->stream));
+            AttnArgs t{};
+            t.qkv = QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
+            t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = nullptr; t.pos_static = t0;
+            t.kcache = s->kcache + (size_t)i * s->kv_layer_stride; t.vcache = s->vcache + (size_t)i * s->kv_layer_stride;
+            t.max_seq = s->max_seq; t.qbuf = Qb; t.part = nullptr; t.out = ATT; t.ld_out = QD;
+            t.B = rows; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = 1; t.rows_per_seq = ch;
+            HIPC(launch_qknorm_rope_kv(t, s->stream));
+            HIPC(launch_attn_prefill(t, s->stream));
+            GemmArgs o; o.W = w.o.t1; o.x = ATT; o.ldx = QD; o.resid = X; o.ldr = H; o.y = SUM; o.ldy = H;
+            o.M = rows; o.N = H; o.K = QD; o.Kpad = kp(QD); o.epi = EPI_RESID;
+            HIPC(launch_lm_gemm(o, s->stream));
+            HIPC(launch_row_den(SUM, H, DEN, rows, H, d.eps, s->stream));
+            GemmArgs gu; gu.W = w.gate.t1; gu.W2 = w.up.t1; gu.x = SUM; gu.ldx = H; gu.norm_w = w.post_ln; gu.den = DEN; gu.y = ACT; gu.ldy = I;
+            gu.M = rows; gu.N = I; gu.K = H; gu.Kpad = kp(H); gu.epi = EPI_SWIGLU;
+            HIPC(launch_lm_gemm(gu, s->stream));
+            GemmArgs dn; dn.W = w.down.t1; dn.x = ACT; dn.ldx = I; dn.resid = SUM; dn.ldr = H; dn.y = X; dn.ldy = H;
+            dn.M = rows; dn.N = H; dn.K = I; dn.Kpad = kp(I); dn.epi = EPI_RESID;
+            HIPC(launch_lm_gemm(dn, s->stream));
+        }
+    }
+    // head on each sequence's last position (row b*ch + ch-1 of the last chunk): final norm -> LASTH, codec_head -> LOGITS
+    HIPC(launch_rmsnorm(X + (size_t)(ch - 1) * H, ch * H, m->norm, s->LASTH, H, B, H, c.rms_eps, s->stream));
+    LinArgs h;
+    h.N = c.codec_vocab; h.K = H; set_w(h, m->codec_head, B, h.N, h.K); h.x = s->LASTH; h.ldx = H; h.y = s->LOGITS; h.ldy = c.codec_vocab;
+    h.M = B; h.epi = EPI_NONE;
+    HIPC(run_linear(s, h));
+    HIPC(hipStreamSynchronize(s->stream));      // tmp buffers are freed on return
+    return Q3_OK;
+}
+
 extern "C" q3_status q3_session_prefill(q3_session* s) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     if (s->prefilled) return set_err(Q3_INVALID_ARG, "session already prefilled");
@@ -1442,7 +1507,12 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     //    and the GEMV kernels take up to 16 rows for the price of one, so each weight pass carries a CHUNK of
     //    16/B consecutive positions per sequence (q3_kernels.h AttnArgs::rows_per_seq). Bit-identical to the
     //    one-position-at-a-time schedule (rows are independent in the GEMV; attention sees the same K/V).
+    static const int gemm_min = [] { const char* e = getenv("Q3_PREFILL_GEMM_MIN"); return e ? atoi(e) : 48; }();   // 0 disables the GEMM path
+    const bool tiles_ok = (d_nh_ok(c));
     const int chunk = s->no_chunk ? 1 : (16 / B > 0 ? 16 / B : 1);
+    if (!s->no_chunk && !s->debug && gemm_min > 0 && S >= gemm_min && tiles_ok) {
+        Q3C(prefill_gemm(s, S));
+    } else
     for (int t0 = 0; t0 < S; t0 += chunk) {
         const int ch = (S - t0) < chunk ? (S - t0) : chunk;
         for (int b = 0; b < B; ++b)

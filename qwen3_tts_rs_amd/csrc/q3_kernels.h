@@ -31,6 +31,20 @@ hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st);   // MFMA bf16x3
 hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st);  // 4-row tiles on the 4x4x4 16-block MFMA (tiled == 2)
 hipError_t launch_linear_rowmajor(const LinArgs& a, hipStream_t st);   // first-generation VALU kernel
 
+// ---- long-prompt prefill (q3_kernels_prefill.hip): real GEMM over the same tiled weight image + query-blocked attention ----
+struct GemmArgs {
+    const uint16_t* W = nullptr; const uint16_t* W2 = nullptr;   // mode-1 tiled bf16 images ([N/16][Kpad/32][64 lanes][8])
+    const float* x = nullptr; int ldx = 0;                       // [M][ldx] f32
+    const float* norm_w = nullptr; const float* den = nullptr;   // fused input RMSNorm: x*norm_w, result / den[m] (launch_row_den)
+    const float* bias = nullptr;
+    const float* resid = nullptr; int ldr = 0;
+    float* y = nullptr; int ldy = 0;
+    int M = 0, N = 0, K = 0, Kpad = 0;
+    int epi = EPI_NONE;
+};
+hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st);
+hipError_t launch_row_den(const float* x, int ldx, float* den, int rows, int cols, float eps, hipStream_t st);
+
 // standalone analogue of kernels/fused_residual_rmsnorm.cu: (normed, sum) for [rows][cols]
 hipError_t launch_fused_residual_rmsnorm_f32(const float* x, const float* res, const float* w, float* normed,
                                              float* sum, int rows, int cols, float eps, hipStream_t st);
@@ -60,6 +74,8 @@ struct AttnArgs {
 hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st);
+// prefill: causal attention of rows_per_seq consecutive positions per sequence (B = total rows), after launch_qknorm_rope_kv
+hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st);
 // fused q/k-norm + RoPE + KV append + attention (+ final normalisation when n_splits == 1)
 hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st);
 

@@ -1,0 +1,458 @@
+// q3_kernels_prefill.hip — long-prompt prefill of the talker (run_prefill_layers,
+// talker.rs:823-841) as real GEMMs plus a query-blocked causal attention, for prompts of hundreds to thousands of
+// positions (VoiceDesign instruct text, ICL reference transcripts + frames: BASELINE config[4]).
+//
+// The decode path streams every weight matrix once per 16 activation rows; over a 4k-position prompt that is 256
+// weight passes and ~43k launches per sequence. Here a chunk of up to 128 positions per sequence goes through each
+// layer at once:
+//   * k_lm_gemm     y[m][n] = Σ_k x[m][k]·W[n][k] on v_mfma_f32_16x16x32_bf16 with the SAME pre-tiled bf16 weight image
+//                   the decode GEMV uses (no second copy of the model) and the same exact bf16x3 split of the f32
+//                   activations, done once per workgroup while staging x into LDS; workgroup tile 64 weight rows x
+//                   128 activation rows, so a weight tile is reused by 128 rows and a staged x tile by 64 weight rows;
+//   * k_attn_prefill  GQA causal attention for 8 consecutive query positions per workgroup: one K/V load serves
+//                   8 positions x 2 query heads (the decode kernel's per-position online softmax, unchanged
+//                   arithmetic), reading the K/V the preceding k_qknorm_rope_kv launch appended to the cache.
+// Same arithmetic contract as the decode path (bf16 weights, f32 activations / accumulation / KV); only summation
+// orders differ, so prefill logits agree with the oracle to the same ~1e-5 as the decode kernels.
+#include "q3_kernels.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+namespace q3 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float pf32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int pu32x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 pbf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float pf32x2_t;
+
+__device__ __forceinline__ uint32_t ppk_bf16(float lo, float hi) {
+    const pf32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pbf16x2_t));
+}
+__device__ __forceinline__ void psplit3_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = ppk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = ppk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = ppk_bf16(sa, sb);
+}
+__device__ __forceinline__ float pwave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float phalf_sum(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// den[m] = sqrt(mean(x[m][:]^2) + eps): the RMSNorm denominator of each activation row (one wave per row)
+__global__ __launch_bounds__(256) void k_row_den(const float* __restrict__ x, int ldx, float* __restrict__ den, int rows, int cols, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float ss = 0.0f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+    }
+    ss = pwave_sum(ss);
+    if (lane == 0) den[row] = sqrtf(ss / (float)cols + eps);
+}
+hipError_t launch_row_den(const float* x, int ldx, float* den, int rows, int cols, float eps, hipStream_t st) {
+    if (cols % 4 || ldx % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_row_den, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, den, rows, cols, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM. Workgroup = 4 waves, tile = 64 weight rows (4 MFMA row tiles) x 128 activation rows (8 column tiles of 16);
+// wave w owns column tiles 2w, 2w+1 and all 4 row tiles. Per stage of 64 k: x[128][64] f32 is staged as three bf16
+// planes [row][64 k] (144-byte pitch: the 16 rows of a ds_read_b128 phase land on distinct 4-bank groups); weight
+// tiles come straight from global memory (the 4 waves read the same 8 tiles: L1 hits).
+// ------------------------------------------------------------------------------------------------
+constexpr int GP = 144;      // LDS bytes per activation row per plane: 64 k x 2 B + 16 pad
+
+template <int EPI, bool RMS>
+__global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 128 * GP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int mj = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.x * 128, rt0 = blockIdx.y * 4;            // first activation row, first 16-row weight tile
+    const int S = a.Kpad >> 5;                                         // k-steps of 32 in the tiled image
+    const pu32x4_t* __restrict__ w1 = reinterpret_cast<const pu32x4_t*>(a.W);
+    const pu32x4_t* __restrict__ w2 = reinterpret_cast<const pu32x4_t*>(NW == 2 ? a.W2 : a.W);
+    constexpr size_t plane = (size_t)128 * GP;
+
+    pf32x4_t acc[NW][4][2];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[w][r][c] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // staging role: thread t handles activation row t/2, k half (t%2)*32 .. +32 of the 64-k stage
+    const int srow = tid >> 1, sk = (tid & 1) * 32;
+    const bool srow_ok = (m0 + srow) < a.M;
+    const float* __restrict__ xrow = a.x + (size_t)(srow_ok ? m0 + srow : 0) * a.ldx;
+
+    for (int k0 = 0; k0 < a.Kpad; k0 += 64) {
+        // weight tiles of this stage first (independent of the LDS traffic below)
+        pu32x4_t A[NW][4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int s = (k0 >> 5) + ks;
+                const size_t off = ((size_t)(rt0 + r) * S + (s < S ? s : S - 1)) * 64 + lane;
+                A[0][r][ks] = __builtin_nontemporal_load(w1 + off);
+                if constexpr (NW == 2) A[1][r][ks] = __builtin_nontemporal_load(w2 + off);
+            }
+        __syncthreads();
+        {
+            float v[32];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + sk + q * 4;
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (srow_ok && k < a.K) {                      // K % 4 == 0
+                    f = *reinterpret_cast<const float4*>(xrow + k);
+                    if constexpr (RMS) { const float4 n = *reinterpret_cast<const float4*>(a.norm_w + k); f.x *= n.x; f.y *= n.y; f.z *= n.z; f.w *= n.w; }
+                }
+                v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+            }
+            unsigned char* dst = smem + (size_t)srow * GP + sk * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                      // 8 floats -> one 16-byte store per plane
+                pu32x4_t h, m, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; psplit3_pair(v[8 * q + 2 * e], v[8 * q + 2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+                *reinterpret_cast<pu32x4_t*>(dst + q * 16) = h;
+                *reinterpret_cast<pu32x4_t*>(dst + plane + q * 16) = m;
+                *reinterpret_cast<pu32x4_t*>(dst + 2 * plane + q * 16) = l;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if ((k0 >> 5) + ks >= S) break;
+            pu32x4_t B[2][3];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned char* bp = smem + (size_t)(wave * 32 + c * 16 + mj) * GP + ks * 64 + kg * 16;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) B[c][pl] = *reinterpret_cast<const pu32x4_t*>(bp + pl * plane);
+            }
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const pbf16x8_t av = __builtin_bit_cast(pbf16x8_t, A[w][r][ks]);
+                        pf32x4_t t = acc[w][r][c];
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(pbf16x8_t, B[c][2]), t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(pbf16x8_t, B[c][1]), t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(pbf16x8_t, B[c][0]), t, 0, 0, 0);
+                        acc[w][r][c] = t;
+                    }
+        }
+    }
+    // epilogue: lane (mj, kg) holds activation row mj of the column tile and weight rows kg*4 .. +3 of the row tile
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int m = m0 + wave * 32 + c * 16 + mj;
+        if (m >= a.M) continue;
+        const float den = RMS ? a.den[m] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = (rt0 + r) * 16 + kg * 4;
+            if (n >= a.N) continue;                                // N % 4 == 0
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[0][r][c][e];
+                float v2 = NW == 2 ? acc[NW - 1][r][c][e] : 0.0f;
+                if constexpr (RMS) { v = v / den; if constexpr (NW == 2) v2 = v2 / den; }
+                if (a.bias) v = v + a.bias[n + e];
+                if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n + e] + v;
+                if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+                if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+                o[e] = v;
+            }
+            *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
+    if (a.Kpad % 32 || a.K % 4 || a.K > a.Kpad || a.ldx % 4 || a.ldy % 4 || a.N % 64 || a.M < 1 || !a.W) return hipErrorInvalidValue;
+    const bool rms = a.norm_w != nullptr;
+    if (rms && !a.den) return hipErrorInvalidValue;
+    dim3 grid((a.M + 127) / 128, a.N / 64);
+#define Q3_GEMM(E, R) hipLaunchKernelGGL((k_lm_gemm<E, R>), grid, dim3(256), 0, st, a)
+    switch (a.epi) {
+        case EPI_NONE: if (rms) Q3_GEMM(EPI_NONE, true); else Q3_GEMM(EPI_NONE, false); break;
+        case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM(EPI_RESID, false); break;
+        case EPI_SWIGLU: if (!rms || !a.W2) return hipErrorInvalidValue; Q3_GEMM(EPI_SWIGLU, true); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef Q3_GEMM
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Causal GQA attention for RQ consecutive query rows of one sequence per workgroup. grid (row blocks, nkv, sequences);
+// 256 threads = 8 groups of 32 lanes, a group owns one cached position at a time (float4 K/V loads, 512 B per
+// position) and applies it to every (query row, query head) of the block whose position is >= that key: the decode
+// kernel's online softmax per group, groups merged through LDS. q comes from qbuf (normed + roped by
+// k_qknorm_rope_kv, which also appended this chunk's K/V rows before this launch).
+// ------------------------------------------------------------------------------------------------
+template <int NREP, int RQ>
+__global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs a) {
+    constexpr int NQ = NREP * RQ;
+    constexpr int NH = NQ > 8 ? 8 : NQ;                       // (row, head) states merged per LDS round (32 KB)
+    __shared__ float sm_m[NH][8], sm_l[NH][8];
+    __shared__ __attribute__((aligned(16))) float sm_acc[NH][8][HEAD_DIM];
+    const int blk = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
+    const int tid = threadIdx.x, grp = tid >> 5, li = tid & 31;
+    const int rps = a.rows_per_seq;
+    const int i0 = blk * RQ;                                   // first row of the block inside the sequence's chunk
+    const int base_pos = a.pos_dev ? a.pos_dev[seq] : a.pos_static;
+    const int nrows = (rps - i0) < RQ ? (rps - i0) : RQ;
+    const int last_pos = base_pos + i0 + nrows - 1;
+    const float scale = 0.08838834764831845f;
+
+    float4 q[NQ];
+#pragma unroll
+    for (int i = 0; i < RQ; ++i)
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            const int row = seq * rps + i0 + (i < nrows ? i : 0);
+            q[i * NREP + r] = *reinterpret_cast<const float4*>(a.qbuf + ((size_t)row * a.nh + kvh * NREP + r) * HEAD_DIM + li * 4);
+        }
+    float m[NQ], l[NQ];
+    float4 acc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { m[j] = -INFINITY; l[j] = 0.0f; acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+    const size_t base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM + li * 4;
+    for (int p = grp; p <= last_pos; p += 8) {
+        const float4 kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
+        const float4 vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) {
+            if (i < nrows && p <= base_pos + i0 + i) {         // causal: key position <= query position
+#pragma unroll
+                for (int r = 0; r < NREP; ++r) {
+                    const int j = i * NREP + r;
+                    float s = q[j].x * kk.x + q[j].y * kk.y + q[j].z * kk.z + q[j].w * kk.w;
+                    s = phalf_sum(s) * scale;
+                    const float mn = fmaxf(m[j], s);
+                    const float corr = expf(m[j] - mn);
+                    const float pe = expf(s - mn);
+                    l[j] = l[j] * corr + pe;
+                    acc[j].x = acc[j].x * corr + pe * vv.x; acc[j].y = acc[j].y * corr + pe * vv.y;
+                    acc[j].z = acc[j].z * corr + pe * vv.z; acc[j].w = acc[j].w * corr + pe * vv.w;
+                    m[j] = mn;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h0 = 0; h0 < NQ; h0 += NH) {
+        if (h0) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < NH; ++jj) {
+            const int j = h0 + jj;
+            if (li == 0) { sm_m[jj][grp] = m[j]; sm_l[jj][grp] = l[j]; }
+            *reinterpret_cast<float4*>(&sm_acc[jj][grp][li * 4]) = acc[j];
+        }
+        __syncthreads();
+        for (int t = tid; t < NH * HEAD_DIM; t += 256) {
+            const int jj = t / HEAD_DIM, d = t % HEAD_DIM, j = h0 + jj, i = j / NREP, r = j % NREP;
+            if (i >= nrows) continue;
+            float M = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) M = fmaxf(M, sm_m[jj][g]);
+            float L = 0.0f, A = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float wgt = sm_m[jj][g] == -INFINITY ? 0.0f : expf(sm_m[jj][g] - M);
+                L += sm_l[jj][g] * wgt;
+                A += sm_acc[jj][g][d] * wgt;
+            }
+            const int row = seq * rps + i0 + i;
+            a.out[(size_t)row * a.ld_out + (kvh * NREP + r) * HEAD_DIM + d] = A / L;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same attention on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation), flash
+// style. Workgroup = 4 waves on one (sequence, kv head, block of 128/NREP query rows); wave w owns 32 query vectors
+// (head w % NREP, rows 32·(w / NREP) .. +32) and keeps Q (64 registers per lane), the 32x128 output accumulator and the
+// running (max, sum) of its rows; K/V tiles of 32 cached positions are staged once per workgroup in LDS and shared
+// by the 4 waves. Per tile: S = Q·Kᵀ (64 MFMAs; the head dimension is walked as d = 64·(lane/32) + step, the same
+// permutation on both operands, so every LDS read is a float4), scale, causal mask, online softmax in the accumulator
+// layout (row statistics by 5-step lane reductions), P through a wave-private LDS patch into A-operand layout,
+// O += P·V (64 MFMAs). The VALU version above needs ~2500 lane-operations per (query, head, key); this one 256 MFMA flops.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float pf32x16_t;
+constexpr int KVP = 132;     // LDS pitch (floats) of a staged K / V row: 128 + 4 → float4 reads of 16 rows hit distinct banks
+constexpr int PP = 36;       // pitch of the P patch rows
+
+__device__ __forceinline__ float prow_max(float v) {       // over the 32 lanes of a half-wave
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+template <int NREP>
+__global__ __launch_bounds__(256) void k_attn_prefill_mfma(AttnArgs a) {
+    constexpr int ROWS_WG = 128 / NREP;
+    __shared__ __attribute__((aligned(16))) float sK[32 * KVP];
+    __shared__ __attribute__((aligned(16))) float sV[32 * KVP];
+    __shared__ __attribute__((aligned(16))) float sP[4][32 * PP];
+    const int blk = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
+    const int rps = a.rows_per_seq;
+    const int base_pos = a.pos_dev ? a.pos_dev[seq] : a.pos_static;
+    const int head = kvh * NREP + (wave % NREP);
+    const int r0 = blk * ROWS_WG + (wave / NREP) * 32;         // first chunk row of this wave
+    const int wg_rows = (rps - blk * ROWS_WG) < ROWS_WG ? (rps - blk * ROWS_WG) : ROWS_WG;
+    const int wg_last_pos = base_pos + blk * ROWS_WG + wg_rows - 1;
+    const int n_tiles = wg_last_pos / 32 + 1;
+    const float scale = 0.08838834764831845f;
+
+    // Q: lane (i = li, lk) holds Q[i][64·lk + s], s = 0..63
+    float q[64];
+    {
+        const int i = r0 + li;
+        const bool ok = i < rps;
+        const float* src = a.qbuf + ((size_t)(seq * rps + (ok ? i : 0)) * a.nh + head) * HEAD_DIM + lk * 64;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 f = ok ? *reinterpret_cast<const float4*>(src + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+            q[4 * t] = f.x; q[4 * t + 1] = f.y; q[4 * t + 2] = f.z; q[4 * t + 3] = f.w;
+        }
+    }
+    pf32x16_t O[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[b][r] = 0.0f;
+    float mrow[16], lrow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.0f; }
+    const int my_first_pos = base_pos + r0, my_last_pos = base_pos + r0 + 31;   // (rows past the chunk end are discarded)
+
+    const size_t cache_base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    const int skey = tid >> 3, sc = (tid & 7) * 16;            // staging role: key row, 16-float column chunk
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();
+        {
+            const int p = tile * 32 + skey;
+            const bool ok = p <= wg_last_pos;
+            const float* kp = a.kcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
+            const float* vp = a.vcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 kf = ok ? *reinterpret_cast<const float4*>(kp + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 vf = ok ? *reinterpret_cast<const float4*>(vp + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&sK[skey * KVP + sc + 4 * t]) = kf;
+                *reinterpret_cast<float4*>(&sV[skey * KVP + sc + 4 * t]) = vf;
+            }
+        }
+        __syncthreads();
+        if (tile * 32 > my_last_pos) continue;                 // wave-uniform: every key of the tile is in this wave's future
+        // S = Q·Kᵀ: B operand lane (j = li, lk) = K[j][64·lk + s]
+        pf32x16_t S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+        const float* krow = &sK[li * KVP + lk * 64];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 kf = *reinterpret_cast<const float4*>(krow + 4 * t);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * t], kf.x, S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * t + 1], kf.y, S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * t + 2], kf.z, S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * t + 3], kf.w, S, 0, 0, 0);
+        }
+        // lane (key j = li, lk) holds S[row(r, lk)][j]; scale, causal mask, online softmax per row
+        const int keypos = tile * 32 + li;
+        const bool need_mask = tile * 32 + 31 > my_first_pos;
+        float* pw = &sP[wave][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            float sv = S[r] * scale;
+            if (need_mask && keypos > my_first_pos + i) sv = -INFINITY;
+            const float mx = prow_max(sv);
+            const float mn = fmaxf(mrow[r], mx);               // finite: key 0 is visible to every row
+            const float corr = expf(mrow[r] - mn);
+            const float pe = expf(sv - mn);
+            const float ps = phalf_sum(pe);
+            lrow[r] = lrow[r] * corr + ps;
+            mrow[r] = mn;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) O[b][r] *= corr;
+            pw[i * PP + li] = pe;
+        }
+        // O += P·V: A operand lane (i = li, lk) = P[i][16·lk + s]; B operand lane (d = li, lk) = V[16·lk + s][32·b + d]
+        // (LDS accesses of one wave are in order: the patch written above is complete when these reads issue)
+        float pa[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 f = *reinterpret_cast<const float4*>(pw + li * PP + lk * 16 + 4 * t);
+            pa[4 * t] = f.x; pa[4 * t + 1] = f.y; pa[4 * t + 2] = f.z; pa[4 * t + 3] = f.w;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float* vcol = &sV[(lk * 16) * KVP + b * 32 + li];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2)
+                O[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s2], vcol[s2 * KVP], O[b], 0, 0, 0);
+        }
+    }
+    // out[row][head·128 + 32·b + li] = O[b][r] / l_row
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int row = r0 + i;
+        if (row < rps) {
+            float* dst = a.out + (size_t)(seq * rps + row) * a.ld_out + head * HEAD_DIM + li;
+            const float inv = lrow[r];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dst[b * 32] = O[b][r] / inv;
+        }
+    }
+}
+
+hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st) {
+    const int nrep = a.nh / a.nkv;
+    const int rps = a.rows_per_seq;
+    if (rps < 1 || a.B % rps) return hipErrorInvalidValue;
+    static const bool valu = getenv("Q3_PREFILL_ATTN_VALU") != nullptr;      // A/B aid: the VALU kernel
+    if (!valu && (nrep == 1 || nrep == 2 || nrep == 4)) {
+        const int rows_wg = 128 / nrep;
+        dim3 grid((rps + rows_wg - 1) / rows_wg, a.nkv, a.B / rps);
+        if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_mfma<1>), grid, dim3(256), 0, st, a);
+        else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_mfma<2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_attn_prefill_mfma<4>), grid, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
+    constexpr int RQ = 8;
+    dim3 grid((rps + RQ - 1) / RQ, a.nkv, a.B / rps);
+    if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill<1, RQ>), grid, dim3(256), 0, st, a);
+    else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill<2, RQ>), grid, dim3(256), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace q3
