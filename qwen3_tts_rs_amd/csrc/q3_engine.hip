@@ -1346,6 +1346,17 @@ static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, flo
     HIPC(hipMalloc((void**)&e, (size_t)n * TD * 4)); HIPC(hipMalloc((void**)&h, (size_t)n * TD * 4));
     q3_status st = Q3_OK;
     hipError_t er = launch_gather_rows_bf16(m->text_emb, ids_dev, e, n, TD, s->stream);
+    if (er == hipSuccess && n >= 48 && TD % 64 == 0 && H % 64 == 0 && !s->no_chunk) {
+        // TextProjection (talker.rs:316-320) over all n token rows as two GEMMs instead of n/8 GEMV passes
+        GemmArgs g1; g1.W = m->fc1w.t1; g1.x = e; g1.ldx = TD; g1.bias = m->fc1b; g1.y = h; g1.ldy = TD;
+        g1.M = n; g1.N = TD; g1.K = TD; g1.Kpad = (TD + 31) / 32 * 32; g1.epi = EPI_SILU;
+        er = launch_lm_gemm(g1, s->stream);
+        if (er == hipSuccess) {
+            GemmArgs g2; g2.W = m->fc2w.t1; g2.x = h; g2.ldx = TD; g2.bias = m->fc2b; g2.y = out_rows; g2.ldy = H;
+            g2.M = n; g2.N = H; g2.K = TD; g2.Kpad = (TD + 31) / 32 * 32; g2.epi = EPI_NONE;
+            er = launch_lm_gemm(g2, s->stream);
+        }
+    } else
     for (int r0 = 0; r0 < n && er == hipSuccess; r0 += 8) {
         const int M = (n - r0) < 8 ? (n - r0) : 8;
         LinArgs a;

@@ -199,6 +199,7 @@ hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
     switch (a.epi) {
         case EPI_NONE: if (rms) Q3_GEMM(EPI_NONE, true); else Q3_GEMM(EPI_NONE, false); break;
         case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM(EPI_RESID, false); break;
+        case EPI_SILU: if (rms) return hipErrorInvalidValue; Q3_GEMM(EPI_SILU, false); break;
         case EPI_SWIGLU: if (!rms || !a.W2) return hipErrorInvalidValue; Q3_GEMM(EPI_SWIGLU, true); break;
         default: return hipErrorInvalidValue;
     }
