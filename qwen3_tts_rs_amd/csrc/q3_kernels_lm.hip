@@ -511,8 +511,9 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
     const size_t base = cache_base + li * 4;
-    for (int p = start + grp; p < end; p += 8) {
-        float4 kk, vv;
+    // the K/V rows of the NEXT position of this group are requested before the current one is consumed: with 17
+    // positions at most (code predictor) a group's whole share is in flight at once instead of one round trip each
+    auto load_kv = [&](int p, float4& kk, float4& vv) {
         if (p == pos) {
             kk = *reinterpret_cast<const float4*>(&s_k[li * 4]);
             vv = *reinterpret_cast<const float4*>(&s_v[li * 4]);
@@ -520,6 +521,12 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
             kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
             vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
         }
+    };
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk, kn = kk, vn = kk, k2 = kk, v2 = kk;
+    if (start + grp < end) load_kv(start + grp, kk, vv);
+    if (start + grp + 8 < end) load_kv(start + grp + 8, kn, vn);
+    for (int p = start + grp; p < end; p += 8) {
+        if (p + 16 < end) load_kv(p + 16, k2, v2);
 #pragma unroll
         for (int r = 0; r < NREP; ++r) {
             float s = q[r].x * kk.x + q[r].y * kk.y + q[r].z * kk.z + q[r].w * kk.w;
@@ -532,6 +539,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
             acc[r].z = acc[r].z * corr + pe * vv.z; acc[r].w = acc[r].w * corr + pe * vv.w;
             m[r] = mn;
         }
+        kk = kn; vv = vn; kn = k2; vn = v2;
     }
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
