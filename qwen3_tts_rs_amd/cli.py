@@ -1,0 +1,137 @@
+"""`python -m qwen3_tts_rs_amd.cli` — the flag surface of the reference's `generate_audio` binary
+(src/bin/generate_audio.rs:30-120, README.md:362-380) on the MI355X engine: synthesize one utterance, write the WAV
+(PCM16, audio/io.rs:143-165) and the dump files the reference writes (codes_seed{S}_frames{N}.bin i64 LE,
+audio_seed{S}_frames{N}.bin f32 LE, metadata_seed{S}_frames{N}.json; generate_audio.rs:724-813).
+
+Differences, all explicit: `--synthetic {tiny,0.6b,1.7b}` runs without a checkpoint (seeded random weights — there is
+no network here); `--token-ids` / `--instruct-ids` bypass the tokenizer; `--ref-audio` needs the speaker / speech
+encoders, which stay on the Rust side — pass `--xvector-npy` / `--ref-codes-bin` instead."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="qwen3_tts_rs_amd.cli", description=__doc__.split("\n\n")[0])
+    ap.add_argument("-t", "--text", default="Hello")
+    ap.add_argument("-s", "--seed", type=int, default=42)
+    ap.add_argument("-f", "--frames", type=int, default=2048, help="max frames (~164 s); generation stops at EOS")
+    ap.add_argument("-d", "--duration", type=float, default=None, help="max duration in seconds (overrides --frames): frames = duration * 12.5")
+    ap.add_argument("--temperature", type=float, default=0.7)
+    ap.add_argument("--top-k", type=int, default=50)
+    ap.add_argument("--top-p", type=float, default=0.9)
+    ap.add_argument("--repetition-penalty", type=float, default=1.05)
+    ap.add_argument("-m", "--model-dir", default="test_data/model")
+    ap.add_argument("-o", "--output-dir", default="test_data/rust_audio")
+    ap.add_argument("--tokenizer-dir", default=None)
+    ap.add_argument("--speaker", default="ryan")
+    ap.add_argument("--language", default="english")
+    ap.add_argument("--instruct", default=None, help="voice description (VoiceDesign models)")
+    ap.add_argument("--ref-audio", default=None)
+    ap.add_argument("--ref-text", default=None)
+    ap.add_argument("--x-vector-only", action="store_true")
+    ap.add_argument("--output", default=None, help="output WAV path (overrides default naming)")
+    ap.add_argument("--device", default="auto", help="auto | hip | hip:N | cuda:N (accepted as an alias)")
+    # engine-specific
+    ap.add_argument("--synthetic", choices=["tiny", "0.6b", "1.7b"], default=None, help="seeded random weights instead of --model-dir")
+    ap.add_argument("--token-ids", default=None, help="comma-separated text token ids (bypasses the tokenizer)")
+    ap.add_argument("--instruct-ids", default=None, help="comma-separated instruct token ids")
+    ap.add_argument("--xvector-npy", default=None, help="speaker embedding [hidden] f32 (.npy) for voice cloning")
+    ap.add_argument("--ref-codes-bin", default=None, help="reference codec frames (codes_*.bin) for ICL voice cloning")
+    ap.add_argument("--streaming", action="store_true", help="stream chunks (reports time to first audio)")
+    ap.add_argument("--no-eos", action="store_true", help="disable EOS (fixed-length runs on synthetic weights)")
+    return ap
+
+
+def parse_device(s: str) -> int:
+    """parse_device (lib.rs:1875-1926): auto / hip / hip:N; cuda[:N] accepted as an alias; cpu / metal are errors here."""
+    s = s.lower()
+    if s in ("auto", "hip", "cuda", "gpu"):
+        return 0
+    for p in ("hip:", "cuda:"):
+        if s.startswith(p):
+            return int(s[len(p):])
+    raise ValueError(f"Unsupported device '{s}': this build runs on MI355X only (auto | hip | hip:N)")
+
+
+def max_frames_from_args(a) -> int:
+    return int(a.duration * 12.5) if a.duration is not None else a.frames
+
+
+def main(argv=None) -> int:
+    a = build_parser().parse_args(argv)
+    import qwen3_tts_rs_amd as q
+    from qwen3_tts_rs_amd import api
+    from qwen3_tts_rs_amd.text import TextTokenizer
+    if a.ref_audio:
+        print("error: --ref-audio needs the speaker / speech encoders, which are not part of this engine; pass "
+              "--xvector-npy (and --ref-codes-bin + --ref-text for ICL) produced by the reference instead", file=sys.stderr)
+        return 2
+    dev = parse_device(a.device)
+    speaker, language = q.Speaker.from_str(a.speaker), q.Language.from_str(a.language)
+    frames = max_frames_from_args(a)
+    t0 = time.time()
+    if a.synthetic:
+        cfg = {"tiny": q.tiny, "0.6b": q.qwen3_tts_0_6b, "1.7b": q.qwen3_tts_1_7b}[a.synthetic]()
+        model = q.Qwen3TTS.from_synthetic(cfg, device=dev)
+        tok = TextTokenizer.from_pretrained(None, a.tokenizer_dir)
+    else:
+        model = q.Qwen3TTS.from_pretrained(a.model_dir, device=dev)
+        tok = TextTokenizer.from_pretrained(a.model_dir, a.tokenizer_dir)
+    print(f"Loaded model in {time.time() - t0:.2f}s ({model.config.name}, type {model.model_type.name if model.model_type else 'unknown'}, tokenizer: {tok.kind})")
+    ids = [int(x) for x in a.token_ids.split(",")] if a.token_ids else tok.encode(a.text)
+    opts = q.SynthesisOptions(max_length=frames, temperature=a.temperature, top_k=a.top_k, top_p=a.top_p,
+                              repetition_penalty=a.repetition_penalty, seed=a.seed)
+    if a.no_eos:
+        opts.eos_token_id = None
+    utt = q.Utterance(ids, speaker, language, seed=a.seed)
+    if a.instruct or a.instruct_ids:
+        utt.instruct_ids = [int(x) for x in a.instruct_ids.split(",")] if a.instruct_ids else tok.encode(a.instruct)
+    if a.xvector_npy:
+        utt.xvector = np.load(a.xvector_npy).astype(np.float32).reshape(-1)
+        if a.ref_codes_bin and not a.x_vector_only:
+            utt.ref_codes = api.load_codes_binary(a.ref_codes_bin)
+            utt.ref_text_ids = tok.encode(a.ref_text or "")
+    print(f"Generating up to {frames} frames...")
+    t1 = time.time(); ttfa = None
+    if a.streaming:
+        ss = api.StreamingSession(model, utt, opts)
+        chunks = []
+        for c in ss:
+            if ttfa is None:
+                ttfa = (time.time() - t1) * 1000.0
+            chunks.append(c.samples)
+        samples = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+        codes = ss._s.codes(0); ss._s.close()
+        timing = None
+    else:
+        s = model.session([utt], opts)
+        audio, timing = s.run()
+        samples, codes = audio[0].samples, s.codes(0); s.close()
+    wall = time.time() - t1
+    n = int(codes.shape[0])
+    audio = api.AudioBuffer(samples, 24000)
+    print(f"Generated: {audio.duration():.2f}s, {len(audio)} samples, {n} frames in {wall * 1e3:.0f} ms (RTF {wall / max(audio.duration(), 1e-9):.3f})"
+          + (f", TTFA {ttfa:.1f} ms" if ttfa is not None else ""))
+    os.makedirs(a.output_dir, exist_ok=True)
+    wav = a.output or os.path.join(a.output_dir, f"audio_seed{a.seed}_frames{n}.wav")
+    audio.save(wav)
+    api.save_codes_binary(os.path.join(a.output_dir, f"codes_seed{a.seed}_frames{n}.bin"), codes)
+    api.save_audio_binary(os.path.join(a.output_dir, f"audio_seed{a.seed}_frames{n}.bin"), samples)
+    meta = {"text": a.text, "seed": a.seed, "num_frames": n, "temperature": a.temperature, "top_k": a.top_k, "top_p": a.top_p,
+            "input_ids": ids, "codes_shape": [n, 16], "audio_samples": int(len(audio)), "sample_rate": 24000}
+    with open(os.path.join(a.output_dir, f"metadata_seed{a.seed}_frames{n}.json"), "w") as f:
+        json.dump(meta, f, indent=2)
+    print(f"Saved WAV to: {wav}")
+    if timing is not None:
+        print(f"Stages: prefill {timing.prefill_ms:.1f} ms, generation {timing.generation_ms:.1f} ms ({timing.generation_frames} frames), decode {timing.decode_ms:.1f} ms")
+    model.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

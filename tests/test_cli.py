@@ -1,0 +1,77 @@
+"""CLI / e2e_bench surface: flag parsing and the tokenizer stand-in on CPU; the end-to-end runs
+(synthetic tiny checkpoint) on the GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from qwen3_tts_rs_amd import cli
+from qwen3_tts_rs_amd.text import TextTokenizer
+
+
+def test_cli_flag_surface_and_defaults():
+    a = cli.build_parser().parse_args([])
+    # README.md:362-380 defaults of the reference CLI
+    assert (a.text, a.seed, a.frames, a.temperature, a.top_k, a.top_p, a.repetition_penalty) == ("Hello", 42, 2048, 0.7, 50, 0.9, 1.05)
+    assert (a.model_dir, a.speaker, a.language, a.device, a.duration) == ("test_data/model", "ryan", "english", "auto", None)
+    a = cli.build_parser().parse_args(["--duration", "4", "--frames", "7"])
+    assert cli.max_frames_from_args(a) == 50          # duration * 12.5 overrides --frames (generate_audio.rs:138-144)
+    assert cli.parse_device("auto") == 0 and cli.parse_device("hip:3") == 3 and cli.parse_device("cuda:1") == 1
+    with pytest.raises(ValueError, match="MI355X"):
+        cli.parse_device("cpu")
+
+
+def test_tokenizer_standin_and_tokenizer_json(tmp_path):
+    t = TextTokenizer.from_pretrained(None)
+    ids = t.encode("The quick brown fox, transformative!")
+    assert t.kind == "synthetic-wordpiece" and ids == t.encode("The quick brown fox, transformative!") and max(ids) < 151643
+    assert len(ids) == 4 + 1 + 2 + 1                  # long word splits in two, punctuation is its own piece
+    # a real tokenizer.json (WordLevel built with the `tokenizers` package) is picked up from the model directory
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    tk = Tokenizer(models.WordLevel({"hello": 5, "world": 9, "[UNK]": 0}, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    (tmp_path / "m").mkdir()
+    tk.save(str(tmp_path / "m" / "tokenizer.json"))
+    t2 = TextTokenizer.from_pretrained(str(tmp_path / "m"))
+    assert t2.kind == "tokenizer.json" and t2.encode("hello world zzz") == [5, 9, 0]
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_synthetic(tmp_path):
+    out = tmp_path / "o"
+    rc = cli.main(["--synthetic", "tiny", "--text", "The quick brown fox", "--frames", "9", "--no-eos", "--seed", "7",
+                   "--output-dir", str(out), "--language", "de", "--speaker", "vivian"])
+    assert rc == 0
+    meta = json.load(open(out / "metadata_seed7_frames9.json"))
+    assert meta["num_frames"] == 9 and meta["audio_samples"] == 9 * 1920 and meta["codes_shape"] == [9, 16] and len(meta["input_ids"]) == 4
+    codes = np.fromfile(out / "codes_seed7_frames9.bin", dtype="<i8").reshape(9, 16)
+    pcm = np.fromfile(out / "audio_seed7_frames9.bin", dtype="<f4")
+    assert codes.min() >= 0 and codes[:, 0].max() < 3072 and pcm.shape == (9 * 1920,)
+    import wave
+    with wave.open(str(out / "audio_seed7_frames9.wav")) as w:
+        assert (w.getnframes(), w.getframerate(), w.getsampwidth()) == (9 * 1920, 24000, 2)
+    # same seed → same codes (streaming path too)
+    rc = cli.main(["--synthetic", "tiny", "--text", "The quick brown fox", "--frames", "9", "--no-eos", "--seed", "7",
+                   "--output-dir", str(tmp_path / "o2"), "--language", "de", "--speaker", "vivian", "--streaming"])
+    assert rc == 0
+    np.testing.assert_array_equal(np.fromfile(tmp_path / "o2" / "codes_seed7_frames9.bin", dtype="<i8").reshape(9, 16), codes)
+    assert cli.main(["--synthetic", "tiny", "--ref-audio", "x.wav"]) == 2
+
+
+@pytest.mark.gpu
+def test_e2e_bench_report_schema(tmp_path):
+    from qwen3_tts_rs_amd import e2e_bench
+    p = tmp_path / "r.json"
+    assert e2e_bench.main(["--synthetic", "tiny", "--iterations", "2", "--warmup", "0", "--only", "short,medium", "--max-frames", "12",
+                           "--json-output", str(p)]) == 0
+    rep = json.load(open(p))
+    assert set(rep) >= {"device", "model_dir", "iterations", "results"} and [r["label"] for r in rep["results"]] == ["short", "medium"]
+    r = rep["results"][0]
+    for k in ("label", "text", "word_count", "wall_clock_ms", "wall_clock_stddev_ms", "wall_clock_min_ms", "wall_clock_max_ms",
+              "audio_duration_secs", "rtf", "ttfa_ms", "tokens_per_sec", "frames_generated", "peak_memory_mb", "stages"):
+        assert k in r
+    assert r["word_count"] == 13 and set(r["stages"]) == {"prefill_ms", "generation_ms", "generation_frames", "decode_ms"}
+    assert e2e_bench.main(["--synthetic", "tiny", "--iterations", "1", "--warmup", "0", "--only", "short", "--max-frames", "12", "--streaming",
+                           "--json-output", str(p)]) == 0
+    assert json.load(open(p))["results"][0]["ttfa_ms"] > 0
