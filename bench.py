@@ -18,6 +18,7 @@ C oracle = port of the reference's candle-CPU F32 path, timed on this host's cor
 sample of the same workload; rank 0, N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -38,7 +39,7 @@ def main():
     ap.add_argument("--prompt-tokens", type=int, default=512)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU-baseline sample (~12 s of oracle time)")
     ap.add_argument("--profile-frames", type=int, default=6)
     ap.add_argument("--ttfa-reps", type=int, default=5)
     args = ap.parse_args()
@@ -204,7 +205,11 @@ def main():
             t_o = time.time()
             om = oracle_model(cfg, synth.DEFAULT_SEED, which=3)
             o_load = time.time() - t_o
-            ncores = os.cpu_count() or 1
+            try:
+                O.olib.q3o_get_threads.restype = ctypes.c_int
+                ncores = int(O.olib.q3o_get_threads())      # threads the oracle's parallel regions actually use (min(cores, 32))
+            except AttributeError:
+                ncores = min(os.cpu_count() or 1, 32)
             utt0 = q.Utterance(synthetic_prompt(args.prompt_tokens, 0), seed=42)
             oo = q.SynthesisOptions(max_length=args.cpu_frames, eos_token_id=None, seed=42)
             tc = time.perf_counter()
@@ -219,7 +224,7 @@ def main():
                              f"({cpu_wall:.1f}s wall, oracle load {o_load:.0f}s not counted); reference-published CPU: "
                              f"2.3/2.1/1.9 frames/s, RTF 5.39-6.48 on 20 Arm cores (docs/BENCHMARKS.md:111-115)"}
         except Exception as e:
-            cpu = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+            cpu = {"value": None, "unit": "frames/s", "cores": min(os.cpu_count() or 1, 32), "kind": "port", "sample": f"failed: {e}"}
 
     out = {
         "metric": "acoustic_frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

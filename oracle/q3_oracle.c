@@ -46,6 +46,7 @@ static int n_threads(void) {
     return g_threads;
 }
 void q3o_set_threads(int n) { if (n > 0) g_threads = n; }
+int q3o_get_threads(void) { return n_threads(); }
 #define PAR_IF(work) if ((double)(work) > 2.0e5) num_threads(n_threads())
 
 static float* fmalloc(size_t n) {

@@ -98,6 +98,7 @@ typedef struct q3o_session q3o_session;
 
 const char* q3o_last_error(void);
 void q3o_set_threads(int n);
+int q3o_get_threads(void);   /* threads the parallel regions use (default min(cores, 32)) */
 
 q3o_model* q3o_model_new(const q3o_config* cfg);
 void q3o_model_free(q3o_model* m);
