@@ -1239,7 +1239,11 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     // KV sized for what the path needs (prefill + frames), not the reference's max_new_tokens+256 (lib.rs:450)
     s->max_seq = s->prefill_len + s->max_frames + 1;
     if (s->max_seq > m->rope_len) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds the RoPE table (%d)", s->max_seq, m->rope_len);
-    { int ns = 256 / (batch * c.n_kv_heads); if (ns < 1) ns = 1; if (ns > MAX_SPLITS) ns = MAX_SPLITS; s->n_splits = ns; }
+    {
+        static const int ns_env = [] { const char* e = getenv("Q3_ATTN_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid
+        int ns = ns_env > 0 ? ns_env : 512 / (batch * c.n_kv_heads);      // ~2 attention workgroups per CU (B = 8: 8 splits, 3.99 vs 4.02 ms/frame at 4)
+        if (ns < 1) ns = 1; if (ns > MAX_SPLITS) ns = MAX_SPLITS; s->n_splits = ns;
+    }
     {   // the frame loop is a chain of ~600 short dependent kernels per frame: give its queue the highest priority so
         // that its workgroups are dispatched ahead of the vocoder segments running beside it (q3_session_run)
         int least = 0, greatest = 0;
