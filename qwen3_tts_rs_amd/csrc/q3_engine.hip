@@ -165,6 +165,9 @@ struct q3_model {
     const void* pk(const float* w) const { auto it = wpk.find(w); return it == wpk.end() ? nullptr : it->second; }
     const float* first_cb = nullptr; const float** rest_cbs_dev = nullptr; // device array of 15 pointers
     const uint16_t** cp_embs_dev = nullptr;                                // device array of 15 pointers
+    // 1.7B: small_to_mtp_projection applied once to every row of the 15 acoustic embedding tables and of the talker's
+    // codec embedding (code_predictor.rs:337-345, 386-396 project the gathered row on every pass): f32 [rows][cp_hidden]
+    float* proj_tabs = nullptr; const float* cp_proj[15] = {}; const float* sem_proj = nullptr;
     // resolved pointers
     const uint16_t *text_emb, *codec_emb;
     TW fc1w, fc2w, codec_head, mtp_w;
@@ -399,7 +402,7 @@ extern "C" void q3_model_free(q3_model* m) {
     if (m->device < 0) { delete m; return; }
     hipSetDevice(m->device);
     hipFree(m->arena); hipFree(m->rope_cos); hipFree(m->rope_sin); hipFree(m->derived); hipFree(m->wpk_arena);
-    hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev);
+    hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev); hipFree(m->proj_tabs);
     delete m;
 }
 
@@ -573,6 +576,37 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
     }
     if (!m->cp_embs_dev) HIPC(hipMalloc((void**)&m->cp_embs_dev, 15 * sizeof(void*)));
     HIPC(hipMemcpy((void*)m->cp_embs_dev, m->cp_emb.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
+    if (m->mtp_w.t1) {
+        // Pre-projected embedding tables (1.7B): 15 x [cp_vocab][CH] + [codec_vocab][CH] f32 (138 MB). Built with the very
+        // GEMV launches the frame loop would use (8 gathered rows per launch), so a table row is exactly what the
+        // per-pass projection of that row computes at a batch of 8.
+        const int Hh = c.hidden, CHh = c.cp_hidden;
+        const size_t total = ((size_t)15 * c.cp_vocab + c.codec_vocab) * CHh;
+        if (!m->proj_tabs) HIPC(hipMalloc((void**)&m->proj_tabs, total * 4));
+        float* xin = nullptr; uint32_t* ids = nullptr;
+        HIPC(hipMalloc((void**)&xin, (size_t)8 * Hh * 4)); HIPC(hipMalloc((void**)&ids, 8 * 4));
+        float* cur = m->proj_tabs;
+        hipError_t e = hipSuccess;
+        for (int tbl = 0; tbl <= 15 && e == hipSuccess; ++tbl) {
+            const uint16_t* emb = tbl < 15 ? m->cp_emb[tbl] : m->codec_emb;
+            const int rows = tbl < 15 ? c.cp_vocab : c.codec_vocab;
+            if (tbl < 15) m->cp_proj[tbl] = cur; else m->sem_proj = cur;
+            for (int r0 = 0; r0 < rows && e == hipSuccess; r0 += 8) {
+                const int M = (rows - r0) < 8 ? (rows - r0) : 8;
+                uint32_t h[8]; for (int i = 0; i < 8; ++i) h[i] = (uint32_t)(r0 + (i < M ? i : 0));
+                e = hipMemcpyAsync(ids, h, sizeof h, hipMemcpyHostToDevice, 0);
+                if (e == hipSuccess) e = launch_gather_rows_bf16(emb, ids, xin, M, Hh, 0);
+                LinArgs a;
+                a.N = CHh; a.K = Hh; set_w(a, m->mtp_w, 8, CHh, Hh); a.x = xin; a.ldx = Hh; a.bias = m->mtp_b; a.y = cur + (size_t)r0 * CHh; a.ldy = CHh;
+                a.M = M; a.epi = EPI_NONE;
+                if (e == hipSuccess) e = launch_linear(a, 0);
+                if (e == hipSuccess) e = hipStreamSynchronize(0);      // `h` is reused by the next iteration
+            }
+            cur += (size_t)rows * CHh;
+        }
+        hipFree(xin); hipFree(ids);
+        if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "projection tables: %s", hipGetErrorString(e));
+    }
 
     // RoPE tables on the host with libm (bit-identical to the CPU oracle): transformer.rs:78-92, 133-175
     if (!m->rope_cos) {
@@ -993,6 +1027,7 @@ struct q3_session {
     int stream_mode = 0;   // 0 = context-free chunk decode (reference behaviour), 1 = continuous (left context re-run: seamless)
     bool profile = false; ProfAcc prof_linear;
     bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
+    bool proj_tables = getenv("Q3_NO_PROJ_TABLES") == nullptr;   // A/B aid: set to project the gathered embedding on every pass
     bool no_chunk = getenv("Q3_NO_CHUNK") != nullptr;         // A/B aid: one position per prefill step, 16-pass code predictor
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
     std::vector<hipEvent_t> prof_pool; size_t prof_pool_next = 0;
@@ -1102,6 +1137,32 @@ static q3_status cp_run(q3_session* s) {
         g.cp_logits = p >= 2 ? s->CP_LOGITS + (size_t)(p - 2) * B * V : nullptr;
         g.cp_vocab = V; g.codes = s->codes; g.frame_idx = s->frame_idx; g.max_frames = s->max_frames; g.B = B;
         float* dst = m->mtp_w.t1 ? s->CP_IN : s->cb.X; const int ld = m->mtp_w.t1 ? H : CH;
+        // 1.7B with pre-projected tables: only the talker hidden state (pass 0) still goes through the 2048 -> 1024
+        // projection at run time; every embedding row arrives already projected (14 GEMV launches less per frame)
+        const bool tabs = m->mtp_w.t1 && m->proj_tabs && s->proj_tables;
+        auto project = [&](int M, int ldy) -> q3_status {
+            LinArgs a;
+            a.N = CH; a.K = H; set_w(a, m->mtp_w, M, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = ldy;
+            a.M = M; a.epi = EPI_NONE;
+            HIPC(run_linear(s, a));
+            return Q3_OK;
+        };
+        if (tabs) {
+            if (rows == 2) {
+                g.pass = 0; g.out = s->CP_IN; g.ld_out = H;                       // B rows of talker hidden
+                HIPC(launch_cp_gather(g, s->stream));
+                Q3C(project(B, 2 * CH));                                           // -> cb.X rows 2b
+                g.pass = 1; g.out = s->cb.X + CH; g.ld_out = 2 * CH; g.proj_tab = m->sem_proj; g.proj_dim = CH;   // rows 2b+1
+                HIPC(launch_cp_gather(g, s->stream));
+            } else if (p == 0) {
+                g.out = s->CP_IN; g.ld_out = H;
+                HIPC(launch_cp_gather(g, s->stream));
+                Q3C(project(B, CH));
+            } else {
+                g.out = s->cb.X; g.ld_out = CH; g.proj_tab = p == 1 ? m->sem_proj : m->cp_proj[p - 2]; g.proj_dim = CH;
+                HIPC(launch_cp_gather(g, s->stream));
+            }
+        } else {
         if (rows == 2) {
             // row 2b = talker hidden (pass-0 source), row 2b+1 = semantic embedding (pass-1 source)
             g.pass = 0; g.out = dst; g.ld_out = 2 * ld;
@@ -1112,11 +1173,7 @@ static q3_status cp_run(q3_session* s) {
             g.out = dst; g.ld_out = ld;
             HIPC(launch_cp_gather(g, s->stream));
         }
-        if (m->mtp_w.t1) {
-            LinArgs a;
-            a.N = CH; a.K = H; set_w(a, m->mtp_w, B * rows, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH;
-            a.M = B * rows; a.epi = EPI_NONE;
-            HIPC(run_linear(s, a));
+        if (m->mtp_w.t1) Q3C(project(B * rows, CH));
         }
         for (int i = 0; i < c.cp_layers; ++i)
             Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,

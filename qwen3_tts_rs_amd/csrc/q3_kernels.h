@@ -102,6 +102,9 @@ struct CpGatherArgs {
     const int* frame_idx;            // [B]
     int max_frames;
     float* out; int ld_out;          // [B][H]
+    // 1.7B: pass >= 1 rows taken from a PRE-PROJECTED f32 table [vocab][proj_dim] (small_to_mtp_projection applied to
+    // every embedding row once at model finalize) instead of the bf16 embedding table; nullptr = embedding table
+    const float* proj_tab = nullptr; int proj_dim = 0;
     int B;
 };
 hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st);

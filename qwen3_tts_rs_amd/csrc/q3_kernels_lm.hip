@@ -684,14 +684,19 @@ __global__ __launch_bounds__(256) void k_cp_gather(CpGatherArgs a) {
         for (int c = threadIdx.x; c < a.H; c += 256) out[c] = src[c];
         return;
     }
-    const uint16_t* src;
+    int row;
     if (a.pass == 1) {
-        src = a.codec_emb + (size_t)a.tok[b] * a.H;
+        row = (int)a.tok[b];
     } else {
-        const int code = block_argmax_first(a.cp_logits + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
-        if (threadIdx.x == 0) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)code;
-        src = a.cp_emb + (size_t)code * a.H;
+        row = block_argmax_first(a.cp_logits + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
+        if (threadIdx.x == 0) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)row;
     }
+    if (a.proj_tab) {
+        const float* src = a.proj_tab + (size_t)row * a.proj_dim;
+        for (int c = threadIdx.x; c < a.proj_dim; c += 256) out[c] = src[c];
+        return;
+    }
+    const uint16_t* src = (a.pass == 1 ? a.codec_emb : a.cp_emb) + (size_t)row * a.H;
     for (int c = threadIdx.x; c < a.H; c += 256) out[c] = bf16_to_f32(src[c]);
 }
 hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st) {
