@@ -168,6 +168,8 @@ struct q3_model {
     // 1.7B: small_to_mtp_projection applied once to every row of the 15 acoustic embedding tables and of the talker's
     // codec embedding (code_predictor.rs:337-345, 386-396 project the gathered row on every pass): f32 [rows][cp_hidden]
     float* proj_tabs = nullptr; const float* cp_proj[15] = {}; const float* sem_proj = nullptr;
+    // layer-0 q|k|v of every such row (input RMSNorm + qkv projection of code-predictor layer 0): f32 [rows][qkv dim]
+    float* qkv0_tabs = nullptr; const float* cp_qkv0[15] = {}; const float* sem_qkv0 = nullptr;
     // resolved pointers
     const uint16_t *text_emb, *codec_emb;
     TW fc1w, fc2w, codec_head, mtp_w;
@@ -402,7 +404,7 @@ extern "C" void q3_model_free(q3_model* m) {
     if (m->device < 0) { delete m; return; }
     hipSetDevice(m->device);
     hipFree(m->arena); hipFree(m->rope_cos); hipFree(m->rope_sin); hipFree(m->derived); hipFree(m->wpk_arena);
-    hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev); hipFree(m->proj_tabs);
+    hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev); hipFree(m->proj_tabs); hipFree(m->qkv0_tabs);
     delete m;
 }
 
@@ -606,6 +608,42 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
         }
         hipFree(xin); hipFree(ids);
         if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "projection tables: %s", hipGetErrorString(e));
+    }
+    if (c.cp_hidden % 4 == 0 && (m->mtp_w.t1 ? m->proj_tabs != nullptr : c.cp_hidden == c.hidden)) {
+        // Layer-0 q|k|v tables: the first code-predictor layer sees only (projected) embedding rows on passes >= 1, so
+        // RMSNorm + qkv of every possible row is computed once, again with the launches the frame loop would use.
+        const int CHh = c.cp_hidden, QKVD = (c.cp_heads + 2 * c.cp_kv_heads) * HEAD_DIM;
+        const size_t total = ((size_t)15 * c.cp_vocab + c.codec_vocab) * QKVD;
+        if (!m->qkv0_tabs) HIPC(hipMalloc((void**)&m->qkv0_tabs, total * 4));
+        float* xin = nullptr; uint32_t* ids = nullptr;
+        HIPC(hipMalloc((void**)&xin, (size_t)8 * CHh * 4)); HIPC(hipMalloc((void**)&ids, 8 * 4));
+        float* cur = m->qkv0_tabs;
+        hipError_t e = hipSuccess;
+        for (int tbl = 0; tbl <= 15 && e == hipSuccess; ++tbl) {
+            const int rows = tbl < 15 ? c.cp_vocab : c.codec_vocab;
+            const float* prow = m->mtp_w.t1 ? (tbl < 15 ? m->cp_proj[tbl] : m->sem_proj) : nullptr;
+            const uint16_t* emb = tbl < 15 ? m->cp_emb[tbl] : m->codec_emb;
+            if (tbl < 15) m->cp_qkv0[tbl] = cur; else m->sem_qkv0 = cur;
+            for (int r0 = 0; r0 < rows && e == hipSuccess; r0 += 8) {
+                const int M = (rows - r0) < 8 ? (rows - r0) : 8;
+                const float* x = prow ? prow + (size_t)r0 * CHh : xin;
+                if (!prow) {
+                    uint32_t h[8]; for (int i = 0; i < 8; ++i) h[i] = (uint32_t)(r0 + (i < M ? i : 0));
+                    e = hipMemcpyAsync(ids, h, sizeof h, hipMemcpyHostToDevice, 0);
+                    if (e == hipSuccess) e = launch_gather_rows_bf16(emb, ids, xin, M, CHh, 0);
+                    if (e == hipSuccess) e = hipStreamSynchronize(0);
+                }
+                LinArgs a;
+                a.N = QKVD; a.K = CHh; set_w(a, m->cl[0].qkv, 8, QKVD, CHh); a.x = x; a.ldx = CHh; a.norm_w = m->cl[0].in_ln; a.eps = c.rms_eps;
+                a.y = cur + (size_t)r0 * QKVD; a.ldy = QKVD; a.M = M; a.epi = EPI_NONE;
+                if (e == hipSuccess) e = launch_linear(a, 0);
+                if (!prow && e == hipSuccess) e = hipStreamSynchronize(0);
+            }
+            cur += (size_t)rows * QKVD;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(0);
+        hipFree(xin); hipFree(ids);
+        if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "layer-0 qkv tables: %s", hipGetErrorString(e));
     }
 
     // RoPE tables on the host with libm (bit-identical to the CPU oracle): transformer.rs:78-92, 133-175
@@ -1028,6 +1066,7 @@ struct q3_session {
     bool profile = false; ProfAcc prof_linear;
     bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
     bool proj_tables = getenv("Q3_NO_PROJ_TABLES") == nullptr;   // A/B aid: set to project the gathered embedding on every pass
+    bool qkv_tables = getenv("Q3_NO_QKV_TABLES") == nullptr;     // A/B aid: set to run the layer-0 qkv GEMV on every pass
     bool no_chunk = getenv("Q3_NO_CHUNK") != nullptr;         // A/B aid: one position per prefill step, 16-pass code predictor
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
     std::vector<hipEvent_t> prof_pool; size_t prof_pool_next = 0;
@@ -1054,7 +1093,7 @@ static hipError_t run_linear(q3_session* s, const LinArgs& a) {
 
 // one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
 static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf& b, float* kc, float* vc, int max_seq,
-                          const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1) {
+                          const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1, bool skip_qkv = false) {
     const q3_model* m = s->m;
     // B = number of activation ROWS of this step: one per sequence, or rows_per_seq consecutive positions per
     // sequence (chunked prefill, the code predictor's 2-token first pass)
@@ -1062,7 +1101,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     LinArgs a;
     a.N = QD + 2 * KD; a.K = d.H; set_w(a, w.qkv, B, a.N, a.K); a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
     a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE;
-    HIPC(run_linear(s, a));
+    if (!skip_qkv) HIPC(run_linear(s, a));       // skip: the caller already filled b.QKV (code predictor layer 0, table rows)
     AttnArgs t{};
     t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
     t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
@@ -1147,19 +1186,34 @@ static q3_status cp_run(q3_session* s) {
             HIPC(run_linear(s, a));
             return Q3_OK;
         };
+        // layer-0 q|k|v of a table row comes from the table too (both model sizes): the layer-0 qkv GEMV then only runs
+        // for the rows that carry the talker hidden state
+        const bool qt = m->qkv0_tabs && s->qkv_tables && (tabs || !m->mtp_w.t1);
+        const int QKVD = (d.nh + 2 * d.nkv) * HEAD_DIM;
+        bool skip0 = false;
+        auto qkv_rows0 = [&](int ldx, int ldy) -> q3_status {      // run-time layer-0 qkv of the B pass-0 rows
+            LinArgs a;
+            a.N = QKVD; a.K = CH; set_w(a, m->cl[0].qkv, B, QKVD, CH); a.x = s->cb.X; a.ldx = ldx; a.norm_w = m->cl[0].in_ln; a.eps = d.eps;
+            a.y = s->cb.QKV; a.ldy = ldy; a.M = B; a.epi = EPI_NONE;
+            HIPC(run_linear(s, a));
+            return Q3_OK;
+        };
         if (tabs) {
             if (rows == 2) {
                 g.pass = 0; g.out = s->CP_IN; g.ld_out = H;                       // B rows of talker hidden
                 HIPC(launch_cp_gather(g, s->stream));
                 Q3C(project(B, 2 * CH));                                           // -> cb.X rows 2b
                 g.pass = 1; g.out = s->cb.X + CH; g.ld_out = 2 * CH; g.proj_tab = m->sem_proj; g.proj_dim = CH;   // rows 2b+1
+                if (qt) { g.qkv_tab = m->sem_qkv0; g.qkv_dim = QKVD; g.qkv_out = s->cb.QKV + QKVD; g.ld_qkv_out = 2 * QKVD; }
                 HIPC(launch_cp_gather(g, s->stream));
+                if (qt) { Q3C(qkv_rows0(2 * CH, 2 * QKVD)); skip0 = true; }
             } else if (p == 0) {
                 g.out = s->CP_IN; g.ld_out = H;
                 HIPC(launch_cp_gather(g, s->stream));
                 Q3C(project(B, CH));
             } else {
                 g.out = s->cb.X; g.ld_out = CH; g.proj_tab = p == 1 ? m->sem_proj : m->cp_proj[p - 2]; g.proj_dim = CH;
+                if (qt) { g.qkv_tab = p == 1 ? m->sem_qkv0 : m->cp_qkv0[p - 2]; g.qkv_dim = QKVD; g.qkv_out = s->cb.QKV; g.ld_qkv_out = QKVD; skip0 = true; }
                 HIPC(launch_cp_gather(g, s->stream));
             }
         } else {
@@ -1168,16 +1222,19 @@ static q3_status cp_run(q3_session* s) {
             g.pass = 0; g.out = dst; g.ld_out = 2 * ld;
             HIPC(launch_cp_gather(g, s->stream));
             g.pass = 1; g.out = dst + ld;
+            if (qt) { g.qkv_tab = m->sem_qkv0; g.qkv_dim = QKVD; g.qkv_out = s->cb.QKV + QKVD; g.ld_qkv_out = 2 * QKVD; }
             HIPC(launch_cp_gather(g, s->stream));
+            if (qt) { Q3C(qkv_rows0(2 * CH, 2 * QKVD)); skip0 = true; }
         } else {
             g.out = dst; g.ld_out = ld;
+            if (qt && p >= 1) { g.qkv_tab = p == 1 ? m->sem_qkv0 : m->cp_qkv0[p - 2]; g.qkv_dim = QKVD; g.qkv_out = s->cb.QKV; g.ld_qkv_out = QKVD; skip0 = true; }
             HIPC(launch_cp_gather(g, s->stream));
         }
         if (m->mtp_w.t1) Q3C(project(B * rows, CH));
         }
         for (int i = 0; i < c.cp_layers; ++i)
             Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,
-                         n_pass + 1, nullptr, rows == 2 ? 0 : p, 1, rows));
+                         n_pass + 1, nullptr, rows == 2 ? 0 : p, 1, rows, i == 0 && skip0));
         if (p >= 1) {
             LinArgs h;
             h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X + (size_t)(rows - 1) * CH; h.ldx = rows * CH;

@@ -105,6 +105,9 @@ struct CpGatherArgs {
     // 1.7B: pass >= 1 rows taken from a PRE-PROJECTED f32 table [vocab][proj_dim] (small_to_mtp_projection applied to
     // every embedding row once at model finalize) instead of the bf16 embedding table; nullptr = embedding table
     const float* proj_tab = nullptr; int proj_dim = 0;
+    // pass >= 1: the row's layer-0 q|k|v projection (input RMSNorm included) from a table built at finalize, copied to
+    // qkv_out[b][0 .. qkv_dim) so that the layer-0 qkv GEMV of this pass can be skipped
+    const float* qkv_tab = nullptr; int qkv_dim = 0; float* qkv_out = nullptr; int ld_qkv_out = 0;
     int B;
 };
 hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st);

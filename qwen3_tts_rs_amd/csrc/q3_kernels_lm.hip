@@ -691,6 +691,11 @@ __global__ __launch_bounds__(256) void k_cp_gather(CpGatherArgs a) {
         row = block_argmax_first(a.cp_logits + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
         if (threadIdx.x == 0) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)row;
     }
+    if (a.qkv_tab) {
+        const float4* src = reinterpret_cast<const float4*>(a.qkv_tab + (size_t)row * a.qkv_dim);
+        float4* dst = reinterpret_cast<float4*>(a.qkv_out + (size_t)b * a.ld_qkv_out);
+        for (int c = threadIdx.x; c < a.qkv_dim / 4; c += 256) dst[c] = src[c];
+    }
     if (a.proj_tab) {
         const float* src = a.proj_tab + (size_t)row * a.proj_dim;
         for (int c = threadIdx.x; c < a.proj_dim; c += 256) out[c] = src[c];
