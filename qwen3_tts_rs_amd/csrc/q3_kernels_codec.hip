@@ -321,7 +321,7 @@ __device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t
     return acc;
 }
 
-template <int K, int CO_M, int T_M, int WCO, int WT>
+template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false>
 __global__ __launch_bounds__(64 * WCO * WT, 3) void k_conv_bf16x3(ConvDev a) {     // 3 waves per SIMD: 2-3 workgroups per CU
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
@@ -408,10 +408,24 @@ __global__ __launch_bounds__(64 * WCO * WT, 3) void k_conv_bf16x3(ConvDev a) {  
             do_step(A1, s0 + 1);
         }
     }
-    // epilogue: lane (li, lk) holds column t = li of rows (reg&3) + 8*(reg>>2) + 4*lk; per-row operands are fetched once
-    // per row and reused by the T_M time tiles
+    // epilogue: lane (li, lk) holds column t = li of rows (reg&3) + 8*(reg>>2) + 4*lk. PRE (residual epilogues of the
+    // single-co-tile geometries): the residual values of a 32-row tile are requested in one batch before the first use —
+    // inside the element loop they serialise into one memory round trip per element (96 channels: 1670 -> 950 us); on
+    // the two-co-tile geometries the extra registers spill and it loses, so those keep the in-loop load.
 #pragma unroll
     for (int cm = 0; cm < CO_M; ++cm) {
+        float rs[PRE ? T_M : 1][16];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int o = co0 + cm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+#pragma unroll
+                for (int tm = 0; tm < T_M; ++tm) {
+                    const int t = t0 + wt * (32 * T_M) + tm * 32 + li;
+                    rs[tm][reg] = (a.resid && o < a.cout && t < a.L) ? a.resid[(size_t)o * a.oL + (size_t)t * a.ostride + ooff] : 0.0f;
+                }
+            }
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int o = co0 + cm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(64 * WCO * WT, 3) void k_conv_bf16x3(ConvDev a) {  
                     if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     if (a.scale) v = v * sc;
                     const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
-                    if (a.resid) v = a.resid[oi] + v;
+                    if (a.resid) v = (PRE ? rs[PRE ? tm : 0][reg] : a.resid[oi]) + v;
                     if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
                     if (a.post_a) {
                         const float va = snake_f(v, pa, pib);
@@ -446,12 +460,16 @@ static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) 
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     const size_t lds = (size_t)3 * (T_WG + (K - 1) * a.dil) * XP;
     dim3 grid((a.L + T_WG - 1) / T_WG, a.cout / CO_WG, phases);
-    hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, dim3(64 * WCO * WT), lds, st, a);
+    if (CO_M == 1 && K == 1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K == 1>), grid, dim3(64 * WCO * WT), lds, st, a);
+    else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, dim3(64 * WCO * WT), lds, st, a);
     return hipGetLastError();
 }
 template <int K>
 static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) {
     const long big_tiles = (long)((a.L + 127) / 128) * (a.cout / 128) * phases;
+    // 1x1 convs with a residual (second conv of every residual unit) are bound by their epilogue traffic, not by x
+    // staging: the single-co-tile 64 co x 128 t geometry with batched residual loads wins at every width
+    if (K == 1 && a.resid && a.cout % 64 == 0 && a.cout != 96 && big_tiles >= 192) return launch_bf16x3_v<K, 1, 2, 2, 2>(a, phases, st);
     if (a.cout % 128 == 0 && big_tiles >= 192) return launch_bf16x3_v<K, 2, 2, 2, 2>(a, phases, st);   // 128 co x 128 t
     if (a.cout == 192) return launch_bf16x3_v<K, 2, 2, 3, 2>(a, phases, st);                            // 192 co x 128 t (x staged once)
     if (a.cout == 96) return launch_bf16x3_v<K, 1, 2, 3, 2>(a, phases, st);                             //  96 co x 128 t
