@@ -326,10 +326,21 @@ __global__ __launch_bounds__(64 * WCO * WT, 3) void k_conv_bf16x3(ConvDev a) {  
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [3 planes][W rows][XP bytes]
+    // per-output-row epilogue operands (bias, layer scale, the consumer's SnakeBeta pair), fetched once per workgroup:
+    // read from global inside the store loop they cannot be hoisted over the stores and cost a round trip per row
+    __shared__ float s_prm[4][CO_WG];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, lk = lane >> 5;
     const int wco = wave % WCO, wt = wave / WCO;
     const int t0 = blockIdx.x * T_WG, co0 = blockIdx.y * CO_WG + wco * (32 * CO_M);
+    for (int i = tid; i < CO_WG; i += NT) {
+        const int o = blockIdx.y * CO_WG + i;
+        const bool ok = o < a.cout;
+        s_prm[0][i] = (a.b && ok) ? a.b[o] : 0.0f;
+        s_prm[1][i] = (a.scale && ok) ? a.scale[o] : 1.0f;
+        s_prm[2][i] = (a.post_a && ok) ? a.post_a[o] : 0.0f;
+        s_prm[3][i] = (a.post_a && ok) ? a.post_ib[o] : 0.0f;
+    }
     const int halo = (K - 1) * a.dil, W = T_WG + halo;
     const size_t plane = (size_t)W * XP;
     const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk) + (size_t)blockIdx.z * a.wpk_phase_stride;
@@ -430,9 +441,8 @@ __global__ __launch_bounds__(64 * WCO * WT, 3) void k_conv_bf16x3(ConvDev a) {  
         for (int reg = 0; reg < 16; ++reg) {
             const int o = co0 + cm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
             const bool ook = o < a.cout;
-            const float bias = (a.b && ook) ? a.b[o] : 0.0f;
-            const float sc = (a.scale && ook) ? a.scale[o] : 1.0f;
-            const float pa = (a.post_a && ook) ? a.post_a[o] : 0.0f, pib = (a.post_a && ook) ? a.post_ib[o] : 0.0f;
+            const int pi = o - blockIdx.y * CO_WG;              // row inside the workgroup's channel range
+            const float bias = s_prm[0][pi], sc = s_prm[1][pi], pa = s_prm[2][pi], pib = s_prm[3][pi];
 #pragma unroll
             for (int tm = 0; tm < T_M; ++tm) {
                 const int t = t0 + wt * (32 * T_M) + tm * 32 + li;
