@@ -1107,7 +1107,9 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
-    if (s->legacy_attn || rows_per_seq > 1) {     // rows of one sequence depend on each other's K/V: three launches
+    if (!s->legacy_attn && rows_per_seq == 2 && !pos_dev && pos_static == 0) {
+        HIPC(launch_attn_first2(t, s->stream));    // the code predictor's 2-token first pass
+    } else if (s->legacy_attn || rows_per_seq > 1) {     // rows of one sequence depend on each other's K/V: three launches
         HIPC(launch_qknorm_rope_kv(t, s->stream));
         HIPC(launch_attn_decode(t, s->stream));
         HIPC(launch_attn_merge(t, s->stream));

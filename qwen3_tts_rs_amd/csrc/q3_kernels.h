@@ -74,6 +74,8 @@ struct AttnArgs {
 hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st);
+// the code predictor's 2-token first pass (rows 2b / 2b+1 at positions 0 / 1 of an empty cache), one launch
+hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st);
 // prefill: causal attention of rows_per_seq consecutive positions per sequence (B = total rows), after launch_qknorm_rope_kv
 hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st);
 // fused q/k-norm + RoPE + KV append + attention (+ final normalisation when n_splits == 1)

@@ -582,6 +582,74 @@ hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// The code predictor's first pass (code_predictor.rs:337-367: talker hidden + semantic embedding as a 2-token causal
+// prefill from an empty cache) in ONE launch instead of k_qknorm_rope_kv + k_attn_decode + k_attn_merge: row 2b sits at
+// position 0 and sees only itself (softmax over one key: its output is its own V row), row 2b+1 at position 1 sees both.
+// grid (nkv, sequences); the per-group / merge arithmetic of the generic kernels is written out for two keys.
+template <int NREP>
+__global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_q[NREP][HEAD_DIM];          // q heads of row 1 (row 0 needs none)
+    __shared__ __attribute__((aligned(16))) float s_k[2][HEAD_DIM], s_v[2][HEAD_DIM];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
+    const size_t cache_base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    // jobs: 0..NREP-1 = q heads of row 1; NREP, NREP+1 = k (+ raw v) of rows 0, 1
+    for (int j = wave; j < NREP + 2; j += 4) {
+        const bool is_q = j < NREP;
+        const int row = is_q ? 1 : j - NREP, pos = row;
+        const float* base = a.qkv + (size_t)(2 * b + row) * a.ld_qkv;
+        const float* src = base + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM);
+        float x1 = src[lane], x2 = src[lane + 64];
+        const float ss = wave_sum(x1 * x1 + x2 * x2);
+        const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
+        const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
+        x1 = x1 / den * nw[lane];
+        x2 = x2 / den * nw[lane + 64];
+        const float c = a.rope_cos[(size_t)pos * 64 + lane], sn = a.rope_sin[(size_t)pos * 64 + lane];
+        const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, sn));
+        const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
+        if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
+        else {
+            const float* vs = base + QD + KD + kvh * HEAD_DIM;
+            const float v1 = vs[lane], v2 = vs[lane + 64];
+            s_k[row][lane] = o1; s_k[row][lane + 64] = o2; s_v[row][lane] = v1; s_v[row][lane + 64] = v2;
+            float* kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM;
+            float* vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM;
+            kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
+        }
+    }
+    __syncthreads();
+    const float scale = 0.08838834764831845f;
+    for (int r = wave; r < NREP; r += 4) {
+        const int h = kvh * NREP + r;
+        // row 0: one key, weight exp(0) / 1
+        float* o0 = a.out + (size_t)(2 * b) * a.ld_out + h * HEAD_DIM;
+        o0[lane] = s_v[0][lane]; o0[lane + 64] = s_v[0][lane + 64];
+        // row 1: two keys
+        const float q1 = s_q[r][lane], q2 = s_q[r][lane + 64];
+        const float sc0 = wave_sum(q1 * s_k[0][lane] + q2 * s_k[0][lane + 64]) * scale;
+        const float sc1 = wave_sum(q1 * s_k[1][lane] + q2 * s_k[1][lane + 64]) * scale;
+        const float M = fmaxf(sc0, sc1);
+        const float w0 = expf(sc0 - M), w1 = expf(sc1 - M);
+        const float L = w0 + w1;
+        float* o1 = a.out + (size_t)(2 * b + 1) * a.ld_out + h * HEAD_DIM;
+        o1[lane] = (s_v[0][lane] * w0 + s_v[1][lane] * w1) / L;
+        o1[lane + 64] = (s_v[0][lane + 64] * w0 + s_v[1][lane + 64] * w1) / L;
+    }
+}
+
+hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
+    const int nrep = a.nh / a.nkv;
+    if (a.rows_per_seq != 2 || a.B % 2) return hipErrorInvalidValue;
+    dim3 grid(a.nkv, a.B / 2);
+    if (nrep == 1) hipLaunchKernelGGL(k_attn_first2<1>, grid, dim3(256), 0, st, a);
+    else if (nrep == 2) hipLaunchKernelGGL(k_attn_first2<2>, grid, dim3(256), 0, st, a);
+    else if (nrep == 4) hipLaunchKernelGGL(k_attn_first2<4>, grid, dim3(256), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // merge the split partials: out[b][h*128+d] = Σ_s A_s[d] e^{m_s-M} / Σ_s l_s e^{m_s-M}
 // A separate launch on purpose. Folding it into k_attn_fused as a "last split block to arrive merges" epilogue (release
 // fence + ticket atomic + acquire fence + agent-scope loads) was built and measured on MI355X: bit-identical output,
