@@ -322,7 +322,7 @@ __device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t
 }
 
 template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false>
-__global__ __launch_bounds__(64 * WCO * WT, 3) void k_conv_bf16x3(ConvDev a) {     // 3 waves per SIMD: 2-3 workgroups per CU
+__global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x3(ConvDev a) {     // waves per SIMD the register budget must allow
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [3 planes][W rows][XP bytes]
@@ -480,8 +480,8 @@ static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) 
     // 1x1 convs with a residual (second conv of every residual unit) are bound by their epilogue traffic, not by x
     // staging: the single-co-tile 64 co x 128 t geometry with batched residual loads wins at every width
     if (K == 1 && a.resid && a.cout % 64 == 0 && a.cout != 96 && big_tiles >= 192) return launch_bf16x3_v<K, 1, 2, 2, 2>(a, phases, st);
-    if (a.cout % 128 == 0 && big_tiles >= 192) return launch_bf16x3_v<K, 2, 2, 2, 2>(a, phases, st);   // 128 co x 128 t
-    if (a.cout == 192) return launch_bf16x3_v<K, 2, 2, 3, 2>(a, phases, st);                            // 192 co x 128 t (x staged once)
+    if (a.cout % 128 == 0 && big_tiles >= 192) return launch_bf16x3_v<K, 2, 2, 2, 2>(a, phases, st);   // 128 co x 128 t (64 x 128: 5-13 % slower at k = 7)
+    if (a.cout == 192) return launch_bf16x3_v<K, 1, 2, 3, 2>(a, phases, st);   // 2 x (96 co x 128 t): 1.32 ms vs 1.50 for 192 x 128 (k = 7)
     if (a.cout == 96) return launch_bf16x3_v<K, 1, 2, 3, 2>(a, phases, st);                             //  96 co x 128 t
     if (a.cout % 64 == 0) return launch_bf16x3_v<K, 1, 1, 2, 2>(a, phases, st);                         //  64 co x  64 t (small grids)
     return hipErrorNotSupported;
