@@ -743,13 +743,16 @@ hipError_t launch_copy_rows(const float* src, int lds, float* dst, int ldd, int 
 // Code-predictor input of pass p (code_predictor.rs:337-345, 386-396): pass 0 = talker hidden,
 // pass 1 = semantic embedding, pass p>=2 = embedding (table p-2) of argmax(previous pass logits);
 // the argmax'd code is also recorded as codes[b][frame][p-1].
+// grid (B, CPG_PARTS): every part re-derives the row id (an argmax over 2048 logits is cheaper than a second launch)
+// and copies its share of the row(s) — one workgroup per sequence spent 8.6 us on the 20 KB of table rows.
+constexpr int CPG_PARTS = 4;
 __global__ __launch_bounds__(256) void k_cp_gather(CpGatherArgs a) {
     __shared__ float red_v[4]; __shared__ int red_i[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, part = blockIdx.y, tid = part * 256 + threadIdx.x, NT = CPG_PARTS * 256;
     float* out = a.out + (size_t)b * a.ld_out;
     if (a.pass == 0) {
         const float* src = a.last_hidden + (size_t)b * a.H;
-        for (int c = threadIdx.x; c < a.H; c += 256) out[c] = src[c];
+        for (int c = tid; c < a.H; c += NT) out[c] = src[c];
         return;
     }
     int row;
@@ -757,23 +760,23 @@ __global__ __launch_bounds__(256) void k_cp_gather(CpGatherArgs a) {
         row = (int)a.tok[b];
     } else {
         row = block_argmax_first(a.cp_logits + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
-        if (threadIdx.x == 0) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)row;
+        if (tid == 0) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)row;
     }
     if (a.qkv_tab) {
         const float4* src = reinterpret_cast<const float4*>(a.qkv_tab + (size_t)row * a.qkv_dim);
         float4* dst = reinterpret_cast<float4*>(a.qkv_out + (size_t)b * a.ld_qkv_out);
-        for (int c = threadIdx.x; c < a.qkv_dim / 4; c += 256) dst[c] = src[c];
+        for (int c = tid; c < a.qkv_dim / 4; c += NT) dst[c] = src[c];
     }
     if (a.proj_tab) {
         const float* src = a.proj_tab + (size_t)row * a.proj_dim;
-        for (int c = threadIdx.x; c < a.proj_dim; c += 256) out[c] = src[c];
+        for (int c = tid; c < a.proj_dim; c += NT) out[c] = src[c];
         return;
     }
     const uint16_t* src = (a.pass == 1 ? a.codec_emb : a.cp_emb) + (size_t)row * a.H;
-    for (int c = threadIdx.x; c < a.H; c += 256) out[c] = bf16_to_f32(src[c]);
+    for (int c = tid; c < a.H; c += NT) out[c] = bf16_to_f32(src[c]);
 }
 hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_cp_gather, dim3(a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_cp_gather, dim3(a.B, CPG_PARTS), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
