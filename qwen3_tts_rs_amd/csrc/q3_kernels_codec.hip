@@ -321,6 +321,11 @@ __device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t
     return acc;
 }
 
+// Summation order of the 1x1 convs whose cin is a multiple of 512 (the pre-transformer / ConvNeXt linears): 128-channel
+// segments are accumulated from zero and added to the total in ascending order — the order k_lin_small_bf16x3 (short
+// sequences, one wave per segment) can reproduce, so both kernels give a position the same bits.
+__host__ __device__ __forceinline__ bool conv_segmented(int k, int cin) { return k == 1 && (cin & 511) == 0; }
+
 template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false>
 __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x3(ConvDev a) {     // waves per SIMD the register budget must allow
     constexpr int NT = 64 * WCO * WT;
@@ -354,6 +359,17 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         for (int j = 0; j < T_M; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    constexpr int SM = K == 1 ? CO_M : 1, SN = K == 1 ? T_M : 1;
+    f32x16_t tot[SM][SN];
+    const bool seg = K == 1 && conv_segmented(a.k, a.cin);
+    if (K == 1) {
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.0f;
+    }
 
     auto load_A = [&](cu32x4_t (&A)[CO_M][3], int ci0, int kk, int c16l) {
 #pragma unroll
@@ -418,6 +434,20 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
             if (s0 + 2 < n_steps) { const int kk = (s0 + 2) / n16; load_A(A0, ci0, kk, (s0 + 2) - kk * n16); }
             do_step(A1, s0 + 1);
         }
+        if (K == 1 && seg && ((ci0 + 32) & 127) == 0) {          // segment boundary: total += segment sum
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int j = 0; j < SN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { tot[i][j][r] = tot[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.0f; }
+        }
+    }
+    if (K == 1 && seg) {
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int j = 0; j < SN; ++j) acc[i][j] = tot[i][j];
     }
     // epilogue: lane (li, lk) holds column t = li of rows (reg&3) + 8*(reg>>2) + 4*lk. PRE (residual epilogues of the
     // single-co-tile geometries): the residual values of a 32-row tile are requested in one batch before the first use —
@@ -465,6 +495,96 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Short sequences (streaming chunks: the pre-transformer and ConvNeXt linears at L <= 32). The tiled kernel above walks
+// cin in 32 serial stages of (weight round trip, two barriers) with 8-16 workgroups on the chip: 29-52 us for a
+// 10-column product whose 3-6 MB of weights stream in 2 us. Here a workgroup owns one 32-co tile and the single column
+// tile; wave w takes the 128-channel segment w of cin, requests ALL its operands up front (24 KB of weight fragments
+// + the x columns straight from global, split in registers), and the segment sums are added in ascending order through
+// LDS. That is the segmented summation order conv_segmented() defines, which the tiled kernel follows for the same
+// shapes — a frame position gets bit-identical values from either kernel (continuous streaming mode depends on it).
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
+    __shared__ float part[W][16][64];
+    constexpr int NR = 16 / W;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
+    const int co32 = blockIdx.x, co0 = co32 * 32;
+    const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk);
+    const float* __restrict__ x = a.x;
+    const int nc16 = a.cin >> 4, nseg = a.cin >> 7;
+    const bool tok = li < a.L;
+    float tot[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) tot[j] = 0.0f;
+    for (int s0 = 0; s0 < nseg; s0 += W) {
+        const int seg = s0 + wave;
+        if (seg < nseg) {                                         // wave-uniform
+            cu32x4_t A[8][3];
+            float xv[8][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const size_t tile = (size_t)co32 * nc16 + seg * 8 + i;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) A[i][pl] = wpk[(tile * 3 + pl) * 64 + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = seg * 128 + i * 16 + lk * 8 + e;
+                    xv[i][e] = tok ? x[(size_t)ci * a.L + li] : 0.0f;
+                }
+            if (a.snake_a) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = seg * 128 + i * 16 + lk * 8 + e;
+                        if (tok) xv[i][e] = snake_f(xv[i][e], a.snake_a[ci], a.snake_ib[ci]);
+                    }
+            }
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cu32x4_t B[3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { uint32_t h, m, l; split3_pair(xv[i][2 * e], xv[i][2 * e + 1], h, m, l); B[0][e] = h; B[1][e] = m; B[2][e] = l; }
+                acc = mfma6(A[i], B, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+        }
+        __syncthreads();
+        const int n = (nseg - s0) < W ? (nseg - s0) : W;
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            for (int q = 0; q < n; ++q) tot[j] = tot[j] + part[q][wave + j * W][lane];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int reg = wave + j * W;
+        const int o = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+        if (o < a.cout && tok) {
+            float v = tot[j] + (a.b ? a.b[o] : 0.0f);
+            if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (a.scale) v = v * a.scale[o];
+            const size_t oi = (size_t)o * a.oL + (size_t)li * a.ostride + a.ooff;
+            if (a.resid) v = a.resid[oi] + v;
+            if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
+            if (a.post_a) {
+                const float va = snake_f(v, a.post_a[o], a.post_ib[o]);
+                if (a.y2) { a.y[oi] = v; a.y2[oi] = va; } else a.y[oi] = va;
+            } else {
+                a.y[oi] = v;
+            }
+        }
+    }
+}
+
 template <int K, int CO_M, int T_M, int WCO, int WT>
 static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
@@ -490,6 +610,12 @@ static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) 
 static hipError_t launch_conv_bf16x3(const ConvDev& a, int phases, hipStream_t st) {
     static const bool off = getenv("Q3_CONV_F32") != nullptr;        // A/B aid: force the f32-MFMA generation
     if (off || !a.wpk || a.cin % 16 || a.cout % 32) return hipErrorNotSupported;
+    static const bool no_small = getenv("Q3_CONV_NO_SMALL") != nullptr;   // A/B aid
+    if (conv_segmented(a.k, a.cin) && a.L <= 32 && phases == 1 && a.cout % 64 == 0 && !no_small) {
+        if (a.cin >= 1024) hipLaunchKernelGGL(k_lin_small_bf16x3<8>, dim3(a.cout / 32), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(k_lin_small_bf16x3<4>, dim3(a.cout / 32), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     switch (a.k) {
         case 1: return launch_bf16x3_k<1>(a, phases, st);
         case 2: return launch_bf16x3_k<2>(a, phases, st);
@@ -581,14 +707,25 @@ hipError_t launch_dwconv7(const float* x, const float* w, const float* b, float*
 
 // channel-wise norms for [C][L] tensors: block = 32 time steps × 8 channel groups
 template <bool LAYERNORM>
-__global__ __launch_bounds__(256) void k_norm_c(const float* x, const float* w, const float* b, float* y, int C, int L,
-                                                float eps) {
+__global__ __launch_bounds__(256) void k_norm_c(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                float* __restrict__ y, int C, int L, float eps) {      // y never aliases x
     __shared__ float s1[8][32], s2[8][32];
     const int tx = threadIdx.x & 31, cg = threadIdx.x >> 5;
     const int t = blockIdx.x * 32 + tx;
     float a = 0.0f, q = 0.0f;
-    if (t < L)
-        for (int c = cg; c < C; c += 8) { const float v = x[(size_t)c * L + t]; a += v; q += v * v; }
+    if (t < L) {
+        // eight loads in flight per thread, summed in channel order (the order — and with it the result — is the same
+        // for every L: the segment-exact decode relies on position-independent arithmetic)
+        int c = cg;
+        for (; c + 56 < C; c += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(c + 8 * u) * L + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += v[u]; q += v[u] * v[u]; }
+        }
+        for (; c < C; c += 8) { const float v = x[(size_t)c * L + t]; a += v; q += v * v; }
+    }
     s1[cg][tx] = a; s2[cg][tx] = q;
     __syncthreads();
     float sum = 0.0f, sq = 0.0f;
@@ -598,9 +735,11 @@ __global__ __launch_bounds__(256) void k_norm_c(const float* x, const float* w, 
     if (LAYERNORM) {
         const float mean = sum / (float)C, var = sq / (float)C - mean * mean;
         const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll 8
         for (int c = cg; c < C; c += 8) y[(size_t)c * L + t] = (x[(size_t)c * L + t] - mean) * inv * w[c] + b[c];
     } else {
         const float den = sqrtf(sq / (float)C + eps);
+#pragma unroll 8
         for (int c = cg; c < C; c += 8) y[(size_t)c * L + t] = x[(size_t)c * L + t] / den * w[c];
     }
 }
