@@ -291,6 +291,54 @@ q3_status q3_codes_write_bin(const char* path, const uint32_t* codes_host, int n
 q3_status q3_codes_read_bin(const char* path, uint32_t* codes_host, int cap_frames, int n_groups, int* n_frames);
 q3_status q3_audio_write_bin(const char* path, const float* samples_host, int64_t n);
 
+/* ---------------- speaker encoder (q3_speaker.hip): x-vector voice cloning ----------------
+ * SpeakerEncoder (models/speaker.rs:345-469) behind create_voice_clone_prompt (lib.rs:1132-1190): 24 kHz mono
+ * reference audio -> log-mel (audio/mel.rs:47-59, 135-227) -> ECAPA-TDNN -> [enc_dim] embedding, the `xvector`
+ * of q3_request. Config = SpeakerEncoderConfig (models/config.rs:100-174), weights = `speaker_encoder.*` of a
+ * Base checkpoint's model.safetensors (kept f32 on the device; bf16/f16 sources are widened on upload).
+ * The ICL half of the prompt (reference codes) needs the Mimi speech encoder, which lives in candle-transformers
+ * (encoder_12hz.rs:23) — not part of this library: pass ref_codes produced elsewhere. */
+typedef struct q3_spk_config {
+    int32_t mel_dim;            /* 128 */
+    int32_t enc_dim;            /* 1024 (0.6B) / 2048 (1.7B): the talker's hidden size */
+    int32_t channels[5];        /* 512,512,512,512,1536 */
+    int32_t kernel_sizes[5];    /* 5,3,3,3,1 */
+    int32_t dilations[5];       /* 1,2,3,4,1 */
+    int32_t attention_channels; /* 128 */
+    int32_t res2net_scale;      /* 8 */
+    int32_t se_channels;        /* 128 */
+    int32_t sample_rate;        /* 24000 */
+} q3_spk_config;
+typedef struct q3_speaker_encoder q3_speaker_encoder;
+/* SpeakerEncoderConfig::default (config.rs:132-174) */
+q3_status q3_spk_config_default(q3_spk_config* out);
+/* `speaker_encoder_config` object of config.json (config.rs:233, serde defaults per field); *present = 0 and the
+ * defaults when the key is absent (CustomVoice / VoiceDesign checkpoints) */
+q3_status q3_spk_config_from_json(const char* path, q3_spk_config* out, int* present);
+/* SpeakerEncoder::new (speaker.rs:362-428): allocates the weight arena for the config's tensor manifest */
+q3_status q3_spk_create(const q3_spk_config* cfg, int device, q3_speaker_encoder** out);
+void q3_spk_free(q3_speaker_encoder* e);
+q3_status q3_spk_get_config(const q3_speaker_encoder* e, q3_spk_config* out);
+int q3_spk_n_tensors(const q3_speaker_encoder* e);
+q3_status q3_spk_tensor_info(const q3_speaker_encoder* e, int i, const char** name, int64_t* n);
+/* data_host: n elements of src_dtype (Q3_DTYPE_F32 / Q3_DTYPE_BF16) */
+q3_status q3_spk_set_tensor(q3_speaker_encoder* e, const char* name, const void* data_host, int src_dtype, int64_t n);
+/* every tensor present -> packs the matrix-core weight images, builds window / DFT / mel-filter tables */
+q3_status q3_spk_finalize(q3_speaker_encoder* e);
+/* uploads every `speaker_encoder.*` tensor of a safetensors file and finalizes; Q3_MISSING_WEIGHT with the
+ * reference's hint (lib.rs:1137-1153) when the file has none */
+q3_status q3_spk_load_safetensors(q3_speaker_encoder* e, const char* path);
+/* frames the mel front end yields for n samples: (n + 2*384 - 1024) / 256 + 1 (mel.rs:168-199) */
+int q3_spk_mel_frames(int64_t n_samples);
+/* MelSpectrogram::compute_for_speaker_encoder (mel.rs:135-166): mel_host [mel_dim][T], T = q3_spk_mel_frames(n) */
+q3_status q3_spk_mel(q3_speaker_encoder* e, const float* samples_host, int64_t n, float* mel_host, int64_t cap_floats, int* n_frames);
+/* SpeakerEncoder::forward (speaker.rs:443-469) for one mel [mel_dim][T]; taps (test hook): NULL or 6 host pointers
+ * (NULL entries skipped): blocks.0 out, the three SE-Res2Net outs [C][T], MFA out [C4][T], pooled [2*C4] */
+q3_status q3_spk_forward(q3_speaker_encoder* e, const float* mel_host, int T, float* out_host, float** taps_host);
+/* SpeakerEncoder::encode (speaker.rs:431-438) = mel + forward; sample_rate must be 24000 (the reference resamples
+ * with rubato first, lib.rs:1156-1166 — resample before calling) */
+q3_status q3_spk_encode(q3_speaker_encoder* e, const float* samples_host, int64_t n, uint32_t sample_rate, float* out_host);
+
 #ifdef __cplusplus
 }
 #endif

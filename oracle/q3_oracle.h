@@ -157,6 +157,33 @@ void q3o_causal_conv1d(const float* x, const float* w, const float* b, float* y,
 void q3o_causal_trans_conv1d(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L, int k, int stride);
 void q3o_snake_beta(const float* x, const float* alpha, const float* beta, float* y, int C, int L);
 
+/* ---- speaker-embedding path (q3_oracle_spk.c): mel.rs:47-59,135-324; speaker.rs:24-469 ---- */
+typedef struct q3o_spk_config {
+    int32_t mel_dim;            /* 128 */
+    int32_t enc_dim;            /* 1024 */
+    int32_t channels[5];        /* 512,512,512,512,1536 */
+    int32_t kernel_sizes[5];    /* 5,3,3,3,1 */
+    int32_t dilations[5];       /* 1,2,3,4,1 */
+    int32_t attention_channels; /* 128 */
+    int32_t res2net_scale;      /* 8 */
+    int32_t se_channels;        /* 128 */
+    int32_t sample_rate;        /* 24000 */
+} q3o_spk_config;
+typedef struct q3o_spk q3o_spk;
+q3o_spk* q3o_spk_new(const q3o_spk_config* cfg);
+void q3o_spk_free(q3o_spk* s);
+int q3o_spk_set_tensor(q3o_spk* s, const char* name, const float* data, int64_t n);
+const char* q3o_spk_last_error(void);
+void q3o_hann_window(int len, float* out);
+void q3o_mel_filterbank(int sample_rate, int n_fft, int n_mels, float fmin, float fmax, float* out /*[n_mels][n_fft/2+1]*/);
+int q3o_mel_frames(int n_samples, int n_fft, int hop);
+/* log-mel for the speaker encoder, out [128][T]; returns T or -1 */
+int q3o_mel_speaker(const float* samples, int n, float* mel, int cap_frames);
+void q3o_reflect_pad_1d(const float* x, int C, int T, int pl, int pr, float* out);
+/* taps (NULL or 6 pointers, NULL entries skipped): 0 blocks.0 out, 1-3 SE-Res2Net outs, 4 MFA out, 5 pooled [2*C4] */
+int q3o_spk_forward(q3o_spk* s, const float* mel /*[mel_dim][T]*/, int T, float* out /*[enc_dim]*/, float** taps);
+int q3o_spk_encode(q3o_spk* s, const float* samples, int n, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,12 @@ class CRequest(ctypes.Structure):
     ]
 
 
+class CSpkConfig(ctypes.Structure):      # q3_spk_config (SpeakerEncoderConfig, config.rs:100-174)
+    _fields_ = [("mel_dim", ctypes.c_int32), ("enc_dim", ctypes.c_int32), ("channels", ctypes.c_int32 * 5),
+                ("kernel_sizes", ctypes.c_int32 * 5), ("dilations", ctypes.c_int32 * 5), ("attention_channels", ctypes.c_int32),
+                ("res2net_scale", ctypes.c_int32), ("se_channels", ctypes.c_int32), ("sample_rate", ctypes.c_int32)]
+
+
 class CTiming(ctypes.Structure):
     _fields_ = [("prefill_ms", ctypes.c_double), ("generation_ms", ctypes.c_double), ("decode_ms", ctypes.c_double),
                 ("generation_frames", ctypes.c_int32)]
@@ -100,6 +106,20 @@ SYMBOLS = {
     "q3_codes_write_bin": (c_int, [c_char_p, c_void_p, c_int, c_int]),
     "q3_codes_read_bin": (c_int, [c_char_p, c_void_p, c_int, c_int, P(c_int)]),
     "q3_audio_write_bin": (c_int, [c_char_p, c_void_p, ctypes.c_int64]),
+    "q3_spk_config_default": (c_int, [P(CSpkConfig)]),
+    "q3_spk_config_from_json": (c_int, [c_char_p, P(CSpkConfig), P(c_int)]),
+    "q3_spk_create": (c_int, [P(CSpkConfig), c_int, P(c_void_p)]),
+    "q3_spk_free": (None, [c_void_p]),
+    "q3_spk_get_config": (c_int, [c_void_p, P(CSpkConfig)]),
+    "q3_spk_n_tensors": (c_int, [c_void_p]),
+    "q3_spk_tensor_info": (c_int, [c_void_p, c_int, P(c_char_p), P(ctypes.c_int64)]),
+    "q3_spk_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int, ctypes.c_int64]),
+    "q3_spk_finalize": (c_int, [c_void_p]),
+    "q3_spk_load_safetensors": (c_int, [c_void_p, c_char_p]),
+    "q3_spk_mel_frames": (c_int, [ctypes.c_int64]),
+    "q3_spk_mel": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, P(c_int)]),
+    "q3_spk_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, P(c_void_p)]),
+    "q3_spk_encode": (c_int, [c_void_p, c_void_p, ctypes.c_int64, ctypes.c_uint32, c_void_p]),
 }
 
 for _name, (_res, _args) in SYMBOLS.items():

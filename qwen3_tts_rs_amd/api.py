@@ -363,7 +363,61 @@ class Qwen3TTS:
         check(lib.q3_model_config(h, ctypes.byref(c)))
         m = cls(Q3Config.from_c(c), device, _handle=h)
         m.model_type = ModelType(mt.value) if mt.value >= 0 else None
+        # Base checkpoints carry `speaker_encoder.*` (lib.rs:233-249): attach the encoder when the keys are there
+        import os
+        from .speaker import SpeakerEncoder, SpeakerEncoderConfig
+        st = os.path.join(str(model_dir), "model.safetensors")
+        probe = ctypes.c_int()
+        if device >= 0 and lib.q3_safetensors_info(st.encode(), b"speaker_encoder.fc.weight", ctypes.byref(probe), None, 0, None) == 0:
+            cfg_path = os.path.join(str(model_dir), "config.json")
+            scfg = SpeakerEncoderConfig.from_json(cfg_path)[0] if os.path.exists(cfg_path) else SpeakerEncoderConfig(enc_dim=m.config.hidden)
+            m.attach_speaker_encoder(SpeakerEncoder.from_safetensors(st, scfg, device))
         return m
+
+    # ---- voice cloning front end (lib.rs:1049-1190) ----
+    speaker_encoder = None       # SpeakerEncoder, attached by from_pretrained for Base checkpoints / attach_speaker_encoder
+
+    def attach_speaker_encoder(self, enc):
+        if enc.config.enc_dim != self.config.hidden:
+            raise ValueError(f"speaker embedding dim {enc.config.enc_dim} != talker hidden size {self.config.hidden}")
+        self.speaker_encoder = enc
+
+    def supports_voice_cloning(self) -> bool:          # lib.rs:390-396
+        return self.model_type in (None, ModelType.Base)
+
+    def has_speaker_encoder(self) -> bool:
+        return self.speaker_encoder is not None
+
+    def has_speech_encoder(self) -> bool:              # lib.rs:1049-1051 — the Mimi encoder is not part of this library
+        return False
+
+    def create_voice_clone_prompt(self, ref_audio: "AudioBuffer", ref_text_ids=None, ref_codes=None):
+        """create_voice_clone_prompt (lib.rs:1132-1190). x_vector_only when `ref_text_ids` is None. The ICL variant needs
+        the reference audio's codec frames: the reference computes them with the Mimi encoder of candle-transformers
+        (encoder_12hz.rs:23), which this library does not contain — pass `ref_codes` computed elsewhere."""
+        from .speaker import VoiceClonePrompt
+        if self.speaker_encoder is None:
+            hint = {ModelType.CustomVoice: " CustomVoice models use preset speakers (synthesize_with_voice), not voice cloning. "
+                                           "Use a Base model for voice cloning.",
+                    ModelType.VoiceDesign: " VoiceDesign models use text-described voices, not voice cloning. "
+                                           "Use a Base model for voice cloning."}.get(
+                self.model_type, " Ensure model weights contain `speaker_encoder.*` keys (only Base models include a speaker encoder).")
+            raise _lib.Q3Error(3, "Speaker encoder not available." + hint)
+        if ref_audio.sample_rate != 24000:
+            raise _lib.Q3Error(7, f"reference audio is {ref_audio.sample_rate} Hz: resample to 24000 Hz first "
+                                  "(the reference uses rubato for this, lib.rs:1156-1166; not part of this library)")
+        emb = self.speaker_encoder.encode(ref_audio.samples, ref_audio.sample_rate)
+        if ref_text_ids is None:
+            return VoiceClonePrompt(emb)
+        if ref_codes is None:
+            raise _lib.Q3Error(7, "ICL voice cloning requires a speech encoder, but it was not loaded. Pass ref_codes, or use "
+                                  "x_vector_only mode by passing ref_text_ids=None.")
+        return VoiceClonePrompt(emb, np.ascontiguousarray(ref_codes, dtype=np.uint32), np.asarray(ref_text_ids, dtype=np.uint32))
+
+    def synthesize_voice_clone_prompt(self, text_ids, prompt, language: "Language", options=None):
+        """synthesize_voice_clone (lib.rs:1202-1262) with a VoiceClonePrompt."""
+        return self.synthesize_voice_clone(text_ids, prompt.speaker_embedding, language, options,
+                                           ref_codes=prompt.ref_codes, ref_text_ids=prompt.ref_text_ids)
 
     def supports_preset_speakers(self) -> bool:        # lib.rs:398-404 (permissive when unknown)
         return self.model_type in (None, ModelType.CustomVoice)

@@ -67,9 +67,23 @@ def main(argv=None) -> int:
     import qwen3_tts_rs_amd as q
     from qwen3_tts_rs_amd import api
     from qwen3_tts_rs_amd.text import TextTokenizer
-    if a.ref_audio:
-        print("error: --ref-audio needs the speaker / speech encoders, which are not part of this engine; pass "
-              "--xvector-npy (and --ref-codes-bin + --ref-text for ICL) produced by the reference instead", file=sys.stderr)
+    # flag validation of generate_audio.rs:163-210
+    if a.instruct and a.ref_audio:
+        print("error: --instruct and --ref-audio are mutually exclusive.\n  --instruct is for VoiceDesign models (text-described voices).\n"
+              "  --ref-audio is for Base models (voice cloning from reference audio).", file=sys.stderr)
+        return 2
+    if a.ref_text and not (a.ref_audio or a.xvector_npy):
+        print("error: --ref-text requires --ref-audio (reference text is the transcript of the reference audio for ICL voice cloning)", file=sys.stderr)
+        return 2
+    if a.x_vector_only and not (a.ref_audio or a.xvector_npy):
+        print("error: --x-vector-only requires --ref-audio (x_vector_only is a voice cloning mode)", file=sys.stderr)
+        return 2
+    if a.x_vector_only and a.ref_text:
+        print("error: --x-vector-only and --ref-text are contradictory.\n  x_vector_only uses only the speaker embedding (no ICL).", file=sys.stderr)
+        return 2
+    if a.ref_audio and a.ref_text and not a.ref_codes_bin:
+        print("error: ICL voice cloning (--ref-audio + --ref-text) needs the reference audio's codec frames; the Mimi speech encoder "
+              "is not part of this engine — pass --ref-codes-bin (codes_*.bin written by the reference), or use --x-vector-only", file=sys.stderr)
         return 2
     dev = parse_device(a.device)
     speaker, language = q.Speaker.from_str(a.speaker), q.Language.from_str(a.language)
@@ -78,6 +92,9 @@ def main(argv=None) -> int:
     if a.synthetic:
         cfg = {"tiny": q.tiny, "0.6b": q.qwen3_tts_0_6b, "1.7b": q.qwen3_tts_1_7b}[a.synthetic]()
         model = q.Qwen3TTS.from_synthetic(cfg, device=dev)
+        if a.ref_audio:      # a Base-style synthetic model: seeded ECAPA-TDNN of the matching embedding width
+            scfg = q.tiny_speaker_config(cfg.hidden) if a.synthetic == "tiny" else q.SpeakerEncoderConfig(enc_dim=cfg.hidden)
+            model.attach_speaker_encoder(q.SpeakerEncoder.from_synthetic(scfg, device=dev))
         tok = TextTokenizer.from_pretrained(None, a.tokenizer_dir)
     else:
         model = q.Qwen3TTS.from_pretrained(a.model_dir, device=dev)
@@ -91,8 +108,18 @@ def main(argv=None) -> int:
     utt = q.Utterance(ids, speaker, language, seed=a.seed)
     if a.instruct or a.instruct_ids:
         utt.instruct_ids = [int(x) for x in a.instruct_ids.split(",")] if a.instruct_ids else tok.encode(a.instruct)
-    if a.xvector_npy:
+    if a.ref_audio:          # run_voice_clone (generate_audio.rs:213-300): speaker embedding from the reference WAV
+        ref = api.AudioBuffer.load(a.ref_audio)
+        print(f"Reference audio: {a.ref_audio} ({ref.duration():.2f}s, {ref.sample_rate} Hz)")
+        print("Mode: ICL (reference codes + text)" if a.ref_text else "Mode: x_vector_only (no reference text)")
+        try:
+            utt.xvector = model.create_voice_clone_prompt(ref).speaker_embedding
+        except api._lib.Q3Error as e:
+            print(f"error: {e}", file=sys.stderr)
+            return 2
+    elif a.xvector_npy:
         utt.xvector = np.load(a.xvector_npy).astype(np.float32).reshape(-1)
+    if utt.xvector is not None:
         if a.ref_codes_bin and not a.x_vector_only:
             utt.ref_codes = api.load_codes_binary(a.ref_codes_bin)
             utt.ref_text_ids = tok.encode(a.ref_text or "")

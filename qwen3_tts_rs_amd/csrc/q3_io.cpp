@@ -360,6 +360,78 @@ extern "C" q3_status q3_config_from_json(const char* path, q3_config* out, int* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// speaker encoder: config.json `speaker_encoder_config` (config.rs:100-174, 233) and its tensors
+// ------------------------------------------------------------------------------------------------
+extern "C" q3_status q3_spk_config_from_json(const char* path, q3_spk_config* out, int* present) {
+    if (!path || !out) return q3i_set_err(Q3_INVALID_ARG, "q3_spk_config_from_json: null argument");
+    std::string text;
+    if (!read_file(path, text)) return q3i_set_err(Q3_IO, "Failed to read config from %s", path);
+    JVal v; std::string err;
+    if (!parse_json(text.data(), text.size(), v, err)) return q3i_set_err(Q3_IO, "Failed to parse config from %s (%s)", path, err.c_str());
+    Q3I_CHECK(q3_spk_config_default(out));
+    const JVal* sc = v.get("speaker_encoder_config");
+    if (present) *present = (sc && sc->kind == JVal::OBJ) ? 1 : 0;
+    if (!sc || sc->kind != JVal::OBJ) return Q3_OK;
+    out->mel_dim = (int32_t)sc->u64_or("mel_dim", out->mel_dim);
+    out->enc_dim = (int32_t)sc->u64_or("enc_dim", out->enc_dim);
+    out->attention_channels = (int32_t)sc->u64_or("enc_attention_channels", out->attention_channels);
+    out->res2net_scale = (int32_t)sc->u64_or("enc_res2net_scale", out->res2net_scale);
+    out->se_channels = (int32_t)sc->u64_or("enc_se_channels", out->se_channels);
+    out->sample_rate = (int32_t)sc->u64_or("sample_rate", out->sample_rate);
+    auto arr5 = [&](const char* key, int32_t* dst) -> q3_status {
+        const JVal* a = sc->get(key);
+        if (!a) return Q3_OK;                              // serde default
+        if (a->kind != JVal::ARR || a->arr.size() != 5) return q3i_set_err(Q3_UNSUPPORTED, "%s: speaker_encoder_config.%s must list 5 blocks", path, key);
+        for (int i = 0; i < 5; ++i) {
+            if (a->arr[(size_t)i].kind != JVal::NUM || !a->arr[(size_t)i].is_int) return q3i_set_err(Q3_IO, "%s: speaker_encoder_config.%s: not an integer list", path, key);
+            dst[i] = (int32_t)a->arr[(size_t)i].inum;
+        }
+        return Q3_OK;
+    };
+    Q3I_CHECK(arr5("enc_channels", out->channels));
+    Q3I_CHECK(arr5("enc_kernel_sizes", out->kernel_sizes));
+    Q3I_CHECK(arr5("enc_dilations", out->dilations));
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_spk_load_safetensors(q3_speaker_encoder* enc, const char* path) {
+    if (!enc || !path) return q3i_set_err(Q3_INVALID_ARG, "q3_spk_load_safetensors: null argument");
+    StFile f; Q3I_CHECK(st_open(path, f));
+    bool any = false;
+    for (auto& kv : f.entries) if (kv.first.rfind("speaker_encoder.", 0) == 0) { any = true; break; }
+    if (!any)   // the reference's hint when the encoder is absent (lib.rs:1137-1153)
+        return q3i_set_err(Q3_MISSING_WEIGHT, "Speaker encoder not available. Ensure model weights contain `speaker_encoder.*` keys "
+                                              "(only Base models include a speaker encoder).");
+    const int nt = q3_spk_n_tensors(enc);
+    for (int i = 0; i < nt; ++i) {
+        const char* name; int64_t n_expect;
+        Q3I_CHECK(q3_spk_tensor_info(enc, i, &name, &n_expect));
+        const StEntry* e = f.find(name);
+        if (!e) return q3i_set_err(Q3_MISSING_WEIGHT, "Missing weight: %s", name);
+        int64_t n = 1;
+        for (int64_t d : e->shape) n *= d;
+        const int es = dtype_size(e->dtype);
+        if (!es) return q3i_set_err(Q3_UNSUPPORTED, "%s: tensor %s has unsupported dtype %s", path, name, e->dtype.c_str());
+        if ((uint64_t)n * (uint64_t)es != e->e - e->b) return q3i_set_err(Q3_IO, "%s: tensor %s: shape does not match its byte range", path, name);
+        if (n != n_expect)
+            return q3i_set_err(Q3_INVALID_ARG, "%s: tensor %s has %lld elements, expected %lld (speaker_encoder_config mismatch?)", path, name,
+                               (long long)n, (long long)n_expect);
+        const uint8_t* src = f.data + e->b;
+        if (e->dtype == "F32") { Q3I_CHECK(q3_spk_set_tensor(enc, name, src, Q3_DTYPE_F32, n)); continue; }
+        if (e->dtype == "BF16") { Q3I_CHECK(q3_spk_set_tensor(enc, name, src, Q3_DTYPE_BF16, n)); continue; }
+        std::vector<float> tmp((size_t)n);
+        if (e->dtype == "F16") {
+            const uint16_t* h = (const uint16_t*)src;
+            for (int64_t j = 0; j < n; ++j) tmp[(size_t)j] = f16_to_f32(h[j]);
+        } else {
+            for (int64_t j = 0; j < n; ++j) { double d; memcpy(&d, src + 8 * j, 8); tmp[(size_t)j] = (float)d; }
+        }
+        Q3I_CHECK(q3_spk_set_tensor(enc, name, tmp.data(), Q3_DTYPE_F32, n));
+    }
+    return q3_spk_finalize(enc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // safetensors → model
 // ------------------------------------------------------------------------------------------------
 extern "C" q3_status q3_model_load_safetensors(q3_model* m, const char* path, int* n_loaded) {

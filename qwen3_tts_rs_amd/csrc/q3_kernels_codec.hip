@@ -41,6 +41,16 @@ __device__ __forceinline__ float snake_f(float x, float a, float ib) { return __
 // ------------------------------------------------------------------------------------------------
 constexpr int CV_CO = 32, CV_T = 128, CV_CI = 16, CV_MAXK = 7, CV_MAXHALO = 54;
 
+// epilogue activations: 1 GELU(erf) (ConvNeXt), 2 clamp (applied after the residual, see the kernels), and the speaker
+// encoder's (speaker.rs:53-61, 136-138, 327-329): 3 ReLU, 4 ReLU then tanh, 5 sigmoid = 1 / (exp(-x) + 1)
+__device__ __forceinline__ float conv_act(float v, int act) {
+    if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 3) return fmaxf(v, 0.0f);
+    if (act == 4) return tanhf(fmaxf(v, 0.0f));
+    if (act == 5) return 1.0f / (expf(-v) + 1.0f);
+    return v;
+}
+
 struct ConvDev {
     const float* x; const float* w; const float* b; float* y;
     int cin, cout, L, k, dil;
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void k_conv1d(ConvDev a) {
             const int t = t0 + tx + 32 * j;
             if (t >= a.L) continue;
             float v = acc[i][j] + bias;
-            if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            v = conv_act(v, a.act);
             if (a.scale) v = v * sc;
             const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
             if (a.resid) v = a.resid[oi] + v;
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvDev a) {
             const int o = co0 + wco * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
             if (o >= a.cout || t >= a.L) continue;
             float v = (half == 0 ? acc0[reg] : acc1[reg]) + (a.b ? a.b[o] : 0.0f);
-            if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            v = conv_act(v, a.act);
             if (a.scale) v = v * a.scale[o];
             const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
             if (a.resid) v = a.resid[oi] + v;
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
                 const int t = t0 + wt * (32 * T_M) + tm * 32 + li;
                 if (ook && t < a.L) {
                     float v = acc[cm][tm][reg] + bias;
-                    if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    v = conv_act(v, a.act);
                     if (a.scale) v = v * sc;
                     const size_t oi = (size_t)o * a.oL + (size_t)t * a.ostride + ooff;
                     if (a.resid) v = (PRE ? rs[PRE ? tm : 0][reg] : a.resid[oi]) + v;
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
         const int o = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
         if (o < a.cout && tok) {
             float v = tot[j] + (a.b ? a.b[o] : 0.0f);
-            if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            v = conv_act(v, a.act);
             if (a.scale) v = v * a.scale[o];
             const size_t oi = (size_t)o * a.oL + (size_t)li * a.ostride + a.ooff;
             if (a.resid) v = a.resid[oi] + v;
@@ -620,6 +630,7 @@ static hipError_t launch_conv_bf16x3(const ConvDev& a, int phases, hipStream_t s
         case 1: return launch_bf16x3_k<1>(a, phases, st);
         case 2: return launch_bf16x3_k<2>(a, phases, st);
         case 3: return launch_bf16x3_k<3>(a, phases, st);
+        case 5: return launch_bf16x3_k<5>(a, phases, st);     // speaker encoder front TDNN
         case 7: return launch_bf16x3_k<7>(a, phases, st);
         default: return hipErrorNotSupported;
     }

@@ -60,7 +60,7 @@ def rel_err(a, b):
 
 
 def write_checkpoint_dir(cfg, root, seed=synth.DEFAULT_SEED, with_config=True, model_type="custom_voice",
-                         f16_names=(), extra=True):
+                         f16_names=(), extra=True, speaker_cfg=None):
     """Write a synthetic checkpoint in the reference's on-disk layout (lib.rs:180-262) with the independent
     `safetensors` package: <root>/config.json, <root>/model.safetensors (bf16 talker + code predictor),
     <root>/speech_tokenizer/model.safetensors (f32 decoder). Tensors named in `f16_names` are stored as F16
@@ -86,7 +86,17 @@ def write_checkpoint_dir(cfg, root, seed=synth.DEFAULT_SEED, with_config=True, m
         raw[name] = (arr, dt)
         (dec if name.startswith("decoder.") else main)[name] = t
     _lib.lib.q3_model_free(h)
-    if extra:
+    spk_raw = {}
+    if speaker_cfg is not None:
+        # Base checkpoints hold the ECAPA-TDNN under speaker_encoder.* in the main file, bf16 like everything else there
+        from qwen3_tts_rs_amd.speaker import SpeakerEncoder, synthetic_speaker_checkpoint
+        enc = SpeakerEncoder(speaker_cfg, device=-1)
+        for name, arr in synthetic_speaker_checkpoint(enc, seed):
+            b = synth.f32_to_bf16(arr)
+            spk_raw[name] = synth.bf16_to_f32(b)
+            main[name] = torch.from_numpy(b.view(np.int16).copy()).view(torch.bfloat16)
+        enc.close()
+    elif extra:
         main["speaker_encoder.blocks.0.conv.weight"] = torch.zeros(4, 3, 5)
         dec["encoder.downsample.conv.weight"] = torch.ones(2, 2, dtype=torch.float64)
     save_file(main, os.path.join(root, "model.safetensors"), metadata={"format": "pt"})
@@ -110,6 +120,14 @@ def write_checkpoint_dir(cfg, root, seed=synth.DEFAULT_SEED, with_config=True, m
                 },
             },
         }
+        if speaker_cfg is not None:
+            conf["speaker_encoder_config"] = {
+                "mel_dim": speaker_cfg.mel_dim, "enc_dim": speaker_cfg.enc_dim, "enc_channels": speaker_cfg.enc_channels,
+                "enc_kernel_sizes": speaker_cfg.enc_kernel_sizes, "enc_dilations": speaker_cfg.enc_dilations,
+                "enc_attention_channels": speaker_cfg.enc_attention_channels, "enc_res2net_scale": speaker_cfg.enc_res2net_scale,
+                "enc_se_channels": speaker_cfg.enc_se_channels, "sample_rate": speaker_cfg.sample_rate}
         with open(os.path.join(root, "config.json"), "w") as f:
             json.dump(conf, f, indent=2)
+    if speaker_cfg is not None:
+        return raw, spk_raw
     return raw

@@ -12,8 +12,8 @@ LIB = os.path.join(ORACLE_DIR, "libq3oracle.so")
 
 
 def build_oracle():
-    src = os.path.join(ORACLE_DIR, "q3_oracle.c")
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("q3_oracle.c", "q3_oracle_spk.c", "q3_oracle.h")]
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libq3oracle.so"], stdout=subprocess.DEVNULL)
 
 
@@ -274,3 +274,91 @@ class OracleSession:
         codes = np.zeros(15, dtype=np.uint32); lg = np.zeros((15, self.cfg.cp_vocab), dtype=np.float32)
         olib.q3o_session_cp_generate(self.h, ptr(lh), ptr(se), ptr(codes), ptr(lg))
         return codes, lg
+
+
+# ---- speaker-embedding path (oracle/q3_oracle_spk.c) ----
+class OSpkConfig(ctypes.Structure):
+    _fields_ = [("mel_dim", ctypes.c_int32), ("enc_dim", ctypes.c_int32), ("channels", ctypes.c_int32 * 5),
+                ("kernel_sizes", ctypes.c_int32 * 5), ("dilations", ctypes.c_int32 * 5), ("attention_channels", ctypes.c_int32),
+                ("res2net_scale", ctypes.c_int32), ("se_channels", ctypes.c_int32), ("sample_rate", ctypes.c_int32)]
+
+
+olib.q3o_spk_new.restype = vp; olib.q3o_spk_new.argtypes = [ctypes.POINTER(OSpkConfig)]
+olib.q3o_spk_free.argtypes = [vp]
+olib.q3o_spk_set_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_int64]
+olib.q3o_spk_last_error.restype = ctypes.c_char_p
+olib.q3o_hann_window.argtypes = [ci, vp]
+olib.q3o_mel_filterbank.argtypes = [ci, ci, ci, ctypes.c_float, ctypes.c_float, vp]
+olib.q3o_mel_frames.argtypes = [ci, ci, ci]
+olib.q3o_mel_speaker.argtypes = [vp, ci, vp, ci]
+olib.q3o_reflect_pad_1d.argtypes = [vp, ci, ci, ci, ci, vp]
+olib.q3o_spk_forward.argtypes = [vp, vp, ci, vp, ctypes.POINTER(vp)]
+olib.q3o_spk_encode.argtypes = [vp, vp, ci, vp]
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def hann_window(n):
+    out = np.empty(n, np.float32); olib.q3o_hann_window(n, _fp(out)); return out
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    out = np.empty((n_mels, n_fft // 2 + 1), np.float32)
+    olib.q3o_mel_filterbank(sr, n_fft, n_mels, fmin, fmax, _fp(out)); return out
+
+
+def mel_speaker(samples):
+    x = np.ascontiguousarray(samples, np.float32)
+    T = olib.q3o_mel_frames(x.size, 1024, 256)
+    out = np.empty((128, T), np.float32)
+    assert olib.q3o_mel_speaker(_fp(x), x.size, _fp(out), T) == T
+    return out
+
+
+def reflect_pad_1d(x, pl, pr):
+    x = np.ascontiguousarray(x, np.float32); C, T = x.shape
+    out = np.empty((C, T + pl + pr), np.float32)
+    olib.q3o_reflect_pad_1d(_fp(x), C, T, pl, pr, _fp(out)); return out
+
+
+class OracleSpeakerEncoder:
+    def __init__(self, cfg):
+        """cfg: qwen3_tts_rs_amd.SpeakerEncoderConfig"""
+        c = OSpkConfig()
+        c.mel_dim, c.enc_dim = cfg.mel_dim, cfg.enc_dim
+        for i in range(5):
+            c.channels[i] = cfg.enc_channels[i]; c.kernel_sizes[i] = cfg.enc_kernel_sizes[i]; c.dilations[i] = cfg.enc_dilations[i]
+        c.attention_channels, c.res2net_scale, c.se_channels, c.sample_rate = cfg.enc_attention_channels, cfg.enc_res2net_scale, cfg.enc_se_channels, cfg.sample_rate
+        self.cfg = cfg
+        self._h = olib.q3o_spk_new(ctypes.byref(c))
+
+    def set_tensor(self, name, arr):
+        a = np.ascontiguousarray(arr, np.float32)
+        assert olib.q3o_spk_set_tensor(self._h, name.encode(), _fp(a), a.size) == 0
+
+    def forward(self, mel, taps=False):
+        m = np.ascontiguousarray(mel, np.float32); T = m.shape[1]
+        out = np.empty(self.cfg.enc_dim, np.float32)
+        c = self.cfg
+        tl = None; tp = None
+        if taps:
+            tl = [np.empty((c.enc_channels[0], T), np.float32)] + [np.empty((c.enc_channels[i], T), np.float32) for i in (1, 2, 3)] + \
+                 [np.empty((c.enc_channels[4], T), np.float32), np.empty(2 * c.enc_channels[4], np.float32)]
+            tp = (vp * 6)(*[_fp(t) for t in tl])
+        rc = olib.q3o_spk_forward(self._h, _fp(m), T, _fp(out), tp)
+        if rc != 0:
+            raise RuntimeError(olib.q3o_spk_last_error().decode())
+        return (out, tl) if taps else out
+
+    def encode(self, samples):
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.empty(self.cfg.enc_dim, np.float32)
+        if olib.q3o_spk_encode(self._h, _fp(x), x.size, _fp(out)) != 0:
+            raise RuntimeError(olib.q3o_spk_last_error().decode())
+        return out
+
+    def close(self):
+        if self._h and olib is not None:
+            olib.q3o_spk_free(self._h); self._h = None

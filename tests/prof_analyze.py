@@ -8,14 +8,19 @@ for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                  int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)))
 rows.sort()
-# steady state = the longest run of kernels whose gaps are all < 100 us (the graph-replayed frame loop)
-best = (0, 0); i0 = 0
-for i in range(1, len(rows) + 1):
-    if i == len(rows) or rows[i][0] - rows[i - 1][1] > 100_000:
-        if i - i0 > best[1] - best[0]:
-            best = (i0, i)
-        i0 = i
-seg = rows[best[0]:best[1]]
+# steady state = the graph-replayed frame loop: from the third sampler launch to the last one (one k_sample per frame);
+# traces without a sampler fall back to the longest run of kernels whose gaps are all < 100 us
+samp = [i for i, r in enumerate(rows) if "k_sample" in r[2]]
+if len(samp) > 8:
+    seg = rows[samp[2] + 1:samp[-1] + 1]
+else:
+    best = (0, 0); i0 = 0
+    for i in range(1, len(rows) + 1):
+        if i == len(rows) or rows[i][0] - rows[i - 1][1] > 100_000:
+            if i - i0 > best[1] - best[0]:
+                best = (i0, i)
+            i0 = i
+    seg = rows[best[0]:best[1]]
 span = seg[-1][1] - seg[0][0]
 busy = sum(e - s for s, e, *_ in seg)
 gaps = [seg[i + 1][0] - seg[i][1] for i in range(len(seg) - 1)]

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from qwen3_tts_rs_amd import cli
+from qwen3_tts_rs_amd import api, cli
 from qwen3_tts_rs_amd.text import TextTokenizer
 
 
@@ -56,7 +56,17 @@ def test_cli_end_to_end_synthetic(tmp_path):
                    "--output-dir", str(tmp_path / "o2"), "--language", "de", "--speaker", "vivian", "--streaming"])
     assert rc == 0
     np.testing.assert_array_equal(np.fromfile(tmp_path / "o2" / "codes_seed7_frames9.bin", dtype="<i8").reshape(9, 16), codes)
-    assert cli.main(["--synthetic", "tiny", "--ref-audio", "x.wav"]) == 2
+    # voice cloning from a reference WAV (generate_audio.rs:213-300), x_vector_only; flag rules of :163-210
+    t = np.arange(24000 * 2) / 24000.0
+    api.save_wav(str(tmp_path / "ref.wav"), (0.4 * np.sin(2 * np.pi * 200 * t) * (0.6 + 0.4 * np.sin(7 * t))).astype(np.float32))
+    rc = cli.main(["--synthetic", "tiny", "--text", "The quick brown fox", "--frames", "5", "--no-eos", "--seed", "7",
+                   "--output-dir", str(tmp_path / "o3"), "--ref-audio", str(tmp_path / "ref.wav"), "--x-vector-only"])
+    assert rc == 0
+    c3 = np.fromfile(tmp_path / "o3" / "codes_seed7_frames5.bin", dtype="<i8").reshape(5, 16)
+    assert not np.array_equal(c3, codes[:5])          # the speaker embedding conditions the prefill
+    assert cli.main(["--synthetic", "tiny", "--ref-audio", str(tmp_path / "ref.wav"), "--ref-text", "hi"]) == 2      # ICL: no Mimi encoder here
+    assert cli.main(["--synthetic", "tiny", "--ref-audio", "x.wav", "--instruct", "deep voice"]) == 2
+    assert cli.main(["--synthetic", "tiny", "--x-vector-only"]) == 2 and cli.main(["--synthetic", "tiny", "--ref-text", "hi"]) == 2
 
 
 @pytest.mark.gpu
