@@ -454,7 +454,10 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
         return hipGetLastError();
     }
     if (force == 8) big = false; else if (force == 16) big = true;
-    if (force == 4) { hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4>), dim3(tiles), dim3(4 * 64), 0, st, a); return hipGetLastError(); }
+    // the two-matrix SwiGLU tile at K = 2048 (talker gate/up, 50 MB): 4 waves — three workgroups fit a CU and the stream
+    // keeps more bytes in flight: 14.1 us at M = 8 against 15.9 (8 waves) / 16.5 (16 waves); M = 1: 13.3 / 14.4 / 15.8
+    const bool four = force == 4 || (force == 0 && EPI == EPI_SWIGLU && S == 64 && tiles >= 256);
+    if (four) { hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4>), dim3(tiles), dim3(4 * 64), 0, st, a); return hipGetLastError(); }
     if (big) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16>), dim3(tiles), dim3(16 * 64), 0, st, a);
     else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8>), dim3(tiles), dim3(8 * 64), 0, st, a);
     return hipGetLastError();
