@@ -449,7 +449,10 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     bool big = S >= 96;
     static const int force = [] { const char* e = getenv("Q3_GEMV_WAVES"); return e ? atoi(e) : 0; }();   // tuning aid
     const bool lds_ok = a.K % 4 == 0 && S >= 8;
-    if (lds_ok && (force == 1 || (force == 0 && tiles < 256 && S > 32 && S <= 64))) {
+    // long-K projections (down-proj, S >= 96) beyond 8 tokens: the LDS-staged kernel is flat in M where the
+    // register-direct one pays for every x row (talker down M = 16: 14.2 vs 16.2 us; code-predictor down 7.9 vs 8.8)
+    const bool lds_pick = (tiles < 256 && S > 32 && S <= 64) || (a.M > 8 && S >= 96);
+    if (lds_ok && (force == 1 || (force == 0 && lds_pick))) {
         hipLaunchKernelGGL((k_gemv_lds<EPI, RMS>), dim3(tiles), dim3(512), 0, st, a);
         return hipGetLastError();
     }
