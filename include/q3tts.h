@@ -290,6 +290,10 @@ q3_status q3_wav_read(const char* path, float* out_host, int64_t cap, int64_t* n
 q3_status q3_codes_write_bin(const char* path, const uint32_t* codes_host, int n_frames, int n_groups);
 q3_status q3_codes_read_bin(const char* path, uint32_t* codes_host, int cap_frames, int n_groups, int* n_frames);
 q3_status q3_audio_write_bin(const char* path, const float* samples_host, int64_t n);
+/* audio::resample / resample_to_24k (audio/resample.rs:17-176): windowed-sinc low-pass with rubato's parameters
+ * (sinc_len 128, cutoff 0.95, BlackmanHarris2), output i at input time i * sr_in / sr_out; out_host = NULL queries
+ * *n_out = round(n * sr_out / sr_in). Host arithmetic (once per reference clip). */
+q3_status q3_resample(const float* in_host, int64_t n, uint32_t sr_in, uint32_t sr_out, float* out_host, int64_t cap, int64_t* n_out);
 
 /* ---------------- speaker encoder (q3_speaker.hip): x-vector voice cloning ----------------
  * SpeakerEncoder (models/speaker.rs:345-469) behind create_voice_clone_prompt (lib.rs:1132-1190): 24 kHz mono
@@ -336,7 +340,7 @@ q3_status q3_spk_mel(q3_speaker_encoder* e, const float* samples_host, int64_t n
  * (NULL entries skipped): blocks.0 out, the three SE-Res2Net outs [C][T], MFA out [C4][T], pooled [2*C4] */
 q3_status q3_spk_forward(q3_speaker_encoder* e, const float* mel_host, int T, float* out_host, float** taps_host);
 /* SpeakerEncoder::encode (speaker.rs:431-438) = mel + forward; sample_rate must be 24000 (the reference resamples
- * with rubato first, lib.rs:1156-1166 — resample before calling) */
+ * first, lib.rs:1156-1166 — q3_resample before calling) */
 q3_status q3_spk_encode(q3_speaker_encoder* e, const float* samples_host, int64_t n, uint32_t sample_rate, float* out_host);
 
 #ifdef __cplusplus

@@ -106,6 +106,7 @@ SYMBOLS = {
     "q3_codes_write_bin": (c_int, [c_char_p, c_void_p, c_int, c_int]),
     "q3_codes_read_bin": (c_int, [c_char_p, c_void_p, c_int, c_int, P(c_int)]),
     "q3_audio_write_bin": (c_int, [c_char_p, c_void_p, ctypes.c_int64]),
+    "q3_resample": (c_int, [c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32, c_void_p, ctypes.c_int64, P(ctypes.c_int64)]),
     "q3_spk_config_default": (c_int, [P(CSpkConfig)]),
     "q3_spk_config_from_json": (c_int, [c_char_p, P(CSpkConfig), P(c_int)]),
     "q3_spk_create": (c_int, [P(CSpkConfig), c_int, P(c_void_p)]),

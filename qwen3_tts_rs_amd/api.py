@@ -403,9 +403,8 @@ class Qwen3TTS:
                                            "Use a Base model for voice cloning."}.get(
                 self.model_type, " Ensure model weights contain `speaker_encoder.*` keys (only Base models include a speaker encoder).")
             raise _lib.Q3Error(3, "Speaker encoder not available." + hint)
-        if ref_audio.sample_rate != 24000:
-            raise _lib.Q3Error(7, f"reference audio is {ref_audio.sample_rate} Hz: resample to 24000 Hz first "
-                                  "(the reference uses rubato for this, lib.rs:1156-1166; not part of this library)")
+        if ref_audio.sample_rate != 24000:        # both encoders assume 24 kHz input (lib.rs:1156-1166)
+            ref_audio = resample_to_24k(ref_audio)
         emb = self.speaker_encoder.encode(ref_audio.samples, ref_audio.sample_rate)
         if ref_text_ids is None:
             return VoiceClonePrompt(emb)
@@ -553,6 +552,21 @@ def load_wav(path: str) -> AudioBuffer:
     out = np.empty(n.value, dtype=np.float32)
     check(lib.q3_wav_read(str(path).encode(), out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(n), ctypes.byref(rate)))
     return AudioBuffer(out, int(rate.value))
+
+
+def resample(audio: AudioBuffer, target_rate: int) -> AudioBuffer:
+    """audio::resample (audio/resample.rs:164-171): windowed-sinc resampling (q3_resample); a copy when rates match."""
+    x = np.ascontiguousarray(audio.samples, dtype=np.float32)
+    n = ctypes.c_int64()
+    check(lib.q3_resample(x.ctypes.data_as(ctypes.c_void_p), x.size, audio.sample_rate, target_rate, None, 0, ctypes.byref(n)))
+    out = np.empty(n.value, np.float32)
+    check(lib.q3_resample(x.ctypes.data_as(ctypes.c_void_p), x.size, audio.sample_rate, target_rate,
+                          out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(n)))
+    return AudioBuffer(out, target_rate)
+
+
+def resample_to_24k(audio: AudioBuffer) -> AudioBuffer:      # audio/resample.rs:174-176
+    return resample(audio, 24000)
 
 
 def save_codes_binary(path: str, codes: np.ndarray):

@@ -360,6 +360,45 @@ extern "C" q3_status q3_config_from_json(const char* path, q3_config* out, int* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Resampler (audio/resample.rs:17-171). The reference delegates to rubato's asynchronous sinc resampler with
+// sinc_len 128, f_cutoff 0.95, BlackmanHarris2 window (resample.rs:83-97); rubato is a Cargo dependency whose sources
+// are not available here, so this is a restatement of the published method with those parameters, not of its code:
+// a 128-tap Blackman-Harris²-windowed sinc low-pass at 0.95 x the lower Nyquist, evaluated exactly at every output
+// instant (f64) instead of interpolating between 128 oversampled tables. Output i sits at input time i / ratio —
+// rubato's stream is additionally delayed by sinc_len / 2 input samples and padded to whole 1024-sample chunks
+// (resample.rs:118-159), so lengths differ by that padding ("parity unpinned" for this helper).
+// ------------------------------------------------------------------------------------------------
+extern "C" q3_status q3_resample(const float* in, int64_t n, uint32_t sr_in, uint32_t sr_out, float* out, int64_t cap, int64_t* n_out) {
+    if (!in || n < 0 || !sr_in || !sr_out) return q3i_set_err(Q3_INVALID_ARG, "q3_resample: bad argument");
+    const double ratio = (double)sr_out / (double)sr_in;
+    const int64_t no = sr_in == sr_out ? n : (int64_t)llround((double)n * ratio);
+    if (n_out) *n_out = no;
+    if (!out) return Q3_OK;                                   // length query
+    if (cap < no) return q3i_set_err(Q3_INVALID_ARG, "q3_resample: output buffer too small (%lld needed)", (long long)no);
+    if (sr_in == sr_out) { memcpy(out, in, (size_t)n * sizeof(float)); return Q3_OK; }     // resample.rs:38-40
+    const int half = 64;                                      // sinc_len 128
+    const double fc = 0.95 * (ratio < 1.0 ? ratio : 1.0);     // cutoff relative to the input Nyquist
+    const double a0 = 0.35875, a1 = 0.48829, a2 = 0.14128, a3 = 0.01168, PI = 3.14159265358979323846;
+    for (int64_t i = 0; i < no; ++i) {
+        const double t = (double)i / ratio;
+        const int64_t c = (int64_t)floor(t);
+        double acc = 0.0;
+        for (int64_t k = c - half + 1; k <= c + half; ++k) {
+            if (k < 0 || k >= n) continue;
+            const double u = t - (double)k, v = u / (double)half;      // |v| <= 1
+            if (v <= -1.0 || v >= 1.0) continue;
+            double w = a0 + a1 * cos(PI * v) + a2 * cos(2.0 * PI * v) + a3 * cos(3.0 * PI * v);
+            w *= w;
+            const double xs = PI * fc * u;
+            const double sinc = fabs(xs) < 1e-12 ? 1.0 : sin(xs) / xs;
+            acc += (double)in[k] * fc * sinc * w;
+        }
+        out[i] = (float)acc;
+    }
+    return Q3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // speaker encoder: config.json `speaker_encoder_config` (config.rs:100-174, 233) and its tensors
 // ------------------------------------------------------------------------------------------------
 extern "C" q3_status q3_spk_config_from_json(const char* path, q3_spk_config* out, int* present) {

@@ -235,3 +235,35 @@ def test_model_load_errors_and_weight_inspection_fallback(tmp_path):
     (root / "model.safetensors").write_bytes(struct.pack("<Q", 1 << 40) + b"{}")
     with pytest.raises(_lib.Q3Error):
         _lib.check(_lib.lib.q3_model_load(str(root).encode(), -1, ctypes.byref(h), None))
+
+
+# ---------------- resampler (audio/resample.rs tests :186-283, on q3_resample) ----------------
+def test_resample_reference_properties():
+    from qwen3_tts_rs_amd import api
+    a = api.AudioBuffer(np.zeros(1000, np.float32), 24000)
+    r = api.resample(a, 24000)
+    assert r.sample_rate == 24000 and len(r) == len(a)                       # test_no_resample_needed
+    r = api.resample(api.AudioBuffer(np.zeros(4800, np.float32), 48000), 24000)
+    assert r.sample_rate == 24000 and 2000 < len(r) < 3000                   # test_downsample
+    r = api.resample_to_24k(api.AudioBuffer(np.zeros(1600, np.float32), 16000))
+    assert r.sample_rate == 24000 and 2000 < len(r) < 4000                   # test_upsample / test_resample_to_24k
+    sine = np.sin(2 * np.pi * 100.0 * np.arange(4800) / 48000.0).astype(np.float32)
+    r = api.resample(api.AudioBuffer(sine, 48000), 24000)
+    assert np.abs(r.samples).max() > 0.5                                     # test_resample_preserves_sine_wave
+
+
+@pytest.mark.parametrize("sr_in,sr_out", [(16000, 24000), (48000, 24000), (44100, 24000), (22050, 24000)])
+def test_resample_accuracy(sr_in, sr_out):
+    """Band-limited signal resampled = the same analytic signal sampled at the new rate (interior; the ends see the
+    truncated filter), and components above the new Nyquist are removed when downsampling."""
+    from qwen3_tts_rs_amd import api
+    n = sr_in // 2
+    t = np.arange(n) / sr_in
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * t) + 0.3 * np.sin(2 * np.pi * 3000.0 * t + 0.7)).astype(np.float32)
+    hi = 0.4 * np.sin(2 * np.pi * 15000.0 * t) if sr_in >= 44100 else 0.0     # above 12 kHz: must vanish at 24 kHz
+    r = api.resample(api.AudioBuffer((x + hi).astype(np.float32), sr_in), sr_out)
+    assert len(r) == round(n * sr_out / sr_in)
+    to = np.arange(len(r)) / sr_out
+    ref = 0.5 * np.sin(2 * np.pi * 440.0 * to) + 0.3 * np.sin(2 * np.pi * 3000.0 * to + 0.7)
+    m = slice(200, len(r) - 200)
+    assert np.abs(r.samples[m] - ref[m]).max() < 2e-3

@@ -247,8 +247,12 @@ def test_gpu_voice_clone_from_checkpoint_dir(tmp_path):
     assert _rel(prompt.speaker_embedding, os_.encode(audio.samples)) <= 2e-4
     with pytest.raises(q.api._lib.Q3Error, match="speech encoder"):
         m.create_voice_clone_prompt(audio, ref_text_ids=[1, 2, 3])
-    with pytest.raises(q.api._lib.Q3Error, match="resample"):
-        m.create_voice_clone_prompt(q.AudioBuffer(audio.samples, 16000))
+    # non-24 kHz reference audio is resampled first (lib.rs:1156-1166)
+    a16 = q.api.resample(audio, 16000)
+    p16 = m.create_voice_clone_prompt(a16)
+    cos = float(np.dot(p16.speaker_embedding, prompt.speaker_embedding) / (np.linalg.norm(p16.speaker_embedding) * np.linalg.norm(prompt.speaker_embedding)))
+    assert cos > 0.9, cos           # band-limited copy of the same clip (8-12 kHz noise gone) → a close embedding
+    np.testing.assert_array_equal(p16.speaker_embedding, m.speaker_encoder.encode(q.api.resample_to_24k(a16).samples))
     # codes from the embedding: GPU vs oracle on identical inputs
     om = O.OracleModel(cfg)
     for k, (arr, dt) in raw.items():
