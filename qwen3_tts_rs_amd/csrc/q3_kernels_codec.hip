@@ -822,10 +822,96 @@ __global__ __launch_bounds__(64) void k_attn_c(const float* q, const float* k, c
     }
     o[hb + (size_t)lane * L + i] = acc / l;
 }
+// The same attention on the matrix cores (v_mfma_f32_32x32x2f32: true f32 products). One wave per (32-query tile,
+// head), key tiles of 32 in ascending order with an online softmax. The [C][L] layout makes every operand a coalesced
+// global read: Sᵀ = K·Qᵀ (A = K: lane (key, d-pair) reads k[d][j0 + key]; B = Q, the tile's 32 x 64 values held in 32
+// registers) puts a QUERY in each lane's column, so the softmax statistics are per-lane reductions over the 16
+// accumulator registers plus one cross-half shuffle, and the probabilities are already in B-operand position for
+// Oᵀ = Vᵀ·Pᵀ: MFMA step r pairs the key of register r in the lower lane half with the key of register r in the upper
+// half, which only fixes which V column each half reads. V goes through LDS (coalesced load, transposed read).
+// A query's arithmetic depends only on its own index (tiles are aligned to absolute positions), so prefix decodes
+// reproduce the whole-utterance values bit for bit, as the streaming modes require.
+typedef __attribute__((ext_vector_type(16))) float f32x16a_t;
+__global__ __launch_bounds__(64) void k_attn_c_mfma(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                    float* __restrict__ o, int L, float scale) {
+    constexpr int VP = 33;
+    __shared__ float vs[64 * VP];
+    const int lane = threadIdx.x, li = lane & 31, lk = lane >> 5;
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y;      // longest (last) query tiles first
+    const int i0 = qt * 32, i = i0 + li;
+    const size_t hb = (size_t)h * 64 * L;
+    float qb[32];                                                              // B operand of step s: Q[i][d = 2s + lk]
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qb[s] = i < L ? q[hb + (size_t)(2 * s + lk) * L + i] : 0.0f;
+    f32x16a_t oacc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
+    float m = -INFINITY, lsum = 0.0f;                                          // lsum: this half's share of the denominator
+    for (int j0 = 0; j0 <= i0; j0 += 32) {
+        const int j = j0 + li;
+        const bool jok = j < L;
+        // V tile -> LDS (rows d, columns key); issued first so that it overlaps the score MFMAs
+        float vr[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) vr[s] = jok ? v[hb + (size_t)(2 * s + lk) * L + j] : 0.0f;
+        f32x16a_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+        float ka[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) ka[s] = jok ? k[hb + (size_t)(2 * s + lk) * L + j] : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qb[s], sacc, 0, 0, 0);
+        __syncthreads();                                                       // previous tile's LDS reads are done
+#pragma unroll
+        for (int s = 0; s < 32; ++s) vs[(2 * s + lk) * VP + li] = vr[s];
+        // scores: register r of this lane = (key j0 + (r&3) + 8*(r>>2) + 4*lk, query i)
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float sv = (key <= i && key < L) ? sacc[r] * scale : -INFINITY;
+            sacc[r] = sv; cm = fmaxf(cm, sv);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);                                         // finite: key j0 <= i0 <= i is always live
+        const float corr = expf(m - mn);
+        float ps = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float p = expf(sacc[r] - mn); sacc[r] = p; ps += p; }
+        lsum = lsum * corr + ps;
+        m = mn;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= corr;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lk;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(t * 32 + li) * VP + key], sacc[r], oacc[t], 0, 0, 0);
+        }
+    }
+    const float den = lsum + __shfl_xor(lsum, 32);
+    if (i < L) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                o[hb + (size_t)d * L + i] = oacc[t][r] / den;
+            }
+    }
+}
 hipError_t launch_attn_c(const float* q, const float* k, const float* v, float* o, int nh, int hd, int L, float scale,
                          hipStream_t st) {
     if (hd != 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_attn_c, dim3(L, nh), dim3(64), 0, st, q, k, v, o, L, scale);
+    static const bool valu = getenv("Q3_ATTN_C_VALU") != nullptr;       // A/B aid: the first-generation VALU kernel
+    if (valu) hipLaunchKernelGGL(k_attn_c, dim3(L, nh), dim3(64), 0, st, q, k, v, o, L, scale);
+    else hipLaunchKernelGGL(k_attn_c_mfma, dim3((L + 31) / 32, nh), dim3(64), 0, st, q, k, v, o, L, scale);
     return hipGetLastError();
 }
 
