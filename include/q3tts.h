@@ -343,6 +343,27 @@ q3_status q3_spk_forward(q3_speaker_encoder* e, const float* mel_host, int T, fl
  * first, lib.rs:1156-1166 — q3_resample before calling) */
 q3_status q3_spk_encode(q3_speaker_encoder* e, const float* samples_host, int64_t n, uint32_t sample_rate, float* out_host);
 
+/* ---------------- data parallelism without torch.distributed (q3_dp.cpp) ----------------
+ * one process per GPU, utterance i -> rank i mod N, exactly one collective on the data path — the
+ * broadcast of rank 0's weight arena over RCCL (xGMI) — plus an all-gather of a few doubles for end-of-job timing. The
+ * reference has no multi-GPU code to replace (per-call KV / RNG / masks, lib.rs:744-756, make utterances independent);
+ * these entry points are what its Rust host would call where bench.py uses torch.distributed. RCCL is dlopen'ed on the
+ * first call. Rendezvous = the host ships the 128-byte id from rank 0 to the other ranks by its own means
+ * (file, TCP, MPI, environment). */
+#define Q3_DP_ID_BYTES 128
+typedef struct q3_dp_comm q3_dp_comm;
+/* ncclGetUniqueId: call on rank 0, hand the bytes to every rank */
+q3_status q3_dp_unique_id(void* id_out /* Q3_DP_ID_BYTES */);
+/* ncclCommInitRank on `device` (collective: every rank of the job must call it) */
+q3_status q3_dp_init(int rank, int world, const void* id, int device, q3_dp_comm** out);
+void q3_dp_free(q3_dp_comm* c);
+q3_status q3_dp_info(const q3_dp_comm* c, int* rank, int* world);
+/* ncclBroadcast of the whole weight arena from `root` (collective); non-root ranks are marked loaded and must then
+ * call q3_model_finalize themselves. world == 1: no-op. */
+q3_status q3_dp_broadcast_weights(q3_dp_comm* c, q3_model* m, int root);
+/* ncclAllGather of n doubles per rank: out_host [world][n] (timings, frame counts) */
+q3_status q3_dp_allgather_f64(q3_dp_comm* c, const double* in_host, int n, double* out_host);
+
 #ifdef __cplusplus
 }
 #endif

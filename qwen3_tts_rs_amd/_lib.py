@@ -107,6 +107,12 @@ SYMBOLS = {
     "q3_codes_read_bin": (c_int, [c_char_p, c_void_p, c_int, c_int, P(c_int)]),
     "q3_audio_write_bin": (c_int, [c_char_p, c_void_p, ctypes.c_int64]),
     "q3_resample": (c_int, [c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32, c_void_p, ctypes.c_int64, P(ctypes.c_int64)]),
+    "q3_dp_unique_id": (c_int, [c_void_p]),
+    "q3_dp_init": (c_int, [c_int, c_int, c_void_p, c_int, P(c_void_p)]),
+    "q3_dp_free": (None, [c_void_p]),
+    "q3_dp_info": (c_int, [c_void_p, P(c_int), P(c_int)]),
+    "q3_dp_broadcast_weights": (c_int, [c_void_p, c_void_p, c_int]),
+    "q3_dp_allgather_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "q3_spk_config_default": (c_int, [P(CSpkConfig)]),
     "q3_spk_config_from_json": (c_int, [c_char_p, P(CSpkConfig), P(c_int)]),
     "q3_spk_create": (c_int, [P(CSpkConfig), c_int, P(c_void_p)]),

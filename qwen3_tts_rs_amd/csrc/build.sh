@@ -18,6 +18,10 @@ if [ ! -f "$BUILD/q3_io.o" ] || [ "$HERE/q3_io.cpp" -nt "$BUILD/q3_io.o" ] || [ 
   $HIPCC -O2 -std=c++17 -fPIC -Wall -c "$HERE/q3_io.cpp" -o "$BUILD/q3_io.o" &
   pids+=($!)
 fi
+if [ ! -f "$BUILD/q3_dp.o" ] || [ "$HERE/q3_dp.cpp" -nt "$BUILD/q3_dp.o" ] || [ "$HERE/q3_internal.h" -nt "$BUILD/q3_dp.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/q3_dp.o" ]; then
+  $HIPCC -O2 -std=c++17 -fPIC -Wall -c "$HERE/q3_dp.cpp" -o "$BUILD/q3_dp.o" &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_gemv.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_kernels_prefill.o" "$BUILD/q3_engine.o" "$BUILD/q3_speaker.o" "$BUILD/q3_io.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_gemv.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_kernels_prefill.o" "$BUILD/q3_engine.o" "$BUILD/q3_speaker.o" "$BUILD/q3_io.o" "$BUILD/q3_dp.o" -ldl
 echo "built $OUT"

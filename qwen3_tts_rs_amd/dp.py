@@ -80,3 +80,61 @@ def sum_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+class NativeComm:
+    """RCCL communicator through the C ABI (q3_dp_*, q3_dp.cpp) — what a host without torch.distributed (the reference's
+    Rust host) uses for the one weight broadcast. Rendezvous: rank 0 creates the 128-byte id and the host ships it to
+    the other ranks; `from_file` does that through a shared path (every rank of the job must call it)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes, device: int):
+        import ctypes
+        from . import _lib
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _lib.check(_lib.lib.q3_dp_init(rank, world, buf, device, ctypes.byref(h)))
+        self._h = h; self.rank = rank; self.world = world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib.q3_dp_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_file(cls, path: str, rank: int, world: int, device: int, timeout_s: float = 120.0) -> "NativeComm":
+        import time
+        if rank == 0:
+            uid = cls.unique_id()
+            with open(path + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(path + ".tmp", path)
+        else:
+            t0 = time.time()
+            while not (os.path.exists(path) and os.path.getsize(path) == 128):
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s}s")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                uid = f.read()
+        return cls(rank, world, uid, device)
+
+    def broadcast_weights(self, model, root: int = 0):
+        from . import _lib
+        _lib.check(_lib.lib.q3_dp_broadcast_weights(self._h, model._h, root))
+
+    def allgather(self, values) -> "list":
+        import ctypes
+        import numpy as np
+        from . import _lib
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        out = np.empty((self.world, v.size), np.float64)
+        _lib.check(_lib.lib.q3_dp_allgather_f64(self._h, v.ctypes.data_as(ctypes.c_void_p), v.size, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def close(self):
+        from . import _lib
+        if getattr(self, "_h", None):
+            _lib.lib.q3_dp_free(self._h); self._h = None

@@ -600,3 +600,24 @@ def test_full_size_gemm_prefill(size):
             pytest.fail(f"sequence {b}: first divergence at frame {f} group {g}")
         osess.close()
     s.close(); gm.close(); om.close()
+
+
+@pytest.mark.gpu
+def test_native_rccl_comm_world1(pair, tmp_path):
+    """q3_dp_* (the C-ABI data-parallel boundary): RCCL resolved at run time, communicator from a
+    file-shipped unique id, the arena broadcast and the timing all-gather run through real RCCL calls (world size 1 on
+    this box; the N-rank protocol is the same calls), and the model still produces the same codes afterwards."""
+    from qwen3_tts_rs_amd import dp
+    cfg, gm, om = pair
+    opts = q.SynthesisOptions(max_length=5, seed=3, eos_token_id=None)
+    utt = _utts("custom", 5)
+    s = gm.session([utt], opts); s.prefill(); s.generate(5); c0 = s.codes(0).copy(); s.close()
+    comm = dp.NativeComm.from_file(str(tmp_path / "rccl_id"), 0, 1, 0)
+    comm.broadcast_weights(gm, 0)
+    got = comm.allgather([1.5, 2.5, 3.5])
+    assert got.shape == (1, 3) and got[0].tolist() == [1.5, 2.5, 3.5]
+    with pytest.raises(_lib.Q3Error):
+        comm.broadcast_weights(gm, 3)          # root outside the communicator
+    comm.close()
+    s = gm.session([utt], opts); s.prefill(); s.generate(5); c1 = s.codes(0).copy(); s.close()
+    assert (c0 == c1).all()
