@@ -336,7 +336,7 @@ __device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t
 // sequences, one wave per segment) can reproduce, so both kernels give a position the same bits.
 __host__ __device__ __forceinline__ bool conv_segmented(int k, int cin) { return k == 1 && (cin & 511) == 0; }
 
-template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false>
+template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false, bool SEG = false>
 __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x3(ConvDev a) {     // waves per SIMD the register budget must allow
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
@@ -347,9 +347,19 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, lk = lane >> 5;
     const int wco = wave % WCO, wt = wave / WCO;
-    const int t0 = blockIdx.x * T_WG, co0 = blockIdx.y * CO_WG + wco * (32 * CO_M);
+    // XCD-aware tile order (1-D grid of nt x nco tiles): workgroup b runs on XCD b % 8, each XCD has its own L2, and the
+    // nco channel tiles of one time tile all stage the same x. They are therefore made consecutive *on one XCD*
+    // (ids 8 apart) instead of nt dispatches apart: the x tile comes from HBM once, not nco times
+    // (profiles/r1_pmc_vocoder_hbm_T640.txt).
+    int bx, by;
+    {
+        const int nco = a.cout / CO_WG, nt = (int)gridDim.x / nco, nt8 = nt & ~7, lin = (int)blockIdx.x;
+        if (lin < nt8 * nco) { const int r = lin >> 3; by = r % nco; bx = (r / nco) * 8 + (lin & 7); }
+        else { const int rem = lin - nt8 * nco; by = rem % nco; bx = nt8 + rem / nco; }
+    }
+    const int t0 = bx * T_WG, co0 = by * CO_WG + wco * (32 * CO_M);
     for (int i = tid; i < CO_WG; i += NT) {
-        const int o = blockIdx.y * CO_WG + i;
+        const int o = by * CO_WG + i;
         const bool ok = o < a.cout;
         s_prm[0][i] = (a.b && ok) ? a.b[o] : 0.0f;
         s_prm[1][i] = (a.scale && ok) ? a.scale[o] : 1.0f;
@@ -369,10 +379,10 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         for (int j = 0; j < T_M; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    constexpr int SM = K == 1 ? CO_M : 1, SN = K == 1 ? T_M : 1;
+    constexpr int SM = SEG ? CO_M : 1, SN = SEG ? T_M : 1;
     f32x16_t tot[SM][SN];
-    const bool seg = K == 1 && conv_segmented(a.k, a.cin);
-    if (K == 1) {
+    constexpr bool seg = SEG;                                     // the launcher instantiates SEG = conv_segmented(k, cin)
+    if (SEG) {
 #pragma unroll
         for (int i = 0; i < SM; ++i)
 #pragma unroll
@@ -389,6 +399,8 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
             for (int pl = 0; pl < 3; ++pl) A[cm][pl] = wpk[(tile * 3 + pl) * 64 + lane];
         }
     };
+    // (Requesting the NEXT stage's x into registers right after the publishing barrier, so that its round trip runs under
+    // the MFMAs, was tried and lost: 24 more live VGPRs cost more than the hidden latency — 640-frame decode 30.4 -> 33 ms.)
     for (int ci0 = 0; ci0 < a.cin; ci0 += 32) {
         const int n16 = (a.cin - ci0) >= 32 ? 2 : 1;
         // the first weight fragments of the stage do not depend on the staging: request them before the barrier
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
             if (s0 + 2 < n_steps) { const int kk = (s0 + 2) / n16; load_A(A0, ci0, kk, (s0 + 2) - kk * n16); }
             do_step(A1, s0 + 1);
         }
-        if (K == 1 && seg && ((ci0 + 32) & 127) == 0) {          // segment boundary: total += segment sum
+        if (SEG && ((ci0 + 32) & 127) == 0) {                    // segment boundary: total += segment sum
 #pragma unroll
             for (int i = 0; i < SM; ++i)
 #pragma unroll
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
                     for (int r = 0; r < 16; ++r) { tot[i][j][r] = tot[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.0f; }
         }
     }
-    if (K == 1 && seg) {
+    if (SEG) {
 #pragma unroll
         for (int i = 0; i < SM; ++i)
 #pragma unroll
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         for (int reg = 0; reg < 16; ++reg) {
             const int o = co0 + cm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
             const bool ook = o < a.cout;
-            const int pi = o - blockIdx.y * CO_WG;              // row inside the workgroup's channel range
+            const int pi = o - by * CO_WG;                      // row inside the workgroup's channel range
             const float bias = s_prm[0][pi], sc = s_prm[1][pi], pa = s_prm[2][pi], pib = s_prm[3][pi];
 #pragma unroll
             for (int tm = 0; tm < T_M; ++tm) {
@@ -599,8 +611,13 @@ template <int K, int CO_M, int T_M, int WCO, int WT>
 static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     const size_t lds = (size_t)3 * (T_WG + (K - 1) * a.dil) * XP;
-    dim3 grid((a.L + T_WG - 1) / T_WG, a.cout / CO_WG, phases);
-    if (CO_M == 1 && K == 1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K == 1>), grid, dim3(64 * WCO * WT), lds, st, a);
+    dim3 grid(((a.L + T_WG - 1) / T_WG) * (a.cout / CO_WG), 1, phases);      // tile order: see the kernel
+    constexpr bool K1 = K == 1;
+    const bool segm = conv_segmented(a.k, a.cin);
+    if (K1 && segm) {
+        if (CO_M == 1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1, K1>), grid, dim3(64 * WCO * WT), lds, st, a);
+        else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, false, K1>), grid, dim3(64 * WCO * WT), lds, st, a);
+    } else if (CO_M == 1 && K1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1>), grid, dim3(64 * WCO * WT), lds, st, a);
     else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, dim3(64 * WCO * WT), lds, st, a);
     return hipGetLastError();
 }
