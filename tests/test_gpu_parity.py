@@ -621,3 +621,37 @@ def test_native_rccl_comm_world1(pair, tmp_path):
     comm.close()
     s = gm.session([utt], opts); s.prefill(); s.generate(5); c1 = s.codes(0).copy(); s.close()
     assert (c0 == c1).all()
+
+
+@pytest.mark.gpu
+def test_error_contract(pair):
+    """Error behaviour of the boundary (SURVEY.md §8b "Errors"): every misuse returns a status with a message, nothing
+    aborts; the session stays usable after a refused call."""
+    cfg, gm, om = pair
+    E = _lib.Q3Error
+    opts = q.SynthesisOptions(max_length=4, seed=1, eos_token_id=None)
+    with pytest.raises(E, match="out of range"):                      # token id beyond the text vocabulary
+        gm.session([q.Utterance([cfg.text_vocab + 5])], opts)
+    with pytest.raises(E, match="max_length"):
+        gm.session([_utts("custom", 4)], q.SynthesisOptions(max_length=0))
+    with pytest.raises(E, match="RoPE table|exceeds"):                # kv_cache.rs:293-300's bail! → Q3_KV_OVERFLOW
+        gm.session([_utts("custom", 4)], q.SynthesisOptions(max_length=10_000_000))
+    bad = np.zeros((3, 16), np.uint32); bad[1, 5] = cfg.cp_vocab + 1
+    with pytest.raises(E, match="out of range for codebook"):         # decode_codes validates every code
+        gm.decode_codes(bad)
+    s = gm.session([_utts("custom", 4)], opts)
+    with pytest.raises(E, match="not prefilled"):
+        s.generate(1)
+    s.prefill()
+    with pytest.raises(E, match="already prefilled"):
+        s.prefill()
+    with pytest.raises(E, match="bad sequence index"):
+        s.codes(3)
+    s.generate(4)                                                     # still healthy
+    assert s.codes(0).shape == (4, 16) and s.frames(0) == (4, True)
+    s.generate(4)                                                     # past max_length: a no-op, not an error
+    assert s.frames(0) == (4, True)
+    s.close()
+    with pytest.raises(E, match="unknown tensor name"):
+        gm.set_tensor("talker.model.layers.99.nope", np.zeros(4, np.float32), 0)
+    assert _lib.lib.q3_last_error().decode().startswith("unknown tensor name")
