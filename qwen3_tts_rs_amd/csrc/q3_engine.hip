@@ -1512,6 +1512,19 @@ static q3_status prefill_gemm(q3_session* s, int S) {
     HIPC(tmp.alloc(&Qb, (size_t)max_rows * QD)); HIPC(tmp.alloc(&ATT, (size_t)max_rows * QD));
     HIPC(tmp.alloc(&SUM, (size_t)max_rows * H)); HIPC(tmp.alloc(&ACT, (size_t)max_rows * I)); HIPC(tmp.alloc(&DEN, (size_t)max_rows));
     auto kp = [](int K) { return (K + 31) / 32 * 32; };
+    // every GEMM input is split once into its three exact bf16 terms (launch_split_rows) instead of once per workgroup
+    // column inside the GEMM; Q3_GEMM_NO_PLANES=1 keeps the in-kernel split (A/B aid)
+    static const bool no_planes = getenv("Q3_GEMM_NO_PLANES") != nullptr;
+    const bool planes = !no_planes && H % 8 == 0 && QD % 8 == 0 && I % 8 == 0;
+    const int kmax = std::max(kp(H), std::max(kp(QD), kp(I)));
+    const size_t plane_elems = (size_t)max_rows * kmax;
+    uint16_t* XP = nullptr;
+    if (planes) HIPC(tmp.alloc(&XP, plane_elems * 3));
+    auto split = [&](GemmArgs& g) -> hipError_t {
+        if (!planes) return hipSuccess;
+        g.xp = XP; g.xp_plane = plane_elems;
+        return launch_split_rows(g.x, g.ldx, g.norm_w, XP, plane_elems, g.M, g.K, g.Kpad, s->stream);
+    };
     int ch = 0;
     for (int t0 = 0; t0 < S; t0 += C) {
         ch = (S - t0) < C ? (S - t0) : C;
@@ -1523,7 +1536,7 @@ static q3_status prefill_gemm(q3_session* s, int S) {
             HIPC(launch_row_den(X, H, DEN, rows, H, d.eps, s->stream));
             GemmArgs g; g.W = w.qkv.t1; g.x = X; g.ldx = H; g.norm_w = w.in_ln; g.den = DEN; g.y = QKV; g.ldy = QD + 2 * KD;
             g.M = rows; g.N = QD + 2 * KD; g.K = H; g.Kpad = kp(H); g.epi = EPI_NONE;
-            HIPC(launch_lm_gemm(g, s->stream));
+            HIPC(split(g)); HIPC(launch_lm_gemm(g, s->stream));
             AttnArgs t{};
             t.qkv = QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
             t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = nullptr; t.pos_static = t0;
@@ -1534,14 +1547,14 @@ static q3_status prefill_gemm(q3_session* s, int S) {
             HIPC(launch_attn_prefill(t, s->stream));
             GemmArgs o; o.W = w.o.t1; o.x = ATT; o.ldx = QD; o.resid = X; o.ldr = H; o.y = SUM; o.ldy = H;
             o.M = rows; o.N = H; o.K = QD; o.Kpad = kp(QD); o.epi = EPI_RESID;
-            HIPC(launch_lm_gemm(o, s->stream));
+            HIPC(split(o)); HIPC(launch_lm_gemm(o, s->stream));
             HIPC(launch_row_den(SUM, H, DEN, rows, H, d.eps, s->stream));
             GemmArgs gu; gu.W = w.gate.t1; gu.W2 = w.up.t1; gu.x = SUM; gu.ldx = H; gu.norm_w = w.post_ln; gu.den = DEN; gu.y = ACT; gu.ldy = I;
             gu.M = rows; gu.N = I; gu.K = H; gu.Kpad = kp(H); gu.epi = EPI_SWIGLU;
-            HIPC(launch_lm_gemm(gu, s->stream));
+            HIPC(split(gu)); HIPC(launch_lm_gemm(gu, s->stream));
             GemmArgs dn; dn.W = w.down.t1; dn.x = ACT; dn.ldx = I; dn.resid = SUM; dn.ldr = H; dn.y = X; dn.ldy = H;
             dn.M = rows; dn.N = H; dn.K = I; dn.Kpad = kp(I); dn.epi = EPI_RESID;
-            HIPC(launch_lm_gemm(dn, s->stream));
+            HIPC(split(dn)); HIPC(launch_lm_gemm(dn, s->stream));
         }
     }
     // head on each sequence's last position (row b*ch + ch-1 of the last chunk): final norm -> LASTH, codec_head -> LOGITS

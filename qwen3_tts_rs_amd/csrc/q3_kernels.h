@@ -41,8 +41,15 @@ struct GemmArgs {
     float* y = nullptr; int ldy = 0;
     int M = 0, N = 0, K = 0, Kpad = 0;
     int epi = EPI_NONE;
+    // optional: x (times norm_w when set) already split into its three exact bf16 terms by launch_split_rows —
+    // [3][plane_elems] bf16, row pitch Kpad. The GEMM then stages plain copies instead of redoing the split in every
+    // one of its N/64 workgroup columns.
+    const uint16_t* xp = nullptr; size_t xp_plane = 0;
 };
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st);
+// planes[pl][row][k] (pitch Kpad, zero beyond K) = pl-th bf16 term of x[row][k] * (norm_w ? norm_w[k] : 1); K % 8 == 0
+hipError_t launch_split_rows(const float* x, int ldx, const float* norm_w, uint16_t* planes, size_t plane_elems, int rows, int K,
+                             int Kpad, hipStream_t st);
 hipError_t launch_row_den(const float* x, int ldx, float* den, int rows, int cols, float eps, hipStream_t st);
 
 // standalone analogue of kernels/fused_residual_rmsnorm.cu: (normed, sum) for [rows][cols]

@@ -68,6 +68,44 @@ hipError_t launch_row_den(const float* x, int ldx, float* den, int rows, int col
     return hipGetLastError();
 }
 
+// The exact bf16x3 split of a whole activation matrix, once (one wave per row, 8 k per lane per step): the GEMM below
+// would otherwise redo it in each of its N/64 workgroup columns — 64-192 times — and be VALU-bound on it.
+template <bool RMS>
+__global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ x, int ldx, const float* __restrict__ norm_w,
+                                                    uint16_t* __restrict__ planes, size_t plane_elems, int rows, int K, int Kpad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    uint16_t* pr = planes + (size_t)row * Kpad;
+    for (int k = lane * 8; k < Kpad; k += 512) {
+        float v[8];
+        if (k < K) {                                            // K % 8 == 0: the octet is all in or all out
+            const float4 a = *reinterpret_cast<const float4*>(xr + k), b = *reinterpret_cast<const float4*>(xr + k + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            if constexpr (RMS) {
+                const float4 n0 = *reinterpret_cast<const float4*>(norm_w + k), n1 = *reinterpret_cast<const float4*>(norm_w + k + 4);
+                v[0] *= n0.x; v[1] *= n0.y; v[2] *= n0.z; v[3] *= n0.w; v[4] *= n1.x; v[5] *= n1.y; v[6] *= n1.z; v[7] *= n1.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        }
+        pu32x4_t h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; psplit3_pair(v[2 * e], v[2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+        *reinterpret_cast<pu32x4_t*>(pr + k) = h;
+        *reinterpret_cast<pu32x4_t*>(pr + plane_elems + k) = m;
+        *reinterpret_cast<pu32x4_t*>(pr + 2 * plane_elems + k) = l;
+    }
+}
+hipError_t launch_split_rows(const float* x, int ldx, const float* norm_w, uint16_t* planes, size_t plane_elems, int rows, int K,
+                             int Kpad, hipStream_t st) {
+    if (K % 8 || Kpad % 8 || ldx % 4 || K > Kpad || (plane_elems % 8)) return hipErrorInvalidValue;
+    if (norm_w) hipLaunchKernelGGL((k_split_rows<true>), dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, norm_w, planes, plane_elems, rows, K, Kpad);
+    else hipLaunchKernelGGL((k_split_rows<false>), dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, norm_w, planes, plane_elems, rows, K, Kpad);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // GEMM. Workgroup = 4 waves, tile = 64 weight rows (4 MFMA row tiles) x 128 activation rows (8 column tiles of 16);
 // wave w owns column tiles 2w, 2w+1 and all 4 row tiles. Per stage of 64 k: x[128][64] f32 is staged as three bf16
@@ -76,7 +114,7 @@ hipError_t launch_row_den(const float* x, int ldx, float* den, int rows, int col
 // ------------------------------------------------------------------------------------------------
 constexpr int GP = 144;      // LDS bytes per activation row per plane: 64 k x 2 B + 16 pad
 
-template <int EPI, bool RMS>
+template <int EPI, bool RMS, bool PL = false>      // PL: x comes pre-split (GemmArgs::xp), staging is a copy
 __global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 128 * GP];
@@ -101,9 +139,19 @@ __global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
     const bool srow_ok = (m0 + srow) < a.M;
     const float* __restrict__ xrow = a.x + (size_t)(srow_ok ? m0 + srow : 0) * a.ldx;
 
-    for (int k0 = 0; k0 < a.Kpad; k0 += 64) {
-        // weight tiles of this stage first (independent of the LDS traffic below)
-        pu32x4_t A[NW][4][2];
+    // pre-split x: the next stage's 3 x 64 bytes per thread are requested before this stage's MFMAs and committed to
+    // LDS after the next barrier, so their round trip is off the critical path
+    pu32x4_t xt[3][4];
+    auto fetch_x = [&](int k0) {
+        const uint16_t* src = a.xp + (size_t)(srow_ok ? m0 + srow : 0) * a.Kpad + k0 + sk;
+        const bool kok = srow_ok && (k0 + sk) < a.Kpad;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xt[pl][q] = kok ? *reinterpret_cast<const pu32x4_t*>(src + pl * a.xp_plane + q * 8) : pu32x4_t{0u, 0u, 0u, 0u};
+    };
+    pu32x4_t A[NW][4][2];
+    auto load_A = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -113,8 +161,19 @@ __global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
                 A[0][r][ks] = __builtin_nontemporal_load(w1 + off);
                 if constexpr (NW == 2) A[1][r][ks] = __builtin_nontemporal_load(w2 + off);
             }
+    };
+    if constexpr (PL) fetch_x(0);
+    for (int k0 = 0; k0 < a.Kpad; k0 += 64) {
+        // weight tiles of this stage first (independent of the LDS traffic below)
+        load_A(k0);
         __syncthreads();
-        {
+        if constexpr (PL) {
+            unsigned char* dst = smem + (size_t)srow * GP + sk * 2;            // 32 k of one row: 64 bytes per plane
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<pu32x4_t*>(dst + pl * plane + q * 16) = xt[pl][q];
+        } else {
             float v[32];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -138,6 +197,7 @@ __global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
             }
         }
         __syncthreads();
+        if constexpr (PL) { if (k0 + 64 < a.Kpad) fetch_x(k0 + 64); }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if ((k0 >> 5) + ks >= S) break;
@@ -148,19 +208,18 @@ __global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) B[c][pl] = *reinterpret_cast<const pu32x4_t*>(bp + pl * plane);
             }
+            // plane outermost (lo, mid, hi: the same per-accumulator order as before): consecutive MFMAs write different
+            // accumulators, so none waits for the previous one's result
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
+            for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int w = 0; w < NW; ++w)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const pbf16x8_t av = __builtin_bit_cast(pbf16x8_t, A[w][r][ks]);
-                        pf32x4_t t = acc[w][r][c];
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(pbf16x8_t, B[c][2]), t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(pbf16x8_t, B[c][1]), t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(pbf16x8_t, B[c][0]), t, 0, 0, 0);
-                        acc[w][r][c] = t;
-                    }
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            acc[w][r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8_t, A[w][r][ks]),
+                                                                                  __builtin_bit_cast(pbf16x8_t, B[c][pl]), acc[w][r][c], 0, 0, 0);
         }
     }
     // epilogue: lane (mj, kg) holds activation row mj of the column tile and weight rows kg*4 .. +3 of the row tile
@@ -195,7 +254,7 @@ hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
     const bool rms = a.norm_w != nullptr;
     if (rms && !a.den) return hipErrorInvalidValue;
     dim3 grid((a.M + 127) / 128, a.N / 64);
-#define Q3_GEMM(E, R) hipLaunchKernelGGL((k_lm_gemm<E, R>), grid, dim3(256), 0, st, a)
+#define Q3_GEMM(E, R) do { if (a.xp) hipLaunchKernelGGL((k_lm_gemm<E, R, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_lm_gemm<E, R, false>), grid, dim3(256), 0, st, a); } while (0)
     switch (a.epi) {
         case EPI_NONE: if (rms) Q3_GEMM(EPI_NONE, true); else Q3_GEMM(EPI_NONE, false); break;
         case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM(EPI_RESID, false); break;
@@ -435,6 +494,136 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third generation: the transposed product. Sᵀ = K·Qᵀ (A = the staged K tile, B = the wave's Q registers) puts ONE
+// QUERY in each lane's accumulator column, so the online-softmax statistics are per-lane reductions over the 16
+// registers plus one cross-half shuffle (the S = Q·Kᵀ form above pays 160 lane shuffles per tile for them), and the
+// probabilities are already in B-operand position for Oᵀ = Vᵀ·Pᵀ — no LDS patch for P. MFMA step r of the second
+// product pairs the key of register r in the lower lane half with the key of register r in the upper half, which only
+// selects the V row each half reads. The next K/V tile is requested into registers before the current tile's MFMAs
+// and committed to LDS after the barrier, so the global round trip is off the critical path; long (late) query blocks
+// are dispatched first. 4105-position prefill of the 1.7B talker: 3.03 -> see DESIGN §4.5 ms of attention per layer.
+// ------------------------------------------------------------------------------------------------
+template <int NREP>
+__global__ __launch_bounds__(256) void k_attn_prefill_t(AttnArgs a) {
+    constexpr int ROWS_WG = 128 / NREP;
+    __shared__ __attribute__((aligned(16))) float sK[32 * KVP];
+    __shared__ __attribute__((aligned(16))) float sV[32 * KVP];
+    const int blk = (int)gridDim.x - 1 - (int)blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
+    const int rps = a.rows_per_seq;
+    const int base_pos = a.pos_dev ? a.pos_dev[seq] : a.pos_static;
+    const int head = kvh * NREP + (wave % NREP);
+    const int r0 = blk * ROWS_WG + (wave / NREP) * 32;         // first chunk row of this wave
+    const int wg_rows = (rps - blk * ROWS_WG) < ROWS_WG ? (rps - blk * ROWS_WG) : ROWS_WG;
+    const int wg_last_pos = base_pos + blk * ROWS_WG + wg_rows - 1;
+    const int n_tiles = wg_last_pos / 32 + 1;
+    const float scale = 0.08838834764831845f;
+
+    // Q as the B operand: lane (query i = li, lk) holds Q[i][64·lk + s], s = 0..63 (the head dimension is walked as
+    // d = 64·(lane/32) + step on both operands, so every LDS read of K is a float4)
+    float q[64];
+    {
+        const int i = r0 + li;
+        const bool ok = i < rps;
+        const float* src = a.qbuf + ((size_t)(seq * rps + (ok ? i : 0)) * a.nh + head) * HEAD_DIM + lk * 64;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 f = ok ? *reinterpret_cast<const float4*>(src + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+            q[4 * t] = f.x; q[4 * t + 1] = f.y; q[4 * t + 2] = f.z; q[4 * t + 3] = f.w;
+        }
+    }
+    pf32x16_t O[4];                                            // Oᵀ: tile b holds d = 32b + row(r, lk), column = query li
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[b][r] = 0.0f;
+    float m = -INFINITY, lsum = 0.0f;                          // lsum: this half's share of the row's denominator
+    const int qpos = base_pos + r0 + li;                       // this lane's query position
+    const int my_first_pos = base_pos + r0, my_last_pos = base_pos + r0 + 31;
+
+    const size_t cache_base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    const int skey = tid >> 3, sc = (tid & 7) * 16;            // staging role: key row, 16-float column chunk
+    float4 kst[4], vst[4];
+    auto fetch = [&](int tile) {
+        const int p = tile * 32 + skey;
+        const bool ok = p <= wg_last_pos;
+        const float* kp = a.kcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
+        const float* vp = a.vcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            kst[t] = ok ? *reinterpret_cast<const float4*>(kp + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vst[t] = ok ? *reinterpret_cast<const float4*>(vp + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();                                       // the previous tile's LDS reads are done
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            *reinterpret_cast<float4*>(&sK[skey * KVP + sc + 4 * t]) = kst[t];
+            *reinterpret_cast<float4*>(&sV[skey * KVP + sc + 4 * t]) = vst[t];
+        }
+        __syncthreads();
+        if (tile + 1 < n_tiles) fetch(tile + 1);               // lands under this tile's MFMAs
+        if (tile * 32 > my_last_pos) continue;                 // wave-uniform: every key of the tile is in this wave's future
+        pf32x16_t S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+        const float* krow = &sK[li * KVP + lk * 64];           // A operand: lane (key j = li, lk) = K[j][64·lk + s]
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 kf = *reinterpret_cast<const float4*>(krow + 4 * t);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, q[4 * t], S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, q[4 * t + 1], S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, q[4 * t + 2], S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, q[4 * t + 3], S, 0, 0, 0);
+        }
+        // register r of this lane = (key tile·32 + (r&3) + 8(r>>2) + 4·lk, query li): scale, causal mask, online softmax
+        const bool need_mask = tile * 32 + 31 > my_first_pos;
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int keypos = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            float sv = S[r] * scale;
+            if (need_mask && keypos > qpos) sv = -INFINITY;
+            S[r] = sv; cm = fmaxf(cm, sv);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);                         // finite from tile 0 on: key 0 is visible to every query
+        const float corr = expf(m - mn);
+        float ps = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float pe = expf(S[r] - mn); S[r] = pe; ps += pe; }
+        lsum = lsum * corr + ps;
+        m = mn;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[b][r] *= corr;
+        // Oᵀ += Vᵀ·Pᵀ: A operand lane (d = 32b + li, lk) = V[key_r(lk)][d]; B operand = S[r] (this lane's query column)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vrow = &sV[((r & 3) + 8 * (r >> 2) + 4 * lk) * KVP + li];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) O[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * b], S[r], O[b], 0, 0, 0);
+        }
+    }
+    const float den = lsum + __shfl_xor(lsum, 32);
+    const int row = r0 + li;
+    if (row < rps) {
+        float* dst = a.out + (size_t)(seq * rps + row) * a.ld_out + head * HEAD_DIM;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {                   // registers 4·r4 .. +3 are four consecutive d
+                const int d = 32 * b + 8 * r4 + 4 * lk;
+                float4 o4 = make_float4(O[b][4 * r4] / den, O[b][4 * r4 + 1] / den, O[b][4 * r4 + 2] / den, O[b][4 * r4 + 3] / den);
+                *reinterpret_cast<float4*>(dst + d) = o4;
+            }
+    }
+}
+
 hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st) {
     const int nrep = a.nh / a.nkv;
     const int rps = a.rows_per_seq;
@@ -443,9 +632,16 @@ hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st) {
     if (!valu && (nrep == 1 || nrep == 2 || nrep == 4)) {
         const int rows_wg = 128 / nrep;
         dim3 grid((rps + rows_wg - 1) / rows_wg, a.nkv, a.B / rps);
-        if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_mfma<1>), grid, dim3(256), 0, st, a);
-        else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_mfma<2>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_attn_prefill_mfma<4>), grid, dim3(256), 0, st, a);
+        static const bool gen2 = getenv("Q3_PREFILL_ATTN_GEN2") != nullptr;  // A/B aid: the S = Q·Kᵀ generation
+        if (gen2) {
+            if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_mfma<1>), grid, dim3(256), 0, st, a);
+            else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_mfma<2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_prefill_mfma<4>), grid, dim3(256), 0, st, a);
+        } else {
+            if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_t<1>), grid, dim3(256), 0, st, a);
+            else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_t<2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_prefill_t<4>), grid, dim3(256), 0, st, a);
+        }
         return hipGetLastError();
     }
     constexpr int RQ = 8;
