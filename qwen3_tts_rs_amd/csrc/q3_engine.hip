@@ -1501,9 +1501,10 @@ static q3_status prefill_gemm(q3_session* s, int S) {
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     const LmDims d = talker_dims(c);
     const int B = s->B, H = d.H, QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, I = d.I;
-    // positions per sequence per pass: about 2048 activation rows per GEMM launch (16 M-tiles x N/64 workgroups fill the
-    // chip; one 128-row tile per launch would leave 3/4 of the CUs idle), at least one 128-row tile per sequence
-    static const int rows_env = [] { const char* e = getenv("Q3_PREFILL_ROWS"); return e ? atoi(e) : 2048; }();
+    // positions per sequence per pass: up to 4224 activation rows per launch (a whole 4k-position prompt in one pass:
+    // 33 M-tiles x N/128 workgroups per GEMM, 520 attention workgroups; 2048-row passes: 113 ms instead of 99 for the
+    // 4105-position prefill of the 1.7B model), at least one 128-row tile per sequence
+    static const int rows_env = [] { const char* e = getenv("Q3_PREFILL_ROWS"); return e ? atoi(e) : 4224; }();
     int C = rows_env / B; C = C < 128 ? 128 : (C / 128) * 128;
     const int max_rows = B * (S < C ? S : C);
     DevPool tmp;

@@ -249,10 +249,134 @@ __global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second GEMM geometry (pre-split inputs only): 2 x 2 wave grid, a wave owns RT row tiles x 4 column tiles
+// (RT = 4, or 2 + 2 for the gate/up pair), workgroup tile (128 / NW) weight rows x 128 activation rows. Per 64-k stage
+// the vector-memory pipe still moves 80 KB (48 KB of planes + the weight fragments, each read by two waves) but now
+// under 96 MFMAs per wave instead of 48: the first geometry is bound by that pipe (64 B/clk per CU), this one by the
+// matrix cores.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, bool RMS>
+__global__ __launch_bounds__(256) void k_lm_gemm2(GemmArgs a) {
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int RT = 4 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 128 * GP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int mj = lane & 15, kg = lane >> 4;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int m0 = blockIdx.x * 128, rt0 = blockIdx.y * (2 * RT) + wr * RT;   // first activation row, this wave's first 16-row weight tile
+    const int S = a.Kpad >> 5;
+    const pu32x4_t* __restrict__ w1 = reinterpret_cast<const pu32x4_t*>(a.W);
+    const pu32x4_t* __restrict__ w2 = reinterpret_cast<const pu32x4_t*>(NW == 2 ? a.W2 : a.W);
+    constexpr size_t plane = (size_t)128 * GP;
+
+    pf32x4_t acc[NW][RT][4];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[w][r][c] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid >> 1, sk = (tid & 1) * 32;            // staging role: activation row, 32-k half of the stage
+    const bool srow_ok = (m0 + srow) < a.M;
+    pu32x4_t xt[3][4];
+    auto fetch_x = [&](int k0) {
+        const uint16_t* src = a.xp + (size_t)(srow_ok ? m0 + srow : 0) * a.Kpad + k0 + sk;
+        const bool kok = srow_ok && (k0 + sk) < a.Kpad;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xt[pl][q] = kok ? *reinterpret_cast<const pu32x4_t*>(src + pl * a.xp_plane + q * 8) : pu32x4_t{0u, 0u, 0u, 0u};
+    };
+    fetch_x(0);
+    for (int k0 = 0; k0 < a.Kpad; k0 += 64) {
+        pu32x4_t A[NW][RT][2];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int s = (k0 >> 5) + ks;
+                const size_t off = ((size_t)(rt0 + r) * S + (s < S ? s : S - 1)) * 64 + lane;
+                A[0][r][ks] = __builtin_nontemporal_load(w1 + off);
+                if constexpr (NW == 2) A[1][r][ks] = __builtin_nontemporal_load(w2 + off);
+            }
+        __syncthreads();
+        {
+            unsigned char* dst = smem + (size_t)srow * GP + sk * 2;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<pu32x4_t*>(dst + pl * plane + q * 16) = xt[pl][q];
+        }
+        __syncthreads();
+        if (k0 + 64 < a.Kpad) fetch_x(k0 + 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if ((k0 >> 5) + ks >= S) break;
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl) {                  // lo, mid, hi: the per-accumulator order of the first geometry
+                pu32x4_t B[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    B[c] = *reinterpret_cast<const pu32x4_t*>(smem + pl * plane + (size_t)(wc * 64 + c * 16 + mj) * GP + ks * 64 + kg * 16);
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[w][r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8_t, A[w][r][ks]),
+                                                                                  __builtin_bit_cast(pbf16x8_t, B[c]), acc[w][r][c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int m = m0 + wc * 64 + c * 16 + mj;
+        if (m >= a.M) continue;
+        const float den = RMS ? a.den[m] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int n = (rt0 + r) * 16 + kg * 4;
+            if (n >= a.N) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[0][r][c][e];
+                float v2 = NW == 2 ? acc[NW - 1][r][c][e] : 0.0f;
+                if constexpr (RMS) { v = v / den; if constexpr (NW == 2) v2 = v2 / den; }
+                if (a.bias) v = v + a.bias[n + e];
+                if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n + e] + v;
+                if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+                if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+                o[e] = v;
+            }
+            *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.Kpad % 32 || a.K % 4 || a.K > a.Kpad || a.ldx % 4 || a.ldy % 4 || a.N % 64 || a.M < 1 || !a.W) return hipErrorInvalidValue;
     const bool rms = a.norm_w != nullptr;
     if (rms && !a.den) return hipErrorInvalidValue;
+    static const bool geo1 = getenv("Q3_GEMM_GEO1") != nullptr;          // A/B aid: the 64 x 128 geometry
+    if (a.xp && !geo1) {
+        const int nt = a.epi == EPI_SWIGLU ? 64 : 128;
+        if (a.N % nt == 0) {
+            dim3 g2((a.M + 127) / 128, a.N / nt);
+#define Q3_GEMM2(E, R) hipLaunchKernelGGL((k_lm_gemm2<E, R>), g2, dim3(256), 0, st, a)
+            switch (a.epi) {
+                case EPI_NONE: if (rms) Q3_GEMM2(EPI_NONE, true); else Q3_GEMM2(EPI_NONE, false); return hipGetLastError();
+                case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM2(EPI_RESID, false); return hipGetLastError();
+                case EPI_SILU: if (rms) return hipErrorInvalidValue; Q3_GEMM2(EPI_SILU, false); return hipGetLastError();
+                case EPI_SWIGLU: if (!rms || !a.W2) return hipErrorInvalidValue; Q3_GEMM2(EPI_SWIGLU, true); return hipGetLastError();
+                default: return hipErrorInvalidValue;
+            }
+#undef Q3_GEMM2
+        }
+    }
     dim3 grid((a.M + 127) / 128, a.N / 64);
 #define Q3_GEMM(E, R) do { if (a.xp) hipLaunchKernelGGL((k_lm_gemm<E, R, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_lm_gemm<E, R, false>), grid, dim3(256), 0, st, a); } while (0)
     switch (a.epi) {
@@ -505,7 +629,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(AttnArgs a) {
 // are dispatched first. 4105-position prefill of the 1.7B talker: 3.03 -> see DESIGN §4.5 ms of attention per layer.
 // ------------------------------------------------------------------------------------------------
 template <int NREP>
-__global__ __launch_bounds__(256) void k_attn_prefill_t(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
     constexpr int ROWS_WG = 128 / NREP;
     __shared__ __attribute__((aligned(16))) float sK[32 * KVP];
     __shared__ __attribute__((aligned(16))) float sV[32 * KVP];
