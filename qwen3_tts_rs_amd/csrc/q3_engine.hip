@@ -1358,7 +1358,10 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     {
         static const int ns_env = [] { const char* e = getenv("Q3_ATTN_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid
         int ns = ns_env > 0 ? ns_env : 512 / (batch * c.n_kv_heads);      // ~2 attention workgroups per CU (B = 8: 8 splits, 3.99 vs 4.02 ms/frame at 4)
-        if (ns < 1) ns = 1; if (ns > MAX_SPLITS) ns = MAX_SPLITS; s->n_splits = ns;
+        // long contexts (a 4k-position prompt: 38 MB of f32 K/V per layer) want more than 16 workgroups per KV head to
+        // stream them (B = 1 at 4.1k positions: 3.90 -> 3.55 ms/frame); short sessions keep the cheaper 16-way merge
+        const int cap = ns_env > 0 ? MAX_SPLITS : (s->max_seq > 2048 ? MAX_SPLITS : 16);
+        if (ns < 1) ns = 1; if (ns > cap) ns = cap; s->n_splits = ns;
     }
     {   // the frame loop is a chain of ~600 short dependent kernels per frame: give its queue the highest priority so
         // that its workgroups are dispatched ahead of the vocoder segments running beside it (q3_session_run)

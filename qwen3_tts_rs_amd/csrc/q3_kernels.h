@@ -8,7 +8,7 @@
 namespace q3 {
 
 constexpr int HEAD_DIM = 128;        // talker / code-predictor head dim (kernels are specialised)
-constexpr int MAX_SPLITS = 16;       // KV splits of the decode attention
+constexpr int MAX_SPLITS = 64;       // KV splits of the decode attention (16 unless the context is long, see q3_session_create)
 constexpr int PART_STRIDE = HEAD_DIM + 2;   // partial record: acc[128], m, l
 
 // ---- bf16-weight skinny GEMM ("GEMV family"): y[m][n] = sum_k x[m][k] * W[n][k] ----

@@ -655,13 +655,14 @@ hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
 // fence + ticket atomic + acquire fence + agent-scope loads) was built and measured on MI355X: bit-identical output,
 // but the frame got 17 % SLOWER (1.7B, B = 8: 4.34 -> 5.07 ms) — device-scope fences write back / invalidate the XCD's
 // L2 under every later launch, while this kernel boundary costs 1.6 us.
+template <int NS>      // capacity of the fixed unroll: 16, or 64 for long-context sessions
 __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* rec = a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE;
     // all loads first (fixed unroll, predicated): one memory round trip instead of 2*n_splits dependent ones
-    float ms[MAX_SPLITS], ls[MAX_SPLITS], as[MAX_SPLITS];
+    float ms[NS], ls[NS], as[NS];
 #pragma unroll
-    for (int s = 0; s < MAX_SPLITS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const bool ok = s < a.n_splits;
         const float* r = rec + (ok ? s : 0) * PART_STRIDE;
         ms[s] = ok ? r[HEAD_DIM] : -INFINITY;
@@ -670,10 +671,10 @@ __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
     }
     float M = -INFINITY;
 #pragma unroll
-    for (int s = 0; s < MAX_SPLITS; ++s) M = fmaxf(M, ms[s]);
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, ms[s]);
     float L = 0.0f, A = 0.0f;
 #pragma unroll
-    for (int s = 0; s < MAX_SPLITS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const float wgt = ms[s] == -INFINITY ? 0.0f : expf(ms[s] - M);
         L += ls[s] * wgt;
         A += as[s] * wgt;
@@ -682,7 +683,8 @@ __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
 }
 
 hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_attn_merge, dim3(a.nh, a.B), dim3(128), 0, st, a);
+    if (a.n_splits <= 16) hipLaunchKernelGGL(k_attn_merge<16>, dim3(a.nh, a.B), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(k_attn_merge<MAX_SPLITS>, dim3(a.nh, a.B), dim3(128), 0, st, a);
     return hipGetLastError();
 }
 
