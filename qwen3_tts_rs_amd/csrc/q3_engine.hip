@@ -1518,6 +1518,12 @@ static q3_status prefill_gemm(q3_session* s, int S) {
     auto kp = [](int K) { return (K + 31) / 32 * 32; };
     // every GEMM input is split once into its three exact bf16 terms (launch_split_rows) instead of once per workgroup
     // column inside the GEMM; Q3_GEMM_NO_PLANES=1 keeps the in-kernel split (A/B aid)
+    // long prompts: every query block's key range is halved over two workgroups and merged (k_attn_prefill_t)
+    static const bool no_split = getenv("Q3_PREFILL_ATTN_NOSPLIT") != nullptr;
+    static const bool gen2_attn = getenv("Q3_PREFILL_ATTN_GEN2") != nullptr || getenv("Q3_PREFILL_ATTN_VALU") != nullptr;
+    const bool kv_split = !no_split && !gen2_attn && S >= 1024;
+    float* PART = nullptr;
+    if (kv_split) HIPC(tmp.alloc(&PART, (size_t)max_rows * d.nh * 2 * PART_STRIDE));
     static const bool no_planes = getenv("Q3_GEMM_NO_PLANES") != nullptr;
     const bool planes = !no_planes && H % 8 == 0 && QD % 8 == 0 && I % 8 == 0;
     const int kmax = std::max(kp(H), std::max(kp(QD), kp(I)));
@@ -1548,7 +1554,9 @@ static q3_status prefill_gemm(q3_session* s, int S) {
             t.max_seq = s->max_seq; t.qbuf = Qb; t.part = nullptr; t.out = ATT; t.ld_out = QD;
             t.B = rows; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = 1; t.rows_per_seq = ch;
             HIPC(launch_qknorm_rope_kv(t, s->stream));
+            if (kv_split) { t.part = PART; t.n_splits = 2; }
             HIPC(launch_attn_prefill(t, s->stream));
+            if (kv_split) HIPC(launch_attn_merge(t, s->stream));
             GemmArgs o; o.W = w.o.t1; o.x = ATT; o.ldx = QD; o.resid = X; o.ldr = H; o.y = SUM; o.ldy = H;
             o.M = rows; o.N = H; o.K = QD; o.Kpad = kp(QD); o.epi = EPI_RESID;
             HIPC(split(o)); HIPC(launch_lm_gemm(o, s->stream));

@@ -633,7 +633,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
     constexpr int ROWS_WG = 128 / NREP;
     __shared__ __attribute__((aligned(16))) float sK[32 * KVP];
     __shared__ __attribute__((aligned(16))) float sV[32 * KVP];
-    const int blk = (int)gridDim.x - 1 - (int)blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
+    // n_splits == 2: the key range of every query block is halved over two workgroups (partials in a.part, merged by
+    // k_attn_merge). All workgroups of a launch are resident at once, so the launch lasts as long as its longest
+    // workgroup — the last query block's walk over every key tile; halving that chain is worth more than the merge costs.
+    const int halves = a.n_splits == 2 ? 2 : 1;
+    const int bid = (int)gridDim.x - 1 - (int)blockIdx.x;      // long (late) query blocks first
+    const int blk = bid / halves, half = bid - blk * halves, kvh = blockIdx.y, seq = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
     const int rps = a.rows_per_seq;
     const int base_pos = a.pos_dev ? a.pos_dev[seq] : a.pos_static;
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
             q[4 * t] = f.x; q[4 * t + 1] = f.y; q[4 * t + 2] = f.z; q[4 * t + 3] = f.w;
         }
     }
-    pf32x16_t O[4];                                            // Oᵀ: tile b holds d = 32b + row(r, lk), column = query li
+    pf32x16_t O[4];                                            // Oᵀ: tile b holds d = 4·row(r, lk) + b, column = query li
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -680,8 +685,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
             vst[t] = ok ? *reinterpret_cast<const float4*>(vp + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    fetch(0);
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    const int h0 = (n_tiles + 1) / 2;
+    const int t_begin = (halves == 2 && half == 1) ? h0 : 0, t_end = (halves == 2 && half == 0) ? h0 : n_tiles;
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                                       // the previous tile's LDS reads are done
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
             *reinterpret_cast<float4*>(&sV[skey * KVP + sc + 4 * t]) = vst[t];
         }
         __syncthreads();
-        if (tile + 1 < n_tiles) fetch(tile + 1);               // lands under this tile's MFMAs
+        if (tile + 1 < t_end) fetch(tile + 1);                 // lands under this tile's MFMAs
         if (tile * 32 > my_last_pos) continue;                 // wave-uniform: every key of the tile is in this wave's future
         pf32x16_t S;
 #pragma unroll
@@ -725,26 +732,40 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[b][r] *= corr;
-        // Oᵀ += Vᵀ·Pᵀ: A operand lane (d = 32b + li, lk) = V[key_r(lk)][d]; B operand = S[r] (this lane's query column)
+        // Oᵀ += Vᵀ·Pᵀ: A operand lane (row li, lk) = V[key_r(lk)][4·li + b] — output row i of tile b is d = 4i + b, so a
+        // lane's four tiles read one float4 of V per step (16 ds_read_b128 per tile instead of 64 ds_read_b32) and
+        // finish as four consecutive d; B operand = S[r] (this lane's query column)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float* vrow = &sV[((r & 3) + 8 * (r >> 2) + 4 * lk) * KVP + li];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) O[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * b], S[r], O[b], 0, 0, 0);
+            const float4 vf = *reinterpret_cast<const float4*>(&sV[((r & 3) + 8 * (r >> 2) + 4 * lk) * KVP + 4 * li]);
+            O[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, S[r], O[0], 0, 0, 0);
+            O[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, S[r], O[1], 0, 0, 0);
+            O[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, S[r], O[2], 0, 0, 0);
+            O[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, S[r], O[3], 0, 0, 0);
         }
     }
     const float den = lsum + __shfl_xor(lsum, 32);
     const int row = r0 + li;
+    if (halves == 2) {
+        if (row < rps) {                                       // partial record: O (relative to m), m, l — k_attn_merge's format
+            float* rec = a.part + (((size_t)(seq * rps + row) * a.nh + head) * 2 + half) * PART_STRIDE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                *reinterpret_cast<float2*>(rec + 4 * i) = make_float2(O[0][r], O[1][r]);
+                *reinterpret_cast<float2*>(rec + 4 * i + 2) = make_float2(O[2][r], O[3][r]);
+            }
+            if (lk == 0) { rec[HEAD_DIM] = m; rec[HEAD_DIM + 1] = den; }
+        }
+        return;
+    }
     if (row < rps) {
         float* dst = a.out + (size_t)(seq * rps + row) * a.ld_out + head * HEAD_DIM;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {                   // registers 4·r4 .. +3 are four consecutive d
-                const int d = 32 * b + 8 * r4 + 4 * lk;
-                float4 o4 = make_float4(O[b][4 * r4] / den, O[b][4 * r4 + 1] / den, O[b][4 * r4 + 2] / den, O[b][4 * r4 + 3] / den);
-                *reinterpret_cast<float4*>(dst + d) = o4;
-            }
+        for (int r = 0; r < 16; ++r) {                         // register r of the four tiles = d 4i .. 4i+3, i = row(r, lk)
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            *reinterpret_cast<float4*>(dst + 4 * i) = make_float4(O[0][r] / den, O[1][r] / den, O[2][r] / den, O[3][r] / den);
+        }
     }
 }
 
@@ -757,6 +778,7 @@ hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st) {
         const int rows_wg = 128 / nrep;
         dim3 grid((rps + rows_wg - 1) / rows_wg, a.nkv, a.B / rps);
         static const bool gen2 = getenv("Q3_PREFILL_ATTN_GEN2") != nullptr;  // A/B aid: the S = Q·Kᵀ generation
+        if (!gen2 && a.n_splits == 2 && a.part) grid.x *= 2;
         if (gen2) {
             if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_mfma<1>), grid, dim3(256), 0, st, a);
             else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_mfma<2>), grid, dim3(256), 0, st, a);
