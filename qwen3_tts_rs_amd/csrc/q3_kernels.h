@@ -45,6 +45,7 @@ struct GemmArgs {
     // [3][plane_elems] bf16, row pitch Kpad. The GEMM then stages plain copies instead of redoing the split in every
     // one of its N/64 workgroup columns.
     const uint16_t* xp = nullptr; size_t xp_plane = 0;
+    int n_split = 1;                                             // set by launch_lm_gemm: N range cut into this many XCD work units per M tile
 };
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st);
 // planes[pl][row][k] (pitch Kpad, zero beyond K) = pl-th bf16 term of x[row][k] * (norm_w ? norm_w[k] : 1); K % 8 == 0

@@ -264,7 +264,21 @@ __global__ __launch_bounds__(256) void k_lm_gemm2(GemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int mj = lane & 15, kg = lane >> 4;
     const int wr = wave & 1, wc = wave >> 1;
-    const int m0 = blockIdx.x * 128, rt0 = blockIdx.y * (2 * RT) + wr * RT;   // first activation row, this wave's first 16-row weight tile
+    // XCD-aware work order. Workgroup b runs on XCD b % 8 and each XCD has its own 4 MB L2. A work unit = one 128-row
+    // M tile x one n_split-th of the N tiles; unit u belongs to XCD u % 8, and the workgroups of a unit are consecutive
+    // on that XCD, so the unit's activation planes (1.5 MB at K = 2048) are fetched into that L2 once and every weight
+    // tile streams past them. In plain (M tile, N tile) order the planes of all 33 M tiles cycle through the L2 between
+    // two uses: each GEMM re-read its input N/128 times from the Infinity Cache (9.6 GB per layer at 4105 positions)
+    // and was bound by exactly that.
+    int mt, ntile;
+    {
+        const int nMt = (a.M + 127) / 128, nNt = a.N / (128 / NW), Q = a.n_split, per = nNt / Q;
+        const int lin = (int)blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        const int u = xcd + 8 * (j / per);                         // this XCD's (j / per)-th unit
+        if (u >= nMt * Q) return;                                   // padding workgroups of the last round
+        mt = u / Q; ntile = (u - mt * Q) * per + j % per;
+    }
+    const int m0 = mt * 128, rt0 = ntile * (2 * RT) + wr * RT;     // first activation row, this wave's first 16-row weight tile
     const int S = a.Kpad >> 5;
     const pu32x4_t* __restrict__ w1 = reinterpret_cast<const pu32x4_t*>(a.W);
     const pu32x4_t* __restrict__ w2 = reinterpret_cast<const pu32x4_t*>(NW == 2 ? a.W2 : a.W);
@@ -365,8 +379,14 @@ hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.xp && !geo1) {
         const int nt = a.epi == EPI_SWIGLU ? 64 : 128;
         if (a.N % nt == 0) {
-            dim3 g2((a.M + 127) / 128, a.N / nt);
-#define Q3_GEMM2(E, R) hipLaunchKernelGGL((k_lm_gemm2<E, R>), g2, dim3(256), 0, st, a)
+            static const int q_env = [] { const char* e = getenv("Q3_GEMM_NSPLIT"); return e ? atoi(e) : 0; }();   // tuning aid
+            const int nMt = (a.M + 127) / 128, nNt = a.N / nt;
+            int Q = q_env > 0 ? q_env : 2;
+            while (Q > 1 && nNt % Q) --Q;
+            GemmArgs b = a; b.n_split = Q;
+            const int units = nMt * Q, rounds = (units + 7) / 8;
+            dim3 g2(8 * rounds * (nNt / Q));
+#define Q3_GEMM2(E, R) hipLaunchKernelGGL((k_lm_gemm2<E, R>), g2, dim3(256), 0, st, b)
             switch (a.epi) {
                 case EPI_NONE: if (rms) Q3_GEMM2(EPI_NONE, true); else Q3_GEMM2(EPI_NONE, false); return hipGetLastError();
                 case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM2(EPI_RESID, false); return hipGetLastError();
