@@ -87,18 +87,28 @@ def main():
     opts = q.SynthesisOptions(max_length=args.frames, eos_token_id=None, seed=42)
     use_graph = not args.no_graph
 
+    phase_ms = []       # (create, run, close) wall per step: the timed step is all three
+
     def one_step():
+        ta = time.perf_counter()
         s = model.session(utts, opts)
+        tb = time.perf_counter()
         try:
             return s.run_timing_only(use_graph=use_graph)
         finally:
+            tc = time.perf_counter()
             s.close()
+            phase_ms.append([(tb - ta) * 1e3, (tc - tb) * 1e3, (time.perf_counter() - tc) * 1e3])
 
     for _ in range(args.warmup):
         one_step()
     dp.barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    timings = [one_step() for _ in range(args.steps)]
+    timings, step_wall = [], []
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        timings.append(one_step())
+        step_wall.append((time.perf_counter() - ts) * 1000.0)
     torch.cuda.synchronize(dev); dp.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(elapsed, device=f"cuda:{dev}" if world > 1 else None)
@@ -235,7 +245,7 @@ def main():
                                f"(eos off), default sampling, non-streaming prefill+generate+decode",
                    "utterances_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"dp{world}",
                    "weights": "bf16", "activations_kv": "f32", "hip_graph": use_graph},
-        "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "latency": lat,
+        "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s},
         "roofline": roofline, "cpu_baseline": cpu,
     }

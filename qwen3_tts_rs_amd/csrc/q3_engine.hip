@@ -19,6 +19,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -780,18 +781,78 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// device buffer helper
+// device buffer helpers
 // ------------------------------------------------------------------------------------------------
+// Session-lifetime buffers (KV pages, workspaces, vocoder scratch) come from a small per-device cache of exact-size
+// blocks: a server creates sessions of a few recurring shapes, and hipMalloc / hipFree of multi-GB blocks on the
+// request path costs driver time that varies from box to box (VRAM clearing, page-table work) — up to 150 ms per
+// 16-utterance session was seen in otherwise identical runs. Blocks are returned only by owners that have
+// synchronised the streams that used them (q3_session_free, prefill_gemm); at most Q3_DEV_CACHE_MB (default 32768)
+// MB stay cached per process, beyond that blocks go back to the driver. HBM is 288 GB: capacity is not the constraint.
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::unordered_multimap<uint64_t, void*> free_blocks;      // key = device << 48 | bytes
+    std::unordered_map<void*, uint64_t> live;                  // blocks handed out by get()
+    size_t cached = 0, cap = 0;
+    DevCache() { const char* e = getenv("Q3_DEV_CACHE_MB"); cap = (size_t)(e ? atol(e) : 32768) << 20; }
+    static uint64_t key(int dev, size_t bytes) { return ((uint64_t)dev << 48) | (uint64_t)bytes; }
+    hipError_t get(void** p, size_t bytes) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        const uint64_t k = key(dev, bytes);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = free_blocks.find(k);
+            if (it != free_blocks.end()) { *p = it->second; free_blocks.erase(it); cached -= bytes; live[*p] = k; return hipSuccess; }
+        }
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) {                                  // out of memory: give the cache back and retry once
+            trim(0);
+            e = hipMalloc(p, bytes);
+            if (e != hipSuccess) return e;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        live[*p] = k;
+        return hipSuccess;
+    }
+    void put(void* p) {
+        if (!p) return;
+        uint64_t k = 0; bool known = false;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = live.find(p);
+            if (it != live.end()) { k = it->second; known = true; live.erase(it); }
+            const size_t bytes = (size_t)(k & 0xffffffffffffull);
+            if (known && cap && cached + bytes <= cap) { free_blocks.emplace(k, p); cached += bytes; return; }
+        }
+        (void)hipFree(p);
+    }
+    void trim(size_t keep) {
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto it = free_blocks.begin(); it != free_blocks.end() && cached > keep;) {
+                cached -= (size_t)(it->first & 0xffffffffffffull); drop.push_back(it->second); it = free_blocks.erase(it);
+            }
+        }
+        for (void* p : drop) (void)hipFree(p);
+    }
+};
+DevCache& dev_cache() { static DevCache* c = new DevCache(); return *c; }    // leaked on purpose: outlives every static destructor
+}  // namespace
+static inline hipError_t dev_malloc(void** p, size_t bytes) { return dev_cache().get(p, bytes ? bytes : 4); }
+static inline void dev_free(void* p) { dev_cache().put(p); }
+
 struct DevPool {
     std::vector<void*> ptrs;
     template <typename T> hipError_t alloc(T** p, size_t count) {
         void* q = nullptr;
-        hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        hipError_t e = dev_malloc(&q, (count ? count : 1) * sizeof(T));
         if (e != hipSuccess) return e;
         ptrs.push_back(q); *p = (T*)q;
         return hipMemset(q, 0, (count ? count : 1) * sizeof(T));
     }
-    ~DevPool() { for (void* p : ptrs) hipFree(p); }
+    ~DevPool() { for (void* p : ptrs) dev_free(p); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -810,7 +871,7 @@ struct CodecWS {
     float *cs = nullptr, *sn = nullptr;
     uint32_t* frames = nullptr; float* pcm = nullptr;
     void release() {
-        hipFree(bufA); hipFree(bufB); hipFree(bufC); hipFree(bufF); hipFree(bufD); hipFree(bufE); hipFree(cs); hipFree(sn); hipFree(frames); hipFree(pcm);
+        dev_free(bufA); dev_free(bufB); dev_free(bufC); dev_free(bufF); dev_free(bufD); dev_free(bufE); dev_free(cs); dev_free(sn); dev_free(frames); dev_free(pcm);
         bufA = bufB = bufC = bufF = bufD = bufE = cs = sn = pcm = nullptr; frames = nullptr; cap_frames = 0; cap_front = 0;
     }
 };
@@ -821,6 +882,7 @@ static q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T, int Tf = 0
     if (T <= ws.cap_frames && Tf <= ws.cap_front) return Q3_OK;
     if (T < ws.cap_frames) T = ws.cap_frames;
     if (Tf < ws.cap_front) Tf = ws.cap_front;
+    if (ws.bufA) HIPC(hipDeviceSynchronize());        // growing: the old blocks go back to the cache, nothing may still be using them
     ws.release();
     const q3_config& c = m->cfg;
     int up = 1; for (int i = 0; i < 2; ++i) up *= c.dec_up_ratios[i];
@@ -837,14 +899,14 @@ static q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T, int Tf = 0
     if ((size_t)c.dec_q_dim > per_front) per_front = (size_t)c.dec_q_dim;
     size_t n = per * (size_t)T;
     if (per_front * (size_t)Tf > n) n = per_front * (size_t)Tf;
-    HIPC(hipMalloc((void**)&ws.bufA, n * 4)); HIPC(hipMalloc((void**)&ws.bufB, n * 4)); HIPC(hipMalloc((void**)&ws.bufC, n * 4));
-    HIPC(hipMalloc((void**)&ws.bufF, n * 4));
+    HIPC(dev_malloc((void**)&ws.bufA, n * 4)); HIPC(dev_malloc((void**)&ws.bufB, n * 4)); HIPC(dev_malloc((void**)&ws.bufC, n * 4));
+    HIPC(dev_malloc((void**)&ws.bufF, n * 4));
     const size_t small = (size_t)Tf * (size_t)(QDm > c.dec_latent ? QDm : c.dec_latent);
-    HIPC(hipMalloc((void**)&ws.bufD, small * 4)); HIPC(hipMalloc((void**)&ws.bufE, small * 4));
-    HIPC(hipMalloc((void**)&ws.cs, (size_t)Tf * 32 * 4)); HIPC(hipMalloc((void**)&ws.sn, (size_t)Tf * 32 * 4));
-    HIPC(hipMalloc((void**)&ws.frames, (size_t)Tf * 16 * 4));
+    HIPC(dev_malloc((void**)&ws.bufD, small * 4)); HIPC(dev_malloc((void**)&ws.bufE, small * 4));
+    HIPC(dev_malloc((void**)&ws.cs, (size_t)Tf * 32 * 4)); HIPC(dev_malloc((void**)&ws.sn, (size_t)Tf * 32 * 4));
+    HIPC(dev_malloc((void**)&ws.frames, (size_t)Tf * 16 * 4));
     size_t total_up = up; for (int b = 0; b < 4; ++b) total_up *= c.dec_up_rates[b];
-    HIPC(hipMalloc((void**)&ws.pcm, (size_t)T * total_up * 4));
+    HIPC(dev_malloc((void**)&ws.pcm, (size_t)T * total_up * 4));
     // RoPE table of the pre-transformer (decoder_12hz.rs:541-553), host libm
     std::vector<float> cs((size_t)Tf * 32), sn((size_t)Tf * 32);
     for (int i = 0; i < 32; ++i) {
@@ -1425,7 +1487,7 @@ extern "C" void q3_session_free(q3_session* s) {
     if (s->graph) hipGraphDestroy(s->graph);
     for (auto& ev : s->prof_pool) hipEventDestroy(ev);
     s->cws.release(); s->seg_ws.release();
-    if (s->pcm_all) hipFree(s->pcm_all);
+    if (s->pcm_all) dev_free(s->pcm_all);
     if (s->dec_ev) hipEventDestroy(s->dec_ev);
     if (s->dec_stream) hipStreamDestroy(s->dec_stream);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -1876,9 +1938,9 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
     }
     Q3C(codec_reserve(s->m, s->seg_ws, seg_env + CODEC_CTX_FRAMES, s->max_frames));
     if (s->pcm_all_floats < (size_t)s->B * s->max_frames * spf) {
-        if (s->pcm_all) HIPC(hipFree(s->pcm_all));
+        if (s->pcm_all) dev_free(s->pcm_all);
         s->pcm_all_floats = (size_t)s->B * s->max_frames * spf;
-        HIPC(hipMalloc((void**)&s->pcm_all, s->pcm_all_floats * 4));
+        HIPC(dev_malloc((void**)&s->pcm_all, s->pcm_all_floats * 4));
     }
     std::vector<int> dec_pos((size_t)s->B, 0);
     std::thread worker; q3_status wst = Q3_OK; std::string werr;
