@@ -63,7 +63,8 @@ struct ConvDev {
     const float* post_a; const float* post_ib;   // SnakeBeta applied to the OUTPUT (the consumer's activation)
     float* y2;                    // if set: y gets the raw value, y2 the activated one; else y gets the activated value
     const void* wpk;              // bf16x3-packed weights (launch_pack_conv_w) or nullptr
-    size_t wpk_phase_stride;      // 16-byte units per blockIdx.z
+    size_t wpk_phase_stride;      // 16-byte units per phase
+    int phases;                   // k_conv_bf16x3: phases folded into its 1-D grid (set by the launcher)
 };
 
 __global__ __launch_bounds__(256) void k_conv1d(ConvDev a) {
@@ -351,11 +352,17 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     // nco channel tiles of one time tile all stage the same x. They are therefore made consecutive *on one XCD*
     // (ids 8 apart) instead of nt dispatches apart: the x tile comes from HBM once, not nco times
     // (profiles/r1_pmc_vocoder_hbm_T640.txt).
-    int bx, by;
+    // The phases of a polyphase transposed conv (a.phases > 1) join the same grouping: phase p writes every stride-th
+    // output sample, so the phases of one tile fill the same cache lines — issued from one XCD back to back the lines
+    // are completed in that L2; as separate grid planes on whichever XCD they reached HBM as partial-line writes
+    // (PMC: 2.8 GB written per launch for a 0.47 GB output).
+    int bx, by, bz;
     {
-        const int nco = a.cout / CO_WG, nt = (int)gridDim.x / nco, nt8 = nt & ~7, lin = (int)blockIdx.x;
-        if (lin < nt8 * nco) { const int r = lin >> 3; by = r % nco; bx = (r / nco) * 8 + (lin & 7); }
-        else { const int rem = lin - nt8 * nco; by = rem % nco; bx = nt8 + rem / nco; }
+        const int P = a.phases, nco = a.cout / CO_WG, per = nco * P, nt = (int)gridDim.x / per, nt8 = nt & ~7, lin = (int)blockIdx.x;
+        int r, tt;
+        if (lin < nt8 * per) { r = lin >> 3; tt = (r / per) * 8 + (lin & 7); r = r % per; }
+        else { const int rem = lin - nt8 * per; tt = nt8 + rem / per; r = rem % per; }
+        bx = tt; bz = r % P; by = r / P;
     }
     const int t0 = bx * T_WG, co0 = by * CO_WG + wco * (32 * CO_M);
     for (int i = tid; i < CO_WG; i += NT) {
@@ -368,8 +375,8 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     }
     const int halo = (K - 1) * a.dil, W = T_WG + halo;
     const size_t plane = (size_t)W * XP;
-    const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk) + (size_t)blockIdx.z * a.wpk_phase_stride;
-    const int ooff = a.ooff + (int)blockIdx.z * a.ooff_phase;
+    const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk) + (size_t)bz * a.wpk_phase_stride;
+    const int ooff = a.ooff + bz * a.ooff_phase;
     const int nc16 = a.cin >> 4;
 
     f32x16_t acc[CO_M][T_M];
@@ -611,14 +618,15 @@ template <int K, int CO_M, int T_M, int WCO, int WT>
 static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     const size_t lds = (size_t)3 * (T_WG + (K - 1) * a.dil) * XP;
-    dim3 grid(((a.L + T_WG - 1) / T_WG) * (a.cout / CO_WG), 1, phases);      // tile order: see the kernel
+    dim3 grid(((a.L + T_WG - 1) / T_WG) * (a.cout / CO_WG) * phases);         // tile order: see the kernel
+    ConvDev ap = a; ap.phases = phases;
     constexpr bool K1 = K == 1;
     const bool segm = conv_segmented(a.k, a.cin);
     if (K1 && segm) {
-        if (CO_M == 1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1, K1>), grid, dim3(64 * WCO * WT), lds, st, a);
-        else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, false, K1>), grid, dim3(64 * WCO * WT), lds, st, a);
-    } else if (CO_M == 1 && K1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1>), grid, dim3(64 * WCO * WT), lds, st, a);
-    else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, dim3(64 * WCO * WT), lds, st, a);
+        if (CO_M == 1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1, K1>), grid, dim3(64 * WCO * WT), lds, st, ap);
+        else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, false, K1>), grid, dim3(64 * WCO * WT), lds, st, ap);
+    } else if (CO_M == 1 && K1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1>), grid, dim3(64 * WCO * WT), lds, st, ap);
+    else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, dim3(64 * WCO * WT), lds, st, ap);
     return hipGetLastError();
 }
 template <int K>
