@@ -850,7 +850,12 @@ struct DevPool {
         hipError_t e = dev_malloc(&q, (count ? count : 1) * sizeof(T));
         if (e != hipSuccess) return e;
         ptrs.push_back(q); *p = (T*)q;
-        return hipMemset(q, 0, (count ? count : 1) * sizeof(T));
+        // zero-fill on the null stream and WAIT for it: the users launch on non-blocking streams, which the null stream
+        // does not order against — a memset still in flight would wipe what their first kernels write (seen once the
+        // blocks started coming from the cache instead of a slow hipMalloc)
+        hipError_t m = hipMemsetAsync(q, 0, (count ? count : 1) * sizeof(T), nullptr);
+        if (m != hipSuccess) return m;
+        return hipStreamSynchronize(nullptr);
     }
     ~DevPool() { for (void* p : ptrs) dev_free(p); }
 };

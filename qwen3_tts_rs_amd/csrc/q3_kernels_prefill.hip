@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(AttnArgs a) {
 // and committed to LDS after the barrier, so the global round trip is off the critical path; long (late) query blocks
 // are dispatched first. 4105-position prefill of the 1.7B talker: 3.03 -> see DESIGN §4.5 ms of attention per layer.
 // ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int rps_blocks(int rps, int rows_wg) { return (rps + rows_wg - 1) / rows_wg; }
 template <int NREP>
 __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
     constexpr int ROWS_WG = 128 / NREP;
@@ -657,8 +658,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
     // k_attn_merge). All workgroups of a launch are resident at once, so the launch lasts as long as its longest
     // workgroup — the last query block's walk over every key tile; halving that chain is worth more than the merge costs.
     const int halves = a.n_splits == 2 ? 2 : 1;
-    const int bid = (int)gridDim.x - 1 - (int)blockIdx.x;      // long (late) query blocks first
-    const int blk = bid / halves, half = bid - blk * halves, kvh = blockIdx.y, seq = blockIdx.z;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8; (sequence, kv head) pair p is served by XCD p % 8 only, so the
+    // 4.2 MB of K/V a pair's query blocks all walk (4105 positions) stay in that XCD's L2 instead of cycling eight
+    // pairs' worth through every L2. Within an XCD: long (late) query blocks first.
+    int blk, half, kvh, seq;
+    {
+        const int nb = (rps_blocks(a.rows_per_seq, ROWS_WG)) * halves, npairs = (a.B / a.rows_per_seq) * a.nkv;
+        const int lin = (int)blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        const int pair = xcd + 8 * (j / nb);                    // this XCD's (j / nb)-th pair
+        if (pair >= npairs) return;                             // padding workgroups of the last round
+        const int bid = nb - 1 - j % nb;
+        blk = bid / halves; half = bid - blk * halves; kvh = pair % a.nkv; seq = pair / a.nkv;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
     const int rps = a.rows_per_seq;
     const int base_pos = a.pos_dev ? a.pos_dev[seq] : a.pos_static;
@@ -804,9 +815,11 @@ hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st) {
             else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_mfma<2>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_prefill_mfma<4>), grid, dim3(256), 0, st, a);
         } else {
-            if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_t<1>), grid, dim3(256), 0, st, a);
-            else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_t<2>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_attn_prefill_t<4>), grid, dim3(256), 0, st, a);
+            const int npairs = (a.B / rps) * a.nkv, rounds = (npairs + 7) / 8;
+            dim3 g1((unsigned)(8 * rounds) * grid.x);            // grid.x already counts (query blocks x key halves)
+            if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_t<1>), g1, dim3(256), 0, st, a);
+            else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_t<2>), g1, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_prefill_t<4>), g1, dim3(256), 0, st, a);
         }
         return hipGetLastError();
     }

@@ -599,7 +599,23 @@ def test_full_size_gemm_prefill(size):
             f, g = np.argwhere(codes != ocodes)[0]
             pytest.fail(f"sequence {b}: first divergence at frame {f} group {g}")
         osess.close()
-    s.close(); gm.close(); om.close()
+    ref_codes = [s.codes(b).copy() for b in range(2)]
+    s.close()
+    # sessions come and go on one model: their buffers are recycled device blocks (DevCache) that must be zeroed and
+    # ordered against the non-blocking session stream — a long 4k-position prompt three times in a row, then the first
+    # batch again, bit-identical each time
+    long_utt = q.Utterance(synthetic_prompt(8, 3), language=q.Language.German, instruct_ids=synthetic_prompt(4000, 77), seed=11)
+    got = []
+    for rep in range(3):
+        s2 = gm.session([long_utt], q.SynthesisOptions(max_length=3, seed=11, eos_token_id=None)); s2.prefill(); s2.generate(3)
+        got.append((s2.get(2, (cfg.codec_vocab,), b=0).copy(), s2.codes(0).copy())); s2.close()
+    assert np.isfinite(got[0][0]).all() and got[0][1].max() > 0
+    for lg, cd in got[1:]:
+        assert np.array_equal(lg, got[0][0]) and np.array_equal(cd, got[0][1])
+    s3 = gm.session(utts, opts); s3.prefill(); s3.generate(4)
+    for b in range(2):
+        assert np.array_equal(s3.codes(b), ref_codes[b])
+    s3.close(); gm.close(); om.close()
 
 
 @pytest.mark.gpu
