@@ -513,6 +513,25 @@ class Qwen3TTS:
                              continuous: bool = False) -> StreamingSession:
         return StreamingSession(self, Utterance(text_ids, speaker, language), options or SynthesisOptions(), continuous)
 
+    def synthesize_voice_design_streaming(self, text_ids, instruct_ids, language: Language, options=None,
+                                          continuous: bool = False) -> StreamingSession:
+        """synthesize_voice_design_streaming (lib.rs:1095-1128)."""
+        return StreamingSession(self, Utterance(text_ids, language=language, instruct_ids=instruct_ids), options or SynthesisOptions(), continuous)
+
+    def synthesize_voice_clone_debug(self, text_ids, prompt, language: Language, options=None):
+        """synthesize_voice_clone_debug (lib.rs:897-1046): (AudioBuffer, FrameCodes) for a VoiceClonePrompt."""
+        return self.synthesize_voice_clone(text_ids, prompt.speaker_embedding, language, options,
+                                           ref_codes=prompt.ref_codes, ref_text_ids=prompt.ref_text_ids)
+
+    def device(self) -> str:                            # lib.rs:1325-1327
+        return f"hip:{self.device_index}"
+
+    @classmethod
+    def from_pretrained_with_tokenizer(cls, model_dir: str, tokenizer_dir: Optional[str], device: int = 0):
+        """from_pretrained_with_tokenizer (lib.rs:192-262): (model, TextTokenizer) — tokenization stays on the host side."""
+        from .text import TextTokenizer
+        return cls.from_pretrained(model_dir, device), TextTokenizer.from_pretrained(model_dir, tokenizer_dir)
+
     def decode_codes(self, codes: np.ndarray, taps=None) -> AudioBuffer:
         """decode_codes (lib.rs:881-890): codes [n][16] u32."""
         c = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, 16)

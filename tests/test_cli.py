@@ -85,3 +85,23 @@ def test_e2e_bench_report_schema(tmp_path):
     assert e2e_bench.main(["--synthetic", "tiny", "--iterations", "1", "--warmup", "0", "--only", "short", "--max-frames", "12", "--streaming",
                            "--json-output", str(p)]) == 0
     assert json.load(open(p))["results"][0]["ttfa_ms"] > 0
+
+
+def test_api_surface_mirrors_the_reference():
+    """Every public method of `Qwen3TTS` the reference exports (lib.rs:183-1325, SURVEY.md §8b "Signatures to mirror") has
+    a counterpart on the Python host-side mirror; constants and enums carry the reference's values."""
+    import qwen3_tts_rs_amd as q
+    want = ["from_pretrained", "from_pretrained_with_tokenizer", "from_tensors", "synthesize", "synthesize_with_voice",
+            "synthesize_with_timing", "synthesize_voice_design", "create_voice_clone_prompt", "synthesize_voice_clone",
+            "synthesize_voice_clone_debug", "synthesize_streaming", "synthesize_voice_design_streaming", "decode_codes",
+            "supports_voice_cloning", "supports_preset_speakers", "supports_voice_design", "has_speech_encoder", "device"]
+    for name in want:
+        assert callable(getattr(q.Qwen3TTS, name)), name
+    for name in ("next_chunk", "frames_generated", "is_done", "__iter__"):
+        assert hasattr(q.StreamingSession, name), name
+    assert q.CODEC_EOS_TOKEN_ID == 2150 and q.SAMPLES_PER_FRAME == 1920                      # lib.rs:1466-1469
+    o = q.SynthesisOptions()                                                                  # lib.rs:1786-1836
+    assert (o.max_length, o.temperature, o.top_k, o.top_p, o.repetition_penalty, o.eos_token_id, o.chunk_frames, o.min_new_tokens) == \
+        (2048, 0.9, 50, 0.9, 1.05, 2150, 10, 2)
+    assert q.Speaker.from_str("ryan") == q.Speaker.Ryan and q.Speaker.Ryan.token_id() == 3061 and q.Language.from_str("en").token_id() == 2050
+    assert callable(api.codes_to_tensor) and callable(api.resample_to_24k) and callable(api.auto_device)
