@@ -671,3 +671,50 @@ def test_error_contract(pair):
     with pytest.raises(E, match="unknown tensor name"):
         gm.set_tensor("talker.model.layers.99.nope", np.zeros(4, np.float32), 0)
     assert _lib.lib.q3_last_error().decode().startswith("unknown tensor name")
+
+
+@pytest.mark.gpu
+def test_soak_mixed_sessions_are_deterministic(pair):
+    """Sessions of changing shape come and go on one model (recycled device blocks, graph capture per session, streaming
+    read-ahead): the same request gives the same codes and PCM whenever it runs, in whatever company."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(2024)
+
+    def request(i):      # key i = (kind, text length); a batch holds one kind (equal prefill lengths, as the engine requires)
+        kind = ["custom", "design", "clone"][i // 9]
+        return _utts(kind, 5 + (i % 9), hidden=cfg.hidden)
+
+    def run_batch(idx, frames):
+        opts = q.SynthesisOptions(max_length=frames, seed=100, eos_token_id=None)
+        us = [request(i) for i in idx]
+        for k, u in enumerate(us):
+            u.seed = 100 + idx[k]
+        s = gm.session(us, opts); s.prefill(); s.generate(frames)
+        out = [(s.codes(b).copy(), s.decode(b).copy()) for b in range(len(us))]
+        s.close()
+        return out
+
+    ref = {}
+    for it in range(40):
+        B = int(rng.integers(1, 6)); frames = int(rng.integers(3, 14))
+        kind = int(rng.integers(0, 3))
+        idx = [9 * kind + int(x) for x in rng.integers(0, 9, size=B)]
+        if it % 5 == 4:                                     # a streaming session in between (read-ahead, second stream)
+            i0 = idx[0]; u = request(i0); u.seed = 100 + i0
+            ss = api.StreamingSession(gm, u, q.SynthesisOptions(max_length=frames, seed=100, eos_token_id=None, chunk_frames=4), continuous=(it % 10 == 9))
+            chunks = [c.samples for c in ss]
+            codes = ss._s.codes(0).copy(); ss._s.close()
+            assert sum(len(c) for c in chunks) == frames * 1920
+            key = (i0, frames)
+            if key in ref:
+                assert np.array_equal(codes, ref[key][0])
+            continue
+        out = run_batch(idx, frames)
+        for k, i in enumerate(idx):
+            key = (i, frames)
+            if key in ref:
+                assert np.array_equal(out[k][0], ref[key][0]), (it, key)
+                assert np.array_equal(out[k][1], ref[key][1]), (it, key)
+            else:
+                ref[key] = out[k]
+    assert len(ref) > 20
