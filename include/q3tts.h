@@ -157,7 +157,9 @@ q3_status q3_synth_fill(uint64_t seed, const char* name, int dtype, float scale,
 /* ---------------- session = one batch of utterances on one GPU ----------------
  * Owns KV pages, RNG streams, penalty masks (the fields of StreamingSession, lib.rs:1484-1508).
  * batch > 1 has no reference counterpart (reference batch = 1): every sequence behaves exactly
- * as its own batch-1 run. */
+ * as its own batch-1 run. One restriction: the sequences of a batch must have equal PREFILL lengths
+ * (same mode and, for voice design / ICL, same instruct / reference lengths — text length is free, it
+ * rides along as trailing text); otherwise Q3_UNSUPPORTED. Group requests by prefill shape, one session each. */
 q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out);
 void      q3_session_free(q3_session* s);
 /* prefill_custom_voice / _voice_clone / _voice_design + run_prefill_layers (talker.rs:451-627,
