@@ -116,3 +116,13 @@ def test_speaker_language_tables():
     assert (o.max_length, o.temperature, o.top_k, o.top_p, o.repetition_penalty, o.eos_token_id, o.chunk_frames, o.min_new_tokens) == \
         (2048, 0.9, 50, 0.9, 1.05, 2150, 10, 2)
     assert q.CODEC_EOS_TOKEN_ID == 2150 and q.SAMPLES_PER_FRAME == 1920
+
+
+def test_integration_doc_covers_every_symbol():
+    """INTEGRATION.md maps every exported symbol to the reference interface it replaces (or marks it new)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "q3tts.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(q3_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 70
+    assert [n for n in names if n not in doc] == []
