@@ -1126,6 +1126,7 @@ struct q3_session {
     CodecWS cws;
     // overlapped segment decode (q3_session_run): vocoder segments run on their own stream while the frame loop continues
     hipStream_t dec_stream = nullptr; hipEvent_t dec_ev = nullptr;
+    std::vector<CodecWS> par_ws; std::vector<hipStream_t> par_streams;     // q3_session_run: utterances vocoded side by side
     CodecWS seg_ws; float* pcm_all = nullptr; size_t pcm_all_floats = 0;
     std::vector<uint32_t> codes_host; bool codes_host_valid = false;
     int stream_pos = 0;    // streaming: frames already decoded
@@ -1491,7 +1492,9 @@ extern "C" void q3_session_free(q3_session* s) {
     if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
     if (s->graph) hipGraphDestroy(s->graph);
     for (auto& ev : s->prof_pool) hipEventDestroy(ev);
+    for (auto st : s->par_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
     s->cws.release(); s->seg_ws.release();
+    for (auto& w : s->par_ws) w.release();
     if (s->pcm_all) dev_free(s->pcm_all);
     if (s->dec_ev) hipEventDestroy(s->dec_ev);
     if (s->dec_stream) hipStreamDestroy(s->dec_stream);
@@ -1924,6 +1927,42 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
         Q3C(refresh_codes(s));
         const auto t2 = clk::now();
         int total = 0;
+        // Four utterances are vocoded at a time, each on its own stream and workspace: most of a decode saturates the
+        // chip, but its front (the pre-transformer's ~90 launches on 10-160 workgroups, ≈4 of 28 ms) is latency-bound
+        // and fills in beside the other utterance's convolutions. Q3_DECODE_PAIRS=n: n at a time (1 = serial; A/B aid).
+        static const int conc = [] { const char* e = getenv("Q3_DECODE_PAIRS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+        bool any_icl = false;
+        for (auto& q : s->seq) any_icl = any_icl || q.icl;
+        if (conc > 1 && s->B > 1 && !any_icl) {
+            while ((int)s->par_ws.size() < conc - 1) {
+                s->par_ws.emplace_back();
+                hipStream_t st = nullptr;
+                HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                s->par_streams.push_back(st);
+            }
+            auto ws_of = [&](int k) -> CodecWS& { return k == 0 ? s->cws : s->par_ws[(size_t)k - 1]; };
+            auto st_of = [&](int k) { return k == 0 ? s->stream : s->par_streams[(size_t)k - 1]; };
+            for (int b0 = 0; b0 < s->B; b0 += conc) {
+                const int nb = (s->B - b0) < conc ? (s->B - b0) : conc;
+                for (int k = 0; k < nb; ++k) {
+                    const int b = b0 + k, T = s->seq[b].n_frames;
+                    if (n_samples) n_samples[b] = (size_t)T * spf;
+                    total += T;
+                    if (T == 0) continue;
+                    Q3C(codec_reserve(s->m, ws_of(k), T));
+                    HIPC(hipMemcpyAsync(ws_of(k).frames, s->codes + (size_t)b * s->max_frames * 16, (size_t)T * 16 * 4, hipMemcpyDeviceToDevice, st_of(k)));
+                    Q3C(codec_decode_dev(s->m, ws_of(k), T, st_of(k), nullptr));
+                }
+                for (int k = 0; k < nb; ++k) {
+                    const int b = b0 + k, T = s->seq[b].n_frames;
+                    HIPC(hipStreamSynchronize(st_of(k)));
+                    if (T && pcm_host && pcm_host[b]) {
+                        if (!cap || cap[b] < (size_t)T * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+                        HIPC(hipMemcpy(pcm_host[b], ws_of(k).pcm, (size_t)T * spf * 4, hipMemcpyDeviceToHost));
+                    }
+                }
+            }
+        } else
         for (int b = 0; b < s->B; ++b) {
             size_t n = 0;
             Q3C(q3_session_decode(s, b, 0, s->seq[b].n_frames, pcm_host ? pcm_host[b] : nullptr, cap ? cap[b] : 0, &n));

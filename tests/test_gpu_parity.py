@@ -718,3 +718,19 @@ def test_soak_mixed_sessions_are_deterministic(pair):
             else:
                 ref[key] = out[k]
     assert len(ref) > 20
+
+
+@pytest.mark.gpu
+def test_run_decodes_utterances_side_by_side(pair):
+    """q3_session_run vocodes up to four utterances at a time on separate streams / workspaces: PCM and sample counts of a
+    5-utterance batch with different end frames (EOS on) equal the one-at-a-time q3_session_decode results bit for bit."""
+    cfg, gm, om = pair
+    utts = [_utts("custom", 4 + i, index=i, hidden=cfg.hidden) for i in range(5)]
+    opts = q.SynthesisOptions(max_length=40, seed=7)             # EOS enabled: ragged lengths
+    s = gm.session(utts, opts)
+    audio, timing = s.run()
+    lens = [s.frames(b)[0] for b in range(5)]
+    assert timing.generation_frames == sum(lens) and all(len(audio[b]) == lens[b] * 1920 for b in range(5))
+    for b in range(5):
+        np.testing.assert_array_equal(audio[b].samples, s.decode(b))
+    s.close()
