@@ -205,12 +205,16 @@ static inline size_t tiled_elems(int mode, int rows, int cols) {
     return mode == 2 ? (size_t)up4(rows) * up128(cols) : (size_t)up16(rows) * up32(cols);
 }
 
-static inline int pick_mode(const TW& w, int M, int N) {
-    if (w.t2 && (M <= 2 || (N <= 1024 && M <= 8) || !w.t1)) return 2;
+// short K with many rows (code-predictor / 0.6B gate-up 3072 x 1024, lm_head 2048 x 1024): the 16-row kernel already has
+// one whole-slice group per wave and >= 128 workgroups, and beats the 4-row tiles even at M = 1 (gate/up 5.3 vs 6.5 us)
+static inline bool short_k_wide(int N, int K) { return K <= 1024 && N >= 2048; }
+static inline int pick_mode(const TW& w, int M, int N, int K) {
+    if (w.t2 && !w.t1) return 2;
+    if (w.t2 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) return 2;
     return 1;
 }
 static inline void set_w(LinArgs& a, const TW& w, int M, int N, int K) {
-    a.tiled = pick_mode(w, M, N); a.W = a.tiled == 2 ? w.t2 : w.t1; a.Kpad = kpad_for(a.tiled, K);
+    a.tiled = pick_mode(w, M, N, K); a.W = a.tiled == 2 ? w.t2 : w.t1; a.Kpad = kpad_for(a.tiled, K);
 }
 static inline void set_w2(LinArgs& a, const TW& w, const TW& w2, int M, int N, int K) {
     set_w(a, w, M, N, K); a.W2 = a.tiled == 2 ? w2.t2 : w2.t1;
@@ -2386,7 +2390,7 @@ extern "C" q3_status q3_session_profile_read(q3_session* s, double* ms, double* 
 extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                                      double* avg_us) {
     if (M < 1 || M > 16 || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
-    if (tiled < 0) tiled = (N < 4096 && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
+    if (tiled < 0) tiled = (N < 4096 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
     HIPC(hipSetDevice(device));
     DevPool pool;
     const size_t welems = tiled == 2 ? tiled_elems(2, N, K) : tiled_elems(1, N, K);
