@@ -502,12 +502,35 @@ class Qwen3TTS:
         finally:
             s.close()
 
+    @staticmethod
+    def prefill_shape(u: "Utterance") -> Tuple[int, int, int, int]:
+        """What fixes an utterance's prefill length (q3_session_create): a session takes utterances of ONE shape."""
+        icl = u.ref_codes is not None and u.ref_text_ids is not None
+        n_ins = len(u.instruct_ids) if u.instruct_ids is not None else 0
+        n_icl = (len(np.asarray(u.ref_codes).reshape(-1, 16)) + 1) if icl else 0
+        return (u.mode(), n_ins, 1 if (len(u.text_ids) > 0 and not icl) else 0, n_icl)
+
     def synthesize_batch(self, utts: Sequence[Utterance], options=None):
-        s = self.session(utts, options)
-        try:
-            return s.run()
-        finally:
-            s.close()
+        """Batch of arbitrary requests: utterances are grouped by prefill shape, one session per group (sessions need
+        equal prefill lengths), results returned in request order. The timing is the sum over the groups."""
+        groups = {}
+        for i, u in enumerate(utts):
+            groups.setdefault(self.prefill_shape(u), []).append(i)
+        audio: List[Optional[AudioBuffer]] = [None] * len(utts)
+        tot = SynthesisTiming(0.0, 0.0, 0, 0.0)
+        for idx in groups.values():
+            for k in range(0, len(idx), 16):                    # a session holds up to 16 sequences
+                part = idx[k:k + 16]
+                s = self.session([utts[i] for i in part], options)
+                try:
+                    a, t = s.run()
+                finally:
+                    s.close()
+                for j, i in enumerate(part):
+                    audio[i] = a[j]
+                tot = SynthesisTiming(tot.prefill_ms + t.prefill_ms, tot.generation_ms + t.generation_ms,
+                                      tot.generation_frames + t.generation_frames, tot.decode_ms + t.decode_ms)
+        return audio, tot
 
     def synthesize_streaming(self, text_ids, speaker: Speaker, language: Language, options=None,
                              continuous: bool = False) -> StreamingSession:

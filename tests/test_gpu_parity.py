@@ -734,3 +734,26 @@ def test_run_decodes_utterances_side_by_side(pair):
     for b in range(5):
         np.testing.assert_array_equal(audio[b].samples, s.decode(b))
     s.close()
+
+
+@pytest.mark.gpu
+def test_synthesize_batch_groups_by_prefill_shape(pair):
+    """A mixed batch (CustomVoice, voice design with two instruct lengths, x-vector clone, 20 requests > one session's 16)
+    is served group by group and every utterance equals its own batch-1 run."""
+    cfg, gm, om = pair
+    kinds = ["custom", "design", "clone", "custom", "design"]
+    utts = []
+    for i in range(20):
+        u = _utts(kinds[i % 5], 3 + i % 4, index=i, hidden=cfg.hidden)
+        if kinds[i % 5] == "design" and i % 2:
+            u.instruct_ids = synthetic_prompt(11, 60 + i)         # a second instruct length → a third prefill shape
+        u.seed = 300 + i
+        utts.append(u)
+    opts = q.SynthesisOptions(max_length=6, seed=1, eos_token_id=None)
+    audio, timing = gm.synthesize_batch(utts, opts)
+    assert len(audio) == 20 and timing.generation_frames == 20 * 6
+    for i in (0, 1, 6, 12, 19):
+        s = gm.session([utts[i]], opts); a1, _ = s.run(); s.close()
+        np.testing.assert_array_equal(audio[i].samples, a1[0].samples)
+    with pytest.raises(_lib.Q3Error, match="same prefill length"):
+        gm.session([utts[0], utts[1]], opts)
