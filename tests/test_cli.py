@@ -105,3 +105,21 @@ def test_api_surface_mirrors_the_reference():
         (2048, 0.9, 50, 0.9, 1.05, 2150, 10, 2)
     assert q.Speaker.from_str("ryan") == q.Speaker.Ryan and q.Speaker.Ryan.token_id() == 3061 and q.Language.from_str("en").token_id() == 2050
     assert callable(api.codes_to_tensor) and callable(api.resample_to_24k) and callable(api.auto_device)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ (written by bench.py on the GPU box) carries every field the driver's
+    contract names, with the roofline and cpu_baseline objects."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, "profiles", "r1_bench_n1_b8.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "frames/s" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 8 * 640 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1000.0)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and len(c["sample"]) > 10
