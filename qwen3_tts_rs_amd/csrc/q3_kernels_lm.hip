@@ -476,6 +476,21 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
     const float scale = 0.08838834764831845f;
     const size_t cache_base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM;
 
+    // The first two cached K/V rows of this group are requested NOW, before the q/k-norm + RoPE prologue: they depend
+    // on nothing but `pos`, and their round trip then runs under the prologue instead of after its barrier (the new
+    // position itself comes from LDS after the barrier, never from the just-written global memory).
+    const size_t base = cache_base + li * 4;
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk, kn = kk, vn = kk, k2 = kk, v2 = kk;
+    const int p_first = start + grp, p_second = start + grp + 8;
+    if (p_first < end && p_first != pos) {
+        kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p_first * HEAD_DIM);
+        vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p_first * HEAD_DIM);
+    }
+    if (p_second < end && p_second != pos) {
+        kn = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p_second * HEAD_DIM);
+        vn = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p_second * HEAD_DIM);
+    }
+
     // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v)
     for (int j = wave; j <= NREP; j += 4) {
         const bool is_q = j < NREP;
@@ -510,21 +525,19 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
     float4 acc[NREP];
 #pragma unroll
     for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    const size_t base = cache_base + li * 4;
     // the K/V rows of the NEXT position of this group are requested before the current one is consumed: with 17
     // positions at most (code predictor) a group's whole share is in flight at once instead of one round trip each
-    auto load_kv = [&](int p, float4& kk, float4& vv) {
+    auto load_kv = [&](int p, float4& ko, float4& vo) {
         if (p == pos) {
-            kk = *reinterpret_cast<const float4*>(&s_k[li * 4]);
-            vv = *reinterpret_cast<const float4*>(&s_v[li * 4]);
+            ko = *reinterpret_cast<const float4*>(&s_k[li * 4]);
+            vo = *reinterpret_cast<const float4*>(&s_v[li * 4]);
         } else {
-            kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
-            vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
+            ko = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
+            vo = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
         }
     };
-    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk, kn = kk, vn = kk, k2 = kk, v2 = kk;
-    if (start + grp < end) load_kv(start + grp, kk, vv);
-    if (start + grp + 8 < end) load_kv(start + grp + 8, kn, vn);
+    if (p_first < end && p_first == pos) load_kv(p_first, kk, vv);          // the new position: from LDS
+    if (p_second < end && p_second == pos) load_kv(p_second, kn, vn);
     for (int p = start + grp; p < end; p += 8) {
         if (p + 16 < end) load_kv(p + 16, k2, v2);
 #pragma unroll
