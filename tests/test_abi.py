@@ -126,3 +126,44 @@ def test_integration_doc_covers_every_symbol():
     names = sorted(set(re.findall(r"\b(q3_[a-z0-9_]+)\s*\(", hdr)))
     assert len(names) >= 70
     assert [n for n in names if n not in doc] == []
+
+
+def test_null_handles_return_status_not_crash():
+    """"Never abort / unwind across the ABI" (Errors): every entry point checks its handles before it
+    touches the GPU, so misuse from a host without a device still comes back as a status + message."""
+    import ctypes
+    from qwen3_tts_rs_amd import _lib
+    L = _lib.lib
+    null = ctypes.c_void_p(None)
+    i = ctypes.c_int(); sz = ctypes.c_size_t(); d = ctypes.c_double()
+    calls = [
+        lambda: L.q3_model_create(None, 0, ctypes.byref(null)),
+        lambda: L.q3_model_set_tensor(None, b"x", 0, None, 0),
+        lambda: L.q3_model_finalize(None),
+        lambda: L.q3_model_arena(None, None, None),
+        lambda: L.q3_session_create(None, None, 1, ctypes.byref(null)),
+        lambda: L.q3_session_prefill(None),
+        lambda: L.q3_session_generate(None, 1, 1),
+        lambda: L.q3_session_frames(None, 0, ctypes.byref(i), ctypes.byref(i)),
+        lambda: L.q3_session_codes(None, 0, None, 0, ctypes.byref(i)),
+        lambda: L.q3_session_decode(None, 0, 0, 0, None, 0, ctypes.byref(sz)),
+        lambda: L.q3_session_run(None, 1, None, None, None, None),
+        lambda: L.q3_session_next_chunk(None, None, 0, ctypes.byref(sz), ctypes.byref(i)),
+        lambda: L.q3_session_set_stream_mode(None, 1),
+        lambda: L.q3_decode_codes(None, None, 0, None, None),
+        lambda: L.q3_spk_create(None, 0, ctypes.byref(null)),
+        lambda: L.q3_spk_finalize(None),
+        lambda: L.q3_spk_encode(None, None, 0, 24000, None),
+        lambda: L.q3_spk_load_safetensors(None, b"/nonexistent"),
+        lambda: L.q3_dp_init(0, 1, None, 0, ctypes.byref(null)),
+        lambda: L.q3_dp_broadcast_weights(None, None, 0),
+        lambda: L.q3_config_from_json(b"/nonexistent/config.json", None, None),
+        lambda: L.q3_model_load(b"/nonexistent", -1, ctypes.byref(null), ctypes.byref(i)),
+        lambda: L.q3_wav_read(b"/nonexistent.wav", None, 0, None, None),
+        lambda: L.q3_resample(None, 1, 16000, 24000, None, 0, None),
+    ]
+    for k, f in enumerate(calls):
+        st = f()
+        assert st != 0, k
+        assert len(L.q3_last_error()) > 0, k
+    L.q3_model_free(None); L.q3_session_free(None); L.q3_spk_free(None); L.q3_dp_free(None)     # free(NULL) is a no-op
