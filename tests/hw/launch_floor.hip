@@ -85,5 +85,20 @@ int main() {
         };
         if (chain(nm, NODES, REPS, L)) return 1;
     }
+    // Does data read by one kernel stay in the L2 / Infinity Cache for the next? Same streaming kernels, but consecutive
+    // nodes alternate between only 2 (or 16) regions instead of walking 1 GiB: "warm" per-node time vs the cold one above.
+    for (int regions : {1, 2, 16}) {
+        for (auto s : {S{256, 512, 4}, S{256, 512, 8}, S{512, 512, 8}}) {
+            char nm[96];
+            const size_t pbv = (size_t)s.thr * s.nl, node_vec = pbv * s.wgs; const double mb = node_vec * 16 / 1e6;
+            snprintf(nm, sizeof nm, "warm x%-2d %5.1f MB %4d WGs x %4d thr x %2d ld", regions, mb, s.wgs, s.thr, s.nl);
+            auto L = [&](hipStream_t st, int i) {
+                const u32x4_t* p = w + (size_t)(i % regions) * node_vec;
+                switch (s.nl) { case 4: hipLaunchKernelGGL(k_stream<4>, dim3(s.wgs), dim3(s.thr), 0, st, p, out, pbv); break;
+                                default: hipLaunchKernelGGL(k_stream<8>, dim3(s.wgs), dim3(s.thr), 0, st, p, out, pbv); }
+            };
+            if (chain(nm, NODES, REPS, L)) return 1;
+        }
+    }
     return 0;
 }
