@@ -52,10 +52,14 @@ def main():
     rank, local_rank, world = dp.env_rank()
     if world != args.gpus and world > 1:
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = local_rank
+    # Q3_DP_TEST_SAME_GPU=1 (single-GPU boxes only): every rank on cuda:0 over gloo — exercises the whole multi-rank
+    # flow (arena broadcast, finalize on non-root ranks, barriers, max-over-ranks timing) where RCCL cannot run
+    # (it refuses two ranks on one device). The numbers of such a run mean nothing.
+    same_gpu = os.environ.get("Q3_DP_TEST_SAME_GPU") == "1"
+    dev = 0 if same_gpu else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
-        dp.init("nccl")
+        dp.init("gloo" if same_gpu else "nccl")
 
     cfg = {"1.7b": q.qwen3_tts_1_7b, "0.6b": q.qwen3_tts_0_6b, "tiny": q.tiny}[args.model]()
 

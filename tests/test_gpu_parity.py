@@ -757,3 +757,17 @@ def test_synthesize_batch_groups_by_prefill_shape(pair):
         np.testing.assert_array_equal(audio[i].samples, a1[0].samples)
     with pytest.raises(_lib.Q3Error, match="same prefill length"):
         gm.session([utts[0], utts[1]], opts)
+
+
+@pytest.mark.gpu
+def test_dp_two_ranks_on_one_gpu():
+    """The data-parallel start-up of bench.py with real GPU memory on both sides: 2 ranks (gloo, both on cuda:0), arena
+    broadcast from rank 0, non-root finalize, identical codes and PCM on both ranks (tests/dp_same_gpu_check.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", os.path.join(root, "tests", "dp_same_gpu_check.py")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0: arena" in r.stdout and "rank 1: arena" in r.stdout and "DIFFER" not in r.stdout
