@@ -433,12 +433,12 @@ def test_model_load_reports_missing_weight(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("eos", [False, True])
-def test_run_overlapped_segment_decode_is_exact(pair, eos):
+def test_run_overlapped_segment_decode_is_exact(pair, eos, monkeypatch):
     """With Q3_DECODE_OVERLAP=1 q3_session_run decodes 128-frame segments on a second stream while the frame loop
     continues (12 frames of left context re-run per segment). The PCM must equal the whole-utterance decode of the
     same codes bit for bit — with EOS off (all sequences 300 frames) and with sequences that end at different frames."""
     cfg, gm, om = pair
-    assert os.environ.get("Q3_DECODE_OVERLAP") == "1"      # set in conftest.py before the library reads it
+    monkeypatch.setenv("Q3_DECODE_OVERLAP", "1")          # opt-in path (off by default: slower on MI355X); read at every q3_session_run
     utts = [_utts("custom", 4 + i, index=i, hidden=cfg.hidden) for i in range(3)]
     if eos:
         opts = q.SynthesisOptions(max_length=300, temperature=1.3, top_k=0, top_p=1.0, seed=11, min_new_tokens=2)
@@ -460,6 +460,24 @@ def test_run_overlapped_segment_decode_is_exact(pair, eos):
     if len(c):
         ref = om.decode(c)
         assert float(np.sqrt(np.mean((audio[0].samples - ref) ** 2))) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_run_side_by_side_decode_is_exact(pair, monkeypatch):
+    """The DEFAULT q3_session_run decode (utterances vocoded four at a time, each on its own stream and workspace) at a
+    length beyond one segment: PCM of every sequence equals its whole-utterance decode bit for bit."""
+    cfg, gm, om = pair
+    monkeypatch.delenv("Q3_DECODE_OVERLAP", raising=False)
+    utts = [_utts("custom", 4 + i, index=i, hidden=cfg.hidden) for i in range(6)]
+    opts = q.SynthesisOptions(max_length=200, seed=11, eos_token_id=None)
+    s = gm.session(utts, opts)
+    audio, timing = s.run()
+    assert timing.generation_frames == 6 * 200
+    for b in range(6):
+        np.testing.assert_array_equal(audio[b].samples, s.decode(b))
+    ref = om.decode(s.codes(5))
+    assert float(np.sqrt(np.mean((audio[5].samples - ref) ** 2))) <= 1e-3
+    s.close()
 
 
 @pytest.mark.gpu
