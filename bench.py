@@ -37,25 +37,44 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=640, help="frames generated per utterance (eos disabled)")
     ap.add_argument("--prompt-tokens", type=int, default=512)
+    ap.add_argument("--workload", default="customvoice", choices=["customvoice", "voicedesign4k", "xvector"],
+                    help="prefill flavour: CustomVoice (10 positions; BASELINE configs[1-3]), VoiceDesign with a 4096-token instruct "
+                         "prompt (config[4]), or Base-model x-vector voice clone")
+    ap.add_argument("--sampling", default="default", choices=["default", "greedy"], help="SURVEY §8d cfg B (0.9/50/0.9/1.05) or cfg A (greedy)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU-baseline sample (~12 s of oracle time)")
+    ap.add_argument("--cpu-frames-single", type=int, default=3, help="frames of the single-thread CPU-baseline sample (~10 s)")
     ap.add_argument("--profile-frames", type=int, default=6)
     ap.add_argument("--ttfa-reps", type=int, default=5)
     args = ap.parse_args()
 
     import numpy as np
     import torch
+    same_gpu = os.environ.get("Q3_DP_TEST_SAME_GPU") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks ourselves (one process per GPU), never a silent world = 1
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus and not same_gpu:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {n_vis} GPU(s) are visible")
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvp(sys.executable, cmd)
     import qwen3_tts_rs_amd as q
     from qwen3_tts_rs_amd import dp, synth
 
     rank, local_rank, world = dp.env_rank()
     if world != args.gpus and world > 1:
         args.gpus = world
+    if world > 1 and not same_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     # Q3_DP_TEST_SAME_GPU=1 (single-GPU boxes only): every rank on cuda:0 over gloo — exercises the whole multi-rank
     # flow (arena broadcast, finalize on non-root ranks, barriers, max-over-ranks timing) where RCCL cannot run
     # (it refuses two ranks on one device). The numbers of such a run mean nothing.
-    same_gpu = os.environ.get("Q3_DP_TEST_SAME_GPU") == "1"
     dev = 0 if same_gpu else local_rank
     torch.cuda.set_device(dev)
     if world > 1:
@@ -87,8 +106,17 @@ def main():
     B = args.batch
     n_total = B * world
     my_idx = dp.shard_indices(n_total, rank, world)
-    utts = [q.Utterance(synthetic_prompt(args.prompt_tokens, i), q.Speaker.Ryan, q.Language.English, seed=42 + i) for i in my_idx]
-    opts = q.SynthesisOptions(max_length=args.frames, eos_token_id=None, seed=42)
+    def make_utt(i):
+        if args.workload == "voicedesign4k":
+            return q.Utterance(synthetic_prompt(args.prompt_tokens, i), language=q.Language.English,
+                               instruct_ids=synthetic_prompt(4096, 5000 + i), seed=42 + i)
+        if args.workload == "xvector":
+            xv = np.random.default_rng(7000 + i).standard_normal(cfg.hidden).astype(np.float32)
+            return q.Utterance(synthetic_prompt(args.prompt_tokens, i), language=q.Language.English, xvector=xv, seed=42 + i)
+        return q.Utterance(synthetic_prompt(args.prompt_tokens, i), q.Speaker.Ryan, q.Language.English, seed=42 + i)
+    utts = [make_utt(i) for i in my_idx]
+    samp = dict(temperature=0.0) if args.sampling == "greedy" else {}
+    opts = q.SynthesisOptions(max_length=args.frames, eos_token_id=None, seed=42, **samp)
     use_graph = not args.no_graph
 
     phase_ms = []       # (create, run, close) wall per step: the timed step is all three
@@ -132,57 +160,54 @@ def main():
              "decode_ms": float(np.mean([t.decode_ms for t in timings]))}
 
     # ---- roofline of the dominant kernel: the bf16-weight MFMA GEMV family (every projection of the frame) ----
-    # Each distinct (N, K, epilogue) of one frame is replayed from a hipGraph over HBM-resident weight copies
-    # and timed with HIP events on the launch stream (q3_bench_linear); achieved = Σ algorithmic weight bytes
-    # of one frame's GEMV launches ÷ Σ their measured launch times, M = this run's batch.
+    # The launch inventory is the ENGINE's: a profiled session runs a few frames and reports every distinct GEMV launch
+    # (M, N, K, epilogue, input-norm form, producer outputs, tiling) with its count per frame. Each shape is then replayed
+    # from a hipGraph over HBM-resident weight copies and timed with HIP events on the launch stream (q3_bench_linear, mean
+    # of 5 replays); achieved = Σ algorithmic weight bytes of one frame's GEMV launches ÷ Σ their launch times. The same
+    # profiled frames also give the in-situ figure (event pairs around every GEMV launch of real frames, eager launches).
     from qwen3_tts_rs_amd.api import bench_linear
-    H, I, CH, CI = cfg.hidden, cfg.inter, cfg.cp_hidden, cfg.cp_inter
-    QD, KD = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
-    CQD, CKD = cfg.cp_heads * cfg.head_dim, cfg.cp_kv_heads * cfg.head_dim
-    # code-predictor passes per frame: the first pass carries two rows per sequence (talker hidden + semantic
-    # embedding, code_predictor.rs:340-362) when 2·B fits the 16-row MFMA tile, then 14 single-row passes;
-    # otherwise 16 single-row passes. (M, launches) pairs below follow the engine's cp_run exactly.
-    Mb = min(B, 16)
-    cp_passes = [(2 * Mb, 1), (Mb, 14)] if 2 * Mb <= 16 else [(Mb, 16)]
-    inventory = [  # (name, N, K, epi, rms, [(M, launches per frame)])
-        ("talker qkv", QD + 2 * KD, H, 0, True, [(Mb, cfg.n_layers)]), ("talker o", H, QD, 1, False, [(Mb, cfg.n_layers)]),
-        ("talker gate/up", I, H, 3, True, [(Mb, cfg.n_layers)]), ("talker down", H, I, 1, False, [(Mb, cfg.n_layers)]),
-        ("codec head", cfg.codec_vocab, H, 0, False, [(Mb, 1)]),
-        ("cp qkv", CQD + 2 * CKD, CH, 0, True, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
-        ("cp o", CH, CQD, 1, False, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
-        ("cp gate/up", CI, CH, 3, True, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
-        ("cp down", CH, CI, 1, False, [(m, c * cfg.cp_layers) for m, c in cp_passes]),
-        ("cp lm_head", cfg.cp_vocab, CH, 0, True, [(Mb, cfg.n_groups - 1)]),
-    ]
-    if H != CH:
-        inventory.append(("cp mtp proj", CH, H, 0, False, cp_passes))
+    pf = max(2, args.profile_frames)
+    sp = model.session(utts, q.SynthesisOptions(max_length=pf + 2, eos_token_id=None, seed=42, **samp))
+    sp.prefill(); sp.generate(1, use_graph=False)             # first frame outside the inventory (lazy initialisation)
+    sp.set_profile(True); sp.profile_shapes(reset=True); sp.profile_read(reset=True)
+    sp.generate(pf, use_graph=False)
+    insitu_ms, insitu_bytes, insitu_n = sp.profile_read(reset=True)
+    shapes = sp.profile_shapes(reset=True)
+    wbytes, kvbytes = sp.frame_bytes((10 if args.workload != "voicedesign4k" else 4105) + args.frames // 2)
+    sp.close()
     tot_bytes = tot_us = 0.0; launches = 0; per_shape = {}
-    for name, N, K, epi, rms, ms in inventory:
+    EPI = {0: "none", 1: "resid", 2: "silu", 3: "swiglu"}
+    for (Mr, N, K, epi, rms, produce, tiled, count) in shapes:
+        assert count % pf == 0, (Mr, N, K, count, pf)
+        cnt = count // pf
         nb = N * K * 2 * (2 if epi == 3 else 1)
-        for Mrows, cnt in ms:
-            us = bench_linear(Mrows, N, K, epi, rms, device=dev)
-            per_shape[f"{name} M={Mrows}"] = {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
-            tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
-    s = model.session(utts, q.SynthesisOptions(max_length=4, eos_token_id=None, seed=42))
-    wbytes, kvbytes = s.frame_bytes(10 + args.frames // 2)
-    s.close()
+        us = bench_linear(Mr, N, K, epi, rms, tiled=tiled, device=dev, produce=bool(produce))
+        per_shape[f"M={Mr} N={N} K={K} {EPI[epi]} norm={rms} prod={produce} tile={16 if tiled == 1 else 4}"] = \
+            {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
+        tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
     achieved = tot_bytes / tot_us / 1e3     # GB/s
     # HBM traffic per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes, FETCH_SIZE x2 gfx950 correction; tests/pmc_collect.sh) — PMC counters cannot be read from inside the run
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", f"r1_pmc_gemv_M{min(B, 16)}.json")
-    if args.model == "1.7b" and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))["shapes"]
-        key = lambda n: n.replace(" ", "_").replace("/", "")
-        if all(key(n) in pmc for n, *_ in inventory):
-            traffic = sum((pmc[key(n)]["fetch_bytes_corrected"] + pmc[key(n)]["write_bytes"]) * sum(c for _, c in ms)
-                          for n, _, _, _, _, ms in inventory) / launches
+    traffic = None; pmc_path = None
+    for cand in (f"r2_pmc_gemv_M{min(B, 16)}.json", f"r1_pmc_gemv_M{min(B, 16)}.json"):
+        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+            pmc_path = os.path.join(ROOT, "profiles", cand); break
+    if args.model == "1.7b" and pmc_path:
+        pmc = json.load(open(pmc_path))
+        traffic = pmc.get("mean_bytes_per_launch")
+        if traffic is None and "shapes" in pmc:
+            vals = [v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc["shapes"].values()]
+            traffic = float(np.mean(vals)) if vals else None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "traffic_source": os.path.basename(pmc_path) if traffic else None,
-                "kernel": "k_gemv_mfma / k_gemv_mfma4 (bf16-weight MFMA GEMV family, M = batch)",
-                "timing": "hipGraph replay of each GEMV shape over HBM-resident weight copies, HIP events on the launch stream",
+                "traffic": traffic, "traffic_source": os.path.basename(pmc_path) if (traffic and pmc_path) else None,
+                "kernel": "k_gemv_mfma / k_gemv_mfma4 / k_gemv_lds (bf16-weight MFMA GEMV family, M = batch)",
+                "timing": "launch inventory from the engine (profiled frames); each shape replayed from a hipGraph over HBM-resident "
+                          "weight copies, HIP events on the launch stream, mean of 5 replays x 200 launches",
                 "launches_per_frame": launches, "avg_launch_us": tot_us / launches, "avg_bytes_per_launch": tot_bytes / launches,
                 "gemv_us_per_frame": tot_us, "per_shape": per_shape,
+                "in_situ": {"what": "HIP event pairs around every GEMV launch of real frames (eager launches, profiling session)",
+                            "launches_per_frame": insitu_n / pf, "avg_launch_us": insitu_ms * 1e3 / max(insitu_n, 1),
+                            "gbps": insitu_bytes / max(insitu_ms, 1e-9) / 1e6, "frac": insitu_bytes / max(insitu_ms, 1e-9) / 1e6 / 8000.0},
                 "frame_weight_bytes": wbytes, "frame_kv_bytes": kvbytes,
                 "frame_model_gbps": (wbytes + kvbytes) / (stage["generation_ms"] / 1000.0 / args.frames) / 1e9}
 
@@ -231,9 +256,25 @@ def main():
             codes = osess.generate()
             pcm = om.decode(codes)
             cpu_wall = time.perf_counter() - tc
-            osess.close(); om.close()
+            osess.close()
+            # single thread (deterministic, one core): a few frames of the same utterance
+            single = None
+            try:
+                O.olib.q3o_set_threads(1)
+                o1 = q.SynthesisOptions(max_length=args.cpu_frames_single, eos_token_id=None, seed=42)
+                t1c = time.perf_counter()
+                os1 = O.OracleSession(om, utt0, o1); c1 = os1.generate(); p1 = om.decode(c1)
+                w1 = time.perf_counter() - t1c
+                os1.close()
+                single = {"value": len(c1) / w1, "unit": "frames/s", "cores": 1, "rtf": w1 / (len(c1) * 0.08),
+                          "sample": f"prefill + {len(c1)} frames + vocoder, {w1:.1f}s wall"}
+            except Exception as e1:
+                single = {"value": None, "sample": f"failed: {e1}"}
+            finally:
+                O.olib.q3o_set_threads(ncores)
+            om.close()
             cpu = {"value": len(codes) / cpu_wall, "unit": "frames/s", "cores": ncores, "kind": "port",
-                   "rtf": cpu_wall / (len(codes) * 0.08),
+                   "rtf": cpu_wall / (len(codes) * 0.08), "single_thread": single,
                    "sample": f"1 utterance, {args.prompt_tokens}-token prompt: prefill + {len(codes)} frames + vocoder "
                              f"({cpu_wall:.1f}s wall, oracle load {o_load:.0f}s not counted); reference-published CPU: "
                              f"2.3/2.1/1.9 frames/s, RTF 5.39-6.48 on 20 Arm cores (docs/BENCHMARKS.md:111-115)"}
@@ -245,12 +286,14 @@ def main():
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"Qwen3-TTS-{args.model} synthetic weights; {B} utterances/GPU x {world} GPU(s), "
-                               f"{args.prompt_tokens}-token prompts, CustomVoice prefill, {args.frames} frames each "
-                               f"(eos off), default sampling, non-streaming prefill+generate+decode",
+                               f"{args.prompt_tokens}-token prompts, {args.workload} prefill, {args.frames} frames each "
+                               f"(eos off), {args.sampling} sampling, non-streaming prefill+generate+decode",
                    "utterances_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"dp{world}",
-                   "weights": "bf16", "activations_kv": "f32", "hip_graph": use_graph},
+                   "weights": "bf16", "activations_kv": "f32", "hip_graph": use_graph, "prefill": args.workload, "sampling": args.sampling,
+                   "pcm_copy_out": False},     # PCM stays in HBM inside the timed step (39 MB / step D2H at B = 8 would add < 0.5 %)
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
-        "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s},
+        "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,
+                                                        "gbps": (bcast_bytes / bcast_s / 1e9) if bcast_s > 0 else None},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -252,6 +252,9 @@ q3_status q3_session_set_profile(q3_session* s, int enable);
 /* accumulated since the last reset: GPU milliseconds, algorithmic weight bytes and launch count of
  * the bf16 GEMV family (the dominant kernel) */
 q3_status q3_session_profile_read(q3_session* s, double* ms, double* bytes, long* launches, int reset);
+/* the distinct GEMV launches of the frame loop since profiling was enabled (bench.py's roofline inventory): rows of 8 ints
+ * {M, N, K, epilogue, input norm 0/1/2, producer outputs 0/1, tiling, count}; rows == NULL: only *n_rows */
+q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap_rows, int* n_rows, int reset);
 /* µs per launch of one GEMV shape: `iters` launches over `n_copies` distinct weight buffers (HBM-resident
  * stream, not Infinity-Cache hits) replayed from one hipGraph and timed with HIP events on that stream.
  * tiled: 1 = 16-row tiles, 2 = 4-row tiles, 0 = first-generation row-major kernel, -1 = the engine's choice.

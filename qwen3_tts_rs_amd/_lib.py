@@ -90,6 +90,7 @@ SYMBOLS = {
     "q3_codes_to_tensor": (None, [c_void_p, c_int, c_void_p]),
     "q3_session_set_profile": (c_int, [c_void_p, c_int]),
     "q3_session_profile_read": (c_int, [c_void_p, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_long), c_int]),
+    "q3_session_profile_shapes": (c_int, [c_void_p, P(c_int), c_int, P(c_int), c_int]),
     "q3_bench_linear": (c_int, [c_int] * 9 + [P(ctypes.c_double)]),
     "q3_session_stream": (c_int, [c_void_p, P(c_void_p)]),
     "q3_session_frame_bytes": (c_int, [c_void_p, c_int, P(ctypes.c_double), P(ctypes.c_double)]),

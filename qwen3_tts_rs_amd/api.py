@@ -281,6 +281,14 @@ class Session:
         check(lib.q3_session_profile_read(self._h, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n), 1 if reset else 0))
         return ms.value, by.value, n.value
 
+    def profile_shapes(self, reset: bool = True) -> List[Tuple[int, ...]]:
+        """distinct GEMV launches since set_profile(True): (M, N, K, epi, rms, produce, tiled, count)"""
+        n = ctypes.c_int()
+        check(lib.q3_session_profile_shapes(self._h, None, 0, ctypes.byref(n), 0))
+        buf = (ctypes.c_int * (8 * max(n.value, 1)))()
+        check(lib.q3_session_profile_shapes(self._h, buf, n.value, ctypes.byref(n), 1 if reset else 0))
+        return [tuple(buf[i * 8:(i + 1) * 8]) for i in range(n.value)]
+
     def frame_bytes(self, kv_len: int) -> Tuple[float, float]:
         w = ctypes.c_double(); k = ctypes.c_double()
         check(lib.q3_session_frame_bytes(self._h, kv_len, ctypes.byref(w), ctypes.byref(k)))
@@ -514,8 +522,12 @@ class Qwen3TTS:
         """Batch of arbitrary requests: utterances are grouped by prefill shape, one session per group (sessions need
         equal prefill lengths), results returned in request order. The timing is the sum over the groups."""
         groups = {}
+        o = options or SynthesisOptions()
         for i, u in enumerate(utts):
-            groups.setdefault(self.prefill_shape(u), []).append(i)
+            key = self.prefill_shape(u)
+            if key[3]:      # ICL: q3_session_create caps max_length at max(75, 6 * n_text) per sequence (lib.rs:913-929) and a
+                key = key + (min(o.max_length, max(75, 6 * len(u.text_ids))),)      # session needs ONE resolved max_length
+            groups.setdefault(key, []).append(i)
         audio: List[Optional[AudioBuffer]] = [None] * len(utts)
         tot = SynthesisTiming(0.0, 0.0, 0, 0.0)
         for idx in groups.values():
@@ -677,14 +689,16 @@ def sample(logits: np.ndarray, u: np.ndarray, options: SynthesisOptions, seen: O
     return out
 
 
-def bench_linear(M: int, N: int, K: int, epi: int = 0, rms: bool = False, tiled: int = -1, iters: int = 200,
-                 n_copies: int = 0, device: int = 0) -> float:
-    """µs per launch of one GEMV shape (graph replay over HBM-resident weight copies)."""
+def bench_linear(M: int, N: int, K: int, epi: int = 0, rms=False, tiled: int = -1, iters: int = 200,
+                 n_copies: int = 0, device: int = 0, produce: bool = False) -> float:
+    """µs per launch of one GEMV shape: mean over 5 hipGraph replays of `iters` launches cycling over HBM-resident weight
+    copies. rms: 0 / False none, 1 / True norm weight applied in the kernel, 2 pre-normed input; produce: the launch
+    also writes the producer-side RMSNorm outputs."""
     nbytes = N * K * 2 * (2 if epi == 3 else 1)
     if n_copies <= 0:
         n_copies = max(2, int(600e6 // nbytes))
     us = ctypes.c_double()
-    check(lib.q3_bench_linear(device, M, N, K, epi, 1 if rms else 0, tiled, iters, n_copies, ctypes.byref(us)))
+    check(lib.q3_bench_linear(device, M, N, K, epi | (16 if produce else 0), int(rms), tiled, iters, n_copies, ctypes.byref(us)))
     return us.value
 
 

@@ -95,11 +95,21 @@ def main(argv=None) -> int:
         if a.ref_audio:      # a Base-style synthetic model: seeded ECAPA-TDNN of the matching embedding width
             scfg = q.tiny_speaker_config(cfg.hidden) if a.synthetic == "tiny" else q.SpeakerEncoderConfig(enc_dim=cfg.hidden)
             model.attach_speaker_encoder(q.SpeakerEncoder.from_synthetic(scfg, device=dev))
-        tok = TextTokenizer.from_pretrained(None, a.tokenizer_dir)
+        tok = TextTokenizer.from_pretrained(None, a.tokenizer_dir, allow_stand_in=True)     # --synthetic: the labelled stand-in
     else:
+        # a real checkpoint needs its real tokenizer (the reference fails to load without one, text.rs:62-110) unless every
+        # piece of text arrives as ids
+        need_text = not a.token_ids or (a.instruct and not a.instruct_ids) or bool(a.ref_text)
+        try:
+            tok = TextTokenizer.from_pretrained(a.model_dir, a.tokenizer_dir)
+        except FileNotFoundError as e:
+            if need_text:
+                print(f"error: {e}", file=sys.stderr)
+                return 2
+            tok = None
         model = q.Qwen3TTS.from_pretrained(a.model_dir, device=dev)
-        tok = TextTokenizer.from_pretrained(a.model_dir, a.tokenizer_dir)
-    print(f"Loaded model in {time.time() - t0:.2f}s ({model.config.name}, type {model.model_type.name if model.model_type else 'unknown'}, tokenizer: {tok.kind})")
+    print(f"Loaded model in {time.time() - t0:.2f}s ({model.config.name}, type {model.model_type.name if model.model_type else 'unknown'}, "
+          f"tokenizer: {tok.kind if tok else 'none (--token-ids)'})")
     ids = [int(x) for x in a.token_ids.split(",")] if a.token_ids else tok.encode(a.text)
     opts = q.SynthesisOptions(max_length=frames, temperature=a.temperature, top_k=a.top_k, top_p=a.top_p,
                               repetition_penalty=a.repetition_penalty, seed=a.seed)

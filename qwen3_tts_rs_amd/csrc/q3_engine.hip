@@ -209,7 +209,9 @@ static inline size_t tiled_elems(int mode, int rows, int cols) {
 // one whole-slice group per wave and >= 128 workgroups, and beats the 4-row tiles even at M = 1 (gate/up 5.3 vs 6.5 us)
 static inline bool short_k_wide(int N, int K) { return K <= 1024 && N >= 2048; }
 static inline int pick_mode(const TW& w, int M, int N, int K) {
+    static const bool no4 = getenv("Q3_GEMV_NO_MFMA4") != nullptr;     // tuning aid: 16-row tiles wherever both images exist (M > 2)
     if (w.t2 && !w.t1) return 2;
+    if (no4 && w.t1 && M > 2) return 1;
     if (w.t2 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) return 2;
     return 1;
 }
@@ -1097,11 +1099,7 @@ extern "C" q3_status q3_decode_codes(q3_model* m, const uint32_t* frames_host, i
 // ------------------------------------------------------------------------------------------------
 // session
 // ------------------------------------------------------------------------------------------------
-// XZ / SUMZ: X / SUM times the RMSNorm weight of their consumer, SQX / SQS: per-output-tile partial sums of X^2 / SUM^2
-// (producer-side RMSNorm, LinArgs::z_out); x_parts = tiles behind SQX while XZ / SQX describe the current X, else 0
-struct LmBuf { float *X, *SUM, *QKV, *Q, *ATT, *ACT, *PART, *XZ, *SUMZ, *SQX, *SQS; int x_parts; };
-constexpr int SSQ_MAX_PARTS = 512;
-static inline bool ssq_parts_ok(int parts) { return parts >= 4 && parts % 4 == 0 && parts <= SSQ_MAX_PARTS; }
+struct LmBuf { float *X, *SUM, *QKV, *Q, *ATT, *ACT, *PART; };
 struct LmDims { int H, I, nh, nkv, layers; float eps; };
 
 struct SeqInfo {
@@ -1111,6 +1109,7 @@ struct SeqInfo {
 };
 
 struct ProfAcc { double ms = 0; double bytes = 0; long launches = 0; };
+struct ProfShape { int M, N, K, epi, rms, produce, tiled, count; };
 
 struct q3_session {
     q3_model* m = nullptr; int B = 0;
@@ -1144,9 +1143,9 @@ struct q3_session {
     bool proj_tables = getenv("Q3_NO_PROJ_TABLES") == nullptr;   // A/B aid: set to project the gathered embedding on every pass
     bool qkv_tables = getenv("Q3_NO_QKV_TABLES") == nullptr;     // A/B aid: set to run the layer-0 qkv GEMV on every pass
     bool no_chunk = getenv("Q3_NO_CHUNK") != nullptr;         // A/B aid: one position per prefill step, 16-pass code predictor
-    bool prenorm = getenv("Q3_NO_PRENORM") == nullptr;        // A/B aid: set to apply every RMSNorm weight inside the consuming GEMV
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
     std::vector<hipEvent_t> prof_pool; size_t prof_pool_next = 0;
+    std::vector<ProfShape> prof_shapes;
 };
 
 static hipError_t run_linear(q3_session* s, const LinArgs& a) {
@@ -1165,14 +1164,19 @@ static hipError_t run_linear(q3_session* s, const LinArgs& a) {
     hipError_t e2 = hipEventRecord(e1, s->stream);
     s->prof_events.push_back({e0, e1});
     s->prof_event_bytes.push_back((double)a.N * a.K * 2.0 * (a.epi == EPI_SWIGLU ? 2.0 : 1.0));
+    {   // launch inventory (q3_session_profile_shapes): M, N, K, epilogue, input-norm form, producer outputs, tiling
+        ProfShape ps{a.M, a.N, a.K, a.epi, a.norm_w ? 1 : 0, 0, a.tiled, 1};
+        bool found = false;
+        for (auto& q : s->prof_shapes)
+            if (q.M == ps.M && q.N == ps.N && q.K == ps.K && q.epi == ps.epi && q.rms == ps.rms && q.produce == ps.produce && q.tiled == ps.tiled) { q.count += 1; found = true; break; }
+        if (!found) s->prof_shapes.push_back(ps);
+    }
     return e != hipSuccess ? e : e2;
 }
 
 // one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
-// next_ln: RMSNorm weight of whatever consumes this layer's output (the next layer's input norm, the final norm), or nullptr
 static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf& b, float* kc, float* vc, int max_seq,
-                          const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1, bool skip_qkv = false,
-                          const float* next_ln = nullptr) {
+                          const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1, bool skip_qkv = false) {
     const q3_model* m = s->m;
     // B = number of activation ROWS of this step: one per sequence, or rows_per_seq consecutive positions per
     // sequence (chunked prefill, the code predictor's 2-token first pass)
@@ -1180,9 +1184,6 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     LinArgs a;
     a.N = QD + 2 * KD; a.K = d.H; set_w(a, w.qkv, B, a.N, a.K); a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
     a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE;
-    if (s->prenorm && b.x_parts && a.tiled == 1) {      // X was written by a GEMV that also left XZ = X * in_ln and the partial sums of X^2
-        a.x = b.XZ; a.norm_w = nullptr; a.ssq_in = b.SQX; a.ssq_parts = b.x_parts; a.ssq_ld = b.x_parts;
-    }
     if (!skip_qkv) HIPC(run_linear(s, a));       // skip: the caller already filled b.QKV (code predictor layer 0, table rows)
     AttnArgs t{};
     t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
@@ -1201,24 +1202,13 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     }
     LinArgs o;
     o.N = d.H; o.K = QD; set_w(o, w.o, B, o.N, o.K); o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID;
+    HIPC(run_linear(s, o));
     LinArgs g;
     g.N = d.I; g.K = d.H; set_w2(g, w.gate, w.up, B, g.N, g.K); g.x = b.SUM; g.ldx = d.H; g.norm_w = w.post_ln; g.eps = d.eps;
     g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU;
-    // producer-side RMSNorm: o-proj leaves SUM * post_ln and the per-tile sums of SUM^2 for the gate/up launch
-    const int o_tiles = linear_out_tiles(o);
-    if (s->prenorm && g.tiled == 1 && ssq_parts_ok(o_tiles)) {
-        o.z_out = b.SUMZ; o.ldz = d.H; o.z_w = w.post_ln; o.ssq_out = b.SQS;
-        g.x = b.SUMZ; g.norm_w = nullptr; g.ssq_in = b.SQS; g.ssq_parts = o_tiles; g.ssq_ld = o_tiles;
-    }
-    HIPC(run_linear(s, o));
     HIPC(run_linear(s, g));
     LinArgs dn;
     dn.N = d.H; dn.K = d.I; set_w(dn, w.down, B, dn.N, dn.K); dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID;
-    const int dn_tiles = linear_out_tiles(dn);
-    b.x_parts = 0;
-    if (s->prenorm && next_ln && ssq_parts_ok(dn_tiles)) {
-        dn.z_out = b.XZ; dn.ldz = d.H; dn.z_w = next_ln; dn.ssq_out = b.SQX; b.x_parts = dn_tiles;
-    }
     HIPC(run_linear(s, dn));
     return Q3_OK;
 }
@@ -1235,11 +1225,9 @@ static LmDims cp_dims(const q3_config& c) { return LmDims{c.cp_hidden, c.cp_inte
 static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, bool with_head, int rows_per_seq = 1) {
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     const LmDims d = talker_dims(c);
-    s->tb.x_parts = 0;             // tb.X comes from the frame embedding / the prompt rows: layer 0 applies its norm weight itself
     for (int i = 0; i < c.n_layers; ++i)
         Q3C(lm_layer(s, d, m->tl[i], s->tb, s->kcache + (size_t)i * s->kv_layer_stride, s->vcache + (size_t)i * s->kv_layer_stride,
-                     s->max_seq, pos_dev, pos_static, s->n_splits, rows_per_seq, false,
-                     i + 1 < c.n_layers ? m->tl[i + 1].in_ln : nullptr));
+                     s->max_seq, pos_dev, pos_static, s->n_splits, rows_per_seq));
     if (with_head) {
         // final norm of each sequence's LAST row of the step
         HIPC(launch_rmsnorm(s->tb.X + (size_t)(rows_per_seq - 1) * c.hidden, rows_per_seq * c.hidden, m->norm, s->LASTH, c.hidden, s->B,
@@ -1329,20 +1317,14 @@ static q3_status cp_run(q3_session* s) {
         }
         if (m->mtp_w.t1) Q3C(project(B * rows, CH));
         }
-        s->cb.x_parts = 0;         // cb.X was just written by the gather / the projection
         for (int i = 0; i < c.cp_layers; ++i)
             Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,
-                         n_pass + 1, nullptr, rows == 2 ? 0 : p, 1, rows, i == 0 && skip0,
-                         i + 1 < c.cp_layers ? m->cl[i + 1].in_ln : (p >= 1 ? m->cp_norm : nullptr)));
+                         n_pass + 1, nullptr, rows == 2 ? 0 : p, 1, rows, i == 0 && skip0));
         if (p >= 1) {
             LinArgs h;
             h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X + (size_t)(rows - 1) * CH; h.ldx = rows * CH;
             h.norm_w = m->cp_norm; h.eps = c.rms_eps;
             h.y = s->CP_LOGITS + (size_t)(p - 1) * B * V; h.ldy = V; h.M = B; h.epi = EPI_NONE;
-            if (s->prenorm && s->cb.x_parts && h.tiled == 1) {      // the last layer's down-proj left X * cp_norm and the partial sums
-                h.x = s->cb.XZ + (size_t)(rows - 1) * CH; h.norm_w = nullptr;
-                h.ssq_in = s->cb.SQX + (size_t)(rows - 1) * s->cb.x_parts; h.ssq_parts = s->cb.x_parts; h.ssq_ld = rows * s->cb.x_parts;
-            }
             HIPC(run_linear(s, h));
         }
     }
@@ -1483,10 +1465,6 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
         if ((e = s->pool.alloc(&b.Q, R * QD)) != hipSuccess) return e;
         if ((e = s->pool.alloc(&b.ATT, R * QD)) != hipSuccess) return e;
         if ((e = s->pool.alloc(&b.ACT, R * d.I)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.XZ, R * d.H)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.SUMZ, R * d.H)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.SQX, R * SSQ_MAX_PARTS)) != hipSuccess) return e;
-        if ((e = s->pool.alloc(&b.SQS, R * SSQ_MAX_PARTS)) != hipSuccess) return e;
         return s->pool.alloc(&b.PART, R * d.nh * nsplit * PART_STRIDE);
     };
     HIPC(alloc_lm(s->tb, talker_dims(c), s->n_splits));
@@ -2262,10 +2240,9 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
                 a.N = CH; a.K = H; set_w(a, m->mtp_w, B, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = CH; a.M = B; a.epi = EPI_NONE;
                 HIPC(launch_linear(a, s->stream));
             }
-            s->cb.x_parts = 0;
             for (int i = 0; i < c.cp_layers; ++i)
                 Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,
-                             c.n_groups + 1, nullptr, p, 1, 1, false, i + 1 < c.cp_layers ? m->cl[i + 1].in_ln : nullptr));
+                             c.n_groups + 1, nullptr, p, 1));
             if (p >= 1) {
                 LinArgs h;
                 h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X; h.ldx = CH; h.norm_w = m->cp_norm; h.eps = c.rms_eps;
@@ -2415,6 +2392,23 @@ extern "C" q3_status q3_session_profile_read(q3_session* s, double* ms, double* 
     return Q3_OK;
 }
 
+// the distinct GEMV launches (and how often each ran) since profiling was enabled / last reset: rows of 8 ints
+// {M, N, K, epilogue, input norm (0 none / 1 in-kernel / 2 pre-normed), producer outputs, tiling, count}
+extern "C" q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap_rows, int* n_rows, int reset) {
+    if (!s || !n_rows) return set_err(Q3_INVALID_ARG, "null argument");
+    *n_rows = (int)s->prof_shapes.size();
+    if (rows) {
+        if (cap_rows < *n_rows) return set_err(Q3_INVALID_ARG, "shape buffer too small (%d < %d rows)", cap_rows, *n_rows);
+        for (int i = 0; i < *n_rows; ++i) {
+            const ProfShape& q = s->prof_shapes[i];
+            const int v[8] = {q.M, q.N, q.K, q.epi, q.rms, q.produce, q.tiled, q.count};
+            memcpy(rows + (size_t)i * 8, v, sizeof v);
+        }
+    }
+    if (reset) s->prof_shapes.clear();
+    return Q3_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // micro-benchmark of one GEMV shape (kernel development aid, used by tests/bench_kernels.py):
 // `iters` back-to-back launches cycling over `n_copies` distinct weight buffers (so the stream comes
@@ -2424,18 +2418,14 @@ extern "C" q3_status q3_session_profile_read(q3_session* s, double* ms, double* 
 extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                                      double* avg_us) {
     if (M < 1 || M > 16 || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
-    // rms: 0 none, 1 norm weight applied in the kernel, 2 pre-normed input + 128 partial sums (producer-side RMSNorm);
-    // epi | 16: the launch also writes z_out / ssq_out (the producer side)
-    const bool produce = (epi & 16) != 0; epi &= 15;
     if (tiled < 0) tiled = (N < 4096 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
     HIPC(hipSetDevice(device));
     DevPool pool;
     const size_t welems = tiled == 2 ? tiled_elems(2, N, K) : tiled_elems(1, N, K);
     const int nmat = epi == EPI_SWIGLU ? 2 : 1;
-    uint16_t* w; float *x, *y, *nw, *res, *zo, *sq, *zw;
+    uint16_t* w; float *x, *y, *nw, *res;
     HIPC(pool.alloc(&w, welems * nmat * n_copies));
     HIPC(pool.alloc(&x, (size_t)16 * K)); HIPC(pool.alloc(&y, (size_t)16 * N)); HIPC(pool.alloc(&nw, (size_t)K)); HIPC(pool.alloc(&res, (size_t)16 * N));
-    HIPC(pool.alloc(&zo, (size_t)16 * N)); HIPC(pool.alloc(&sq, (size_t)16 * (N > 512 ? N : 512))); HIPC(pool.alloc(&zw, (size_t)N));
     {   // random-ish bf16 weights / f32 activations (never zeros: DVFS, guide §5.4 rule 25)
         std::vector<uint16_t> hw(welems);
         q3_synth_fill(1, "bench.w", Q3_DTYPE_BF16, 0.02f, 0.0f, (int64_t)welems, hw.data());
@@ -2451,10 +2441,8 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
         const int c = i % n_copies;
         a.W = w + (size_t)c * nmat * welems; a.W2 = nmat == 2 ? a.W + welems : nullptr;
         a.N = N; a.K = K; a.Kpad = tiled == 2 ? up128(K) : up32(K); a.tiled = tiled; a.x = x; a.ldx = K; a.y = y; a.ldy = N; a.M = M; a.epi = epi;
-        if (rms == 1) { a.norm_w = nw; a.eps = 1e-6f; }
-        if (rms == 2) { a.ssq_in = sq; a.ssq_parts = 128; a.ssq_ld = 128; a.eps = 1e-6f; }
+        if (rms) { a.norm_w = nw; a.eps = 1e-6f; }
         if (epi == EPI_RESID) { a.resid = res; a.ldr = N; }
-        if (produce) { a.z_out = zo; a.ldz = N; a.z_w = zw; a.ssq_out = sq; }
         return launch_linear(a, st);
     };
     for (int i = 0; i < 4; ++i) HIPC(one(i));

@@ -25,14 +25,7 @@ struct LinArgs {
     int epi = EPI_NONE;
     int tiled = 0;                  // 1: 16-row MFMA tiles [N/16][Kpad/32][64 lanes][8 bf16]; 2: 4-row tiles [N/4][Kpad/128][64][8]
     int Kpad = 0;                   // K rounded up to 32 (tiled == 1) or 128 (tiled == 2)
-    // Producer-side RMSNorm (decode chain): the GEMV that WRITES a hidden state also writes z = y * z_w (the consumer's norm
-    // weight folded in once, instead of once per consuming workgroup) and, per output tile, the partial sum of y^2 of
-    // its columns: ssq_out[m][tile], tiles = linear_out_tiles(). The consuming GEMV (norm_w == nullptr, ssq_in != nullptr)
-    // reads z as its x, adds the partials of row m in a fixed order and divides its result by sqrt(sum / K + eps).
-    float* z_out = nullptr; int ldz = 0; const float* z_w = nullptr; float* ssq_out = nullptr;
-    const float* ssq_in = nullptr; int ssq_parts = 0; int ssq_ld = 0;   // ssq_in[m * ssq_ld + part]; ssq_parts % 4 == 0, <= 512
 };
-inline int linear_out_tiles(const LinArgs& a) { return a.tiled == 2 ? (a.N + 3) / 4 : (a.N + 15) / 16; }
 hipError_t launch_linear(const LinArgs& a, hipStream_t st);       // dispatches on a.tiled
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st);   // MFMA bf16x3 kernel (16-row tiles, tiled == 1)
 hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st);  // 4-row tiles on the 4x4x4 16-block MFMA (tiled == 2)

@@ -111,27 +111,6 @@ __device__ __forceinline__ Split3 gemv_prep(bool valid, const float4& x0, const 
     return split3(xv);
 }
 
-// ---- producer-side RMSNorm (LinArgs::z_out / ssq_out / ssq_in) ----
-// consumer: this thread's share of row `col`'s partial sums, requested at kernel start (16 threads per row, float4 j*16 + row)
-struct SsqPre { float4 q[8]; };
-__device__ __forceinline__ void ssq_request(SsqPre& p, const LinArgs& a, int col, int row, bool on) {
-    const int nq = a.ssq_parts >> 2;
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.ssq_in + (size_t)col * a.ssq_ld);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int idx = row + 16 * j;
-        p.q[j] = (on && idx < nq) ? src[idx] : float4{0.f, 0.f, 0.f, 0.f};
-    }
-}
-// fixed-order total over the 16 threads of a row (all 64 lanes must call it)
-__device__ __forceinline__ float ssq_total(const SsqPre& p) {
-    float t = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { t += p.q[j].x; t += p.q[j].y; t += p.q[j].z; t += p.q[j].w; }
-    t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
-    return t;
-}
-
 // NWAVES waves split K; weights for up to G k-steps are requested up front (G KiB per wave in flight per
 // matrix) before any of them is consumed, so a wave's whole slice is usually one HBM round trip.
 //
@@ -140,13 +119,10 @@ __device__ __forceinline__ float ssq_total(const SsqPre& p) {
 // column's 32 bytes are fetched by lanes m and m + 8 of the same 16-lane row in ONE instruction (lane m + 8 would
 // otherwise idle) and exchanged with a DPP row rotate: one x (and one norm-weight) instruction per k-step instead of two.
 // Lanes m >= 8 end up holding column m - 8 with its halves swapped — columns nobody reads.
-// RMSM: 0 = no input norm, 1 = fused input RMSNorm from raw x (norm weight loaded and applied here), 2 = x already carries
-// the norm weight and the row's sum of squares arrives as partial sums (ssq_in) from the kernel that wrote x.
-template <int EPI, int RMSM, int NWAVES, bool HALF>
+template <int EPI, bool RMS, int NWAVES, bool HALF>
 __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
-    constexpr bool RMS = RMSM == 1;
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr int G = (NW == 2 || RMSM != 0) ? 4 : 6;
+    constexpr int G = (NW == 2 || RMS) ? 4 : 6;
     __shared__ __attribute__((aligned(16))) float red[NWAVES][NW][256];
     __shared__ float ssq[NWAVES][4][16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -162,16 +138,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 + xhalf : nullptr;
 
     // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
-    float pre_b = 0.0f, pre_r = 0.0f, pre_zw = 0.0f;
-    SsqPre pre_q;
+    float pre_b = 0.0f, pre_r = 0.0f;
     {
         const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
         if (tid < 256 && col < a.M && n < a.N) {
             if (a.bias) pre_b = a.bias[n];
             if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
-            if (a.z_w) pre_zw = a.z_w[n];
         }
-        if constexpr (RMSM == 2) ssq_request(pre_q, a, col < a.M ? col : 0, tid & 15, tid < 256 && col < a.M);
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.0f;
@@ -181,50 +154,95 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     // 16-wave workgroups have 128 VGPRs per lane — not enough to hold a group's splits — and keep the interleaved
     // per-step order.
     constexpr bool HOIST = NWAVES <= 8;
-    for (int sb = s0; sb < s1; sb += G) {
-        u32x4_t wa[G], wb[G];
-        float4 xa[G], xb[G], na[G], nb[G];
-        if constexpr (HOIST) {
+    // two groups in flight only where the registers are there: the half-row form (M <= 8) holds half the x / norm operands
+#ifdef Q3_NO_PIPE
+    constexpr bool PIPE = false;      // development aid: A/B build without the software pipeline
+#else
+    constexpr bool PIPE = HALF;
+#endif
+    if constexpr (HOIST) {
+        // Software-pipelined groups: the loads of group i + 1 are in flight while group i is split and multiplied, so a
+        // wave whose K slice is longer than one group (K >= 2048) pays ONE HBM round trip plus streaming, not one per
+        // group. The two consume sites are separate code paths on purpose: vmcnt is a static count, and a join of
+        // "next group requested" with "nothing requested" would force the wait for the current group down to vmcnt(0).
+        struct Grp { u32x4_t wa[G], wb[G]; float4 xa[G], xb[G], na[G], nb[G]; };
+        auto load_group = [&](Grp& g, int sb) {
 #pragma unroll
             for (int i = 0; i < G; ++i) {
-                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);      // clamp: duplicate load, masked below
-                const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;    // K tail (K % 32 != 0): clamp, masked below
-                // lanes of unused batch columns (m >= M) issue no request — measured per variant: qkv 7.8 -> 7.4 us,
-                // code-predictor qkv 5.2 -> 4.6 us at M = 8, but the SwiGLU pair loses (13.7 -> 15.7 us) and stays unmasked
+                const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);      // clamp: duplicate load, masked in consume
+                const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;    // K tail (K % 32 != 0): clamp, masked in consume
+                // lanes of unused batch columns issue no request — measured per variant: qkv 7.8 -> 7.4 us, code-predictor
+                // qkv 5.2 -> 4.6 us at M = 8, but the two-instruction SwiGLU pair loses (13.7 -> 15.7 us) and stays unmasked
                 const bool ld = (NW == 2 && !HALF) || act;
-                xa[i] = ld ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (!HALF) xb[i] = ld ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                g.xa[i] = ld ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) g.xb[i] = ld ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (RMS) {
-                    na[i] = *reinterpret_cast<const float4*>(nwp + ko);
-                    if constexpr (!HALF) nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
+                    g.na[i] = *reinterpret_cast<const float4*>(nwp + ko);
+                    if constexpr (!HALF) g.nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
                 }
             }
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
 #if Q3_ABLATE == 4
-                wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; wb[i] = wa[i];
+                g.wa[i] = u32x4_t{(unsigned)s, 1u, 2u, 3u}; g.wb[i] = g.wa[i];
 #else
-                wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
-                if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
+                g.wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+                if constexpr (NW == 2) g.wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
 #endif
             }
-            __builtin_amdgcn_sched_barrier(0);      // keep every load of the group issued before the first use
+        };
+        auto consume = [&](Grp& g, int sb) {
             Split3 sp[G];
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int s = sb + i;      // s >= s1 (ragged last group): zero operand, its MFMAs add nothing — no branch,
                 const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;   // so the group stays one scheduling region
-                if constexpr (HALF) { xb[i] = ror8(xa[i]); if constexpr (RMS) nb[i] = ror8(na[i]); }
-                sp[i] = gemv_prep<RMS>(valid, xa[i], xb[i], RMS ? na[i] : xa[i], RMS ? nb[i] : xb[i], ss);
+                if constexpr (HALF) { g.xb[i] = ror8(g.xa[i]); if constexpr (RMS) g.nb[i] = ror8(g.na[i]); }
+                sp[i] = gemv_prep<RMS>(valid, g.xa[i], g.xb[i], RMS ? g.na[i] : g.xa[i], RMS ? g.nb[i] : g.xb[i], ss);
             }
             __builtin_amdgcn_sched_barrier(0);      // all splits done before the first wait on a weight tile
 #pragma unroll
             for (int i = 0; i < G; ++i) {
-                acc0 = mfma3(wa[i], sp[i], acc0);
-                if constexpr (NW == 2) acc1 = mfma3(wb[i], sp[i], acc1);
+                acc0 = mfma3(g.wa[i], sp[i], acc0);
+                if constexpr (NW == 2) acc1 = mfma3(g.wb[i], sp[i], acc1);
             }
-        } else {
+        };
+        if constexpr (!PIPE) {
+            Grp A;
+            for (int sb = s0; sb < s1; sb += G) {
+                load_group(A, sb);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(A, sb);
+            }
+        } else if (s0 < s1) {
+            Grp A, B;
+            load_group(A, s0);
+            for (int sb = s0;; sb += 2 * G) {
+                if (sb + G < s1) {
+                    load_group(B, sb + G);
+                    __builtin_amdgcn_sched_barrier(0);      // keep every load issued before the first use
+                    consume(A, sb);
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(A, sb);
+                    break;
+                }
+                if (sb + 2 * G < s1) {
+                    load_group(A, sb + 2 * G);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(B, sb + G);
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(B, sb + G);
+                    break;
+                }
+            }
+        }
+    } else {
+        for (int sb = s0; sb < s1; sb += G) {
+            u32x4_t wa[G], wb[G];
+            float4 xa[G], xb[G], na[G], nb[G];
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
@@ -264,44 +282,33 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = acc1;
     if constexpr (RMS) ssq[wave][kg][m] = ss;
     __syncthreads();
-    if (tid < 256) {             // whole waves (0-3): the shuffles below run on all 64 lanes
+    if (tid < 256) {
         const int col = tid >> 4, row = tid & 15;
-        const int n = blockIdx.x * 16 + row;
-        const bool live = col < a.M && n < a.N;
-        float tot_pre = 0.0f;
-        if constexpr (RMSM == 2) tot_pre = ssq_total(pre_q);
-        float v = 0.0f, v2 = 0.0f;
         if (col < a.M) {
+            float v = 0.0f, v2 = 0.0f;
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w) {
                 v += red[w][0][tid];
                 if constexpr (NW == 2) v2 += red[w][1][tid];
             }
-            if constexpr (RMSM != 0) {
-                float tot = tot_pre;
-                if constexpr (RMS) {
+            if constexpr (RMS) {
+                float tot = 0.0f;
 #pragma unroll
-                    for (int w = 0; w < NWAVES; ++w)
+                for (int w = 0; w < NWAVES; ++w)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) tot += ssq[w][g][col];
-                }
+                    for (int g = 0; g < 4; ++g) tot += ssq[w][g][col];
                 const float den = sqrtf(tot / (float)a.K + a.eps);
                 v = v / den;
                 if constexpr (NW == 2) v2 = v2 / den;
             }
+            const int n = blockIdx.x * 16 + row;
             if (n < a.N) {
                 if (a.bias) v = v + pre_b;
                 if constexpr (EPI == EPI_RESID) v = pre_r + v;
                 if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
                 if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
                 a.y[(size_t)col * a.ldy + n] = v;
-                if (a.z_out) a.z_out[(size_t)col * a.ldz + n] = v * pre_zw;
             }
-        }
-        if (a.ssq_out) {          // wave-uniform: partial sum of y^2 over this tile's 16 output columns, fixed order
-            float q = live ? v * v : 0.0f;
-            q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
-            if (row == 0 && col < a.M) a.ssq_out[(size_t)col * gridDim.x + blockIdx.x] = q;
         }
     }
 }
@@ -410,13 +417,12 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
     float* __restrict__ ssq = lds + NWAVES * ZB;      // [NWAVES][16], outside the area `red` aliases
 
     // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
-    float pre_b = 0.0f, pre_r = 0.0f, pre_zw = 0.0f;
+    float pre_b = 0.0f, pre_r = 0.0f;
     {
         const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
         if (tid < 256 && col < a.M && n < a.N) {
             if (a.bias) pre_b = a.bias[n];
             if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
-            if (a.z_w) pre_zw = a.z_w[n];
         }
     }
 
@@ -462,12 +468,10 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
     *reinterpret_cast<f32x4_t*>(&red[(wave * NW + 0) * 256 + m * 16 + kg * 4]) = acc0;
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[(wave * NW + 1) * 256 + m * 16 + kg * 4]) = acc1;
     __syncthreads();
-    if (tid < 256) {             // whole waves (0-3): the shuffles below run on all 64 lanes
+    if (tid < 256) {
         const int col = tid >> 4, row = tid & 15;
-        const int n = blockIdx.x * 16 + row;
-        const bool live = col < a.M && n < a.N;
-        float v = 0.0f, v2 = 0.0f;
         if (col < a.M) {
+            float v = 0.0f, v2 = 0.0f;
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w) {
                 v += red[(w * NW + 0) * 256 + tid];
@@ -481,24 +485,19 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
                 v = v / den;
                 if constexpr (NW == 2) v2 = v2 / den;
             }
+            const int n = blockIdx.x * 16 + row;
             if (n < a.N) {
                 if (a.bias) v = v + pre_b;
                 if constexpr (EPI == EPI_RESID) v = pre_r + v;
                 if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
                 if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
                 a.y[(size_t)col * a.ldy + n] = v;
-                if (a.z_out) a.z_out[(size_t)col * a.ldz + n] = v * pre_zw;
             }
-        }
-        if (a.ssq_out) {          // producer-side RMSNorm: see k_gemv_mfma
-            float q = live ? v * v : 0.0f;
-            q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
-            if (row == 0 && col < a.M) a.ssq_out[(size_t)col * gridDim.x + blockIdx.x] = q;
         }
     }
 }
 
-template <int EPI, int RMS>      // RMS: k_gemv_mfma's RMSM
+template <int EPI, bool RMS>
 static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     const int tiles = (a.N + 15) / 16;
     const int S = a.Kpad >> 5;
@@ -516,12 +515,13 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     const bool lds_ok = a.K % 4 == 0 && S >= 8;
     // long-K projections (down-proj, S >= 96) beyond 8 tokens: the LDS-staged kernel is flat in M where the
     // register-direct one pays for every x row (talker down M = 16: 14.2 vs 16.2 us; code-predictor down 7.9 vs 8.8)
-    const bool lds_pick = (tiles < 256 && S > 32 && S <= 64) || (a.M > 8 && S >= 96);
-    if constexpr (RMS != 2) {
-        if (lds_ok && (force == 1 || (force == 0 && lds_pick))) {
-            hipLaunchKernelGGL((k_gemv_lds<EPI, RMS == 1>), dim3(tiles), dim3(512), 0, st, a);
-            return hipGetLastError();
-        }
+    static const bool no_lds = getenv("Q3_GEMV_NO_LDS") != nullptr;       // tuning aids
+    static const bool big8 = getenv("Q3_GEMV_BIG8") != nullptr;
+    const bool lds_pick = !no_lds && ((tiles < 256 && S > 32 && S <= 64) || (a.M > 8 && S >= 96));
+    if (big8 && a.M <= 8) big = false;
+    if (lds_ok && (force == 1 || (force == 0 && lds_pick))) {
+        hipLaunchKernelGGL((k_gemv_lds<EPI, RMS>), dim3(tiles), dim3(512), 0, st, a);
+        return hipGetLastError();
     }
     if (force == 8) big = false; else if (force == 16) big = true;
     // the two-matrix SwiGLU tile at K = 2048 (talker gate/up, 50 MB): 4 waves — three workgroups fit a CU and the stream
@@ -593,13 +593,12 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     }
     const float* __restrict__ nwp = RMS ? a.norm_w + kb * 8 : nullptr;
 
-    float pre_b = 0.0f, pre_r = 0.0f, pre_zw = 0.0f;     // epilogue operands requested up front (see k_gemv_mfma)
+    float pre_b = 0.0f, pre_r = 0.0f;     // epilogue operands requested up front (see k_gemv_mfma)
     if (tid < 16 * MG) {
         const int m = tid >> 2, n = blockIdx.x * 4 + (tid & 3);
         if (m < a.M && n < a.N) {
             if (a.bias) pre_b = a.bias[n];
             if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)m * a.ldr + n];
-            if (a.z_w) pre_zw = a.z_w[n];
         }
     }
     f32x4_t acc[NW][MG];
@@ -722,19 +721,18 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
         }
     }
     __syncthreads();
-    if (tid < 64) {               // wave 0 (16 * MG <= 64 threads carry results; the shuffles below need the whole wave)
+    if (tid < 16 * MG) {
         const int m = tid >> 2, i = tid & 3, g = m >> 2, jj = m & 3;
         const int n = blockIdx.x * 4 + i;
-        const bool live = tid < 16 * MG && m < a.M && n < a.N;
-        float v = 0.0f, v2 = 0.0f;
-        if (live) {
+        if (m < a.M && n < a.N) {
+            float v = 0.0f, v2 = 0.0f;
             for (int w = 0; w < nwv; ++w) {
-                v += red[w][0][g < MG ? g : 0][i][jj];
-                if constexpr (NW == 2) v2 += red[w][1][g < MG ? g : 0][i][jj];
+                v += red[w][0][g][i][jj];
+                if constexpr (NW == 2) v2 += red[w][1][g][i][jj];
             }
             if constexpr (RMS) {
                 float tot = 0.0f;
-                for (int w = 0; w < nwv; ++w) tot += ssq[w][g < MG ? g : 0][jj];
+                for (int w = 0; w < nwv; ++w) tot += ssq[w][g][jj];
                 const float den = sqrtf(tot / (float)a.K + a.eps);
                 v = v / den;
                 if constexpr (NW == 2) v2 = v2 / den;
@@ -744,12 +742,6 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
             if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
             if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
             a.y[(size_t)m * a.ldy + n] = v;
-            if (a.z_out) a.z_out[(size_t)m * a.ldz + n] = v * pre_zw;
-        }
-        if (a.ssq_out) {          // producer-side RMSNorm: partial sum of y^2 over this tile's 4 output columns
-            float q = live ? v * v : 0.0f;
-            q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
-            if (i == 0 && tid < 16 * MG && m < a.M) a.ssq_out[(size_t)m * gridDim.x + blockIdx.x] = q;
         }
     }
 }
@@ -774,7 +766,6 @@ static hipError_t launch_gemv4_t(const LinArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st) {
-    if (a.ssq_in) return hipErrorInvalidValue;          // the pre-normed input form exists for the 16-row tiles only
     if (a.Kpad % 128 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
         return hipErrorInvalidValue;
     const bool rms = a.norm_w != nullptr;
@@ -791,17 +782,11 @@ hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st) {
     if (a.Kpad % 32 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
         return hipErrorInvalidValue;
     const bool rms = a.norm_w != nullptr;
-    if (a.ssq_in) {          // pre-normed input: partial sums of squares from the producing launch
-        if (rms || a.ssq_parts < 4 || a.ssq_parts % 4 != 0 || a.ssq_parts > 512 || a.ssq_ld % 4 != 0) return hipErrorInvalidValue;
-        if (a.epi == EPI_NONE) return launch_gemv_t<EPI_NONE, 2>(a, st);
-        if (a.epi == EPI_SWIGLU) return launch_gemv_t<EPI_SWIGLU, 2>(a, st);
-        return hipErrorInvalidValue;
-    }
     switch (a.epi) {
-        case EPI_NONE: return rms ? launch_gemv_t<EPI_NONE, 1>(a, st) : launch_gemv_t<EPI_NONE, 0>(a, st);
-        case EPI_RESID: return rms ? hipErrorInvalidValue : launch_gemv_t<EPI_RESID, 0>(a, st);
-        case EPI_SILU: return rms ? hipErrorInvalidValue : launch_gemv_t<EPI_SILU, 0>(a, st);
-        case EPI_SWIGLU: return rms ? launch_gemv_t<EPI_SWIGLU, 1>(a, st) : launch_gemv_t<EPI_SWIGLU, 0>(a, st);
+        case EPI_NONE: return rms ? launch_gemv_t<EPI_NONE, true>(a, st) : launch_gemv_t<EPI_NONE, false>(a, st);
+        case EPI_RESID: return rms ? hipErrorInvalidValue : launch_gemv_t<EPI_RESID, false>(a, st);
+        case EPI_SILU: return rms ? hipErrorInvalidValue : launch_gemv_t<EPI_SILU, false>(a, st);
+        case EPI_SWIGLU: return rms ? launch_gemv_t<EPI_SWIGLU, true>(a, st) : launch_gemv_t<EPI_SWIGLU, false>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -55,7 +55,7 @@ def main(argv=None) -> int:
     dev = parse_device(a.device)
     if a.synthetic:
         model = q.Qwen3TTS.from_synthetic({"tiny": q.tiny, "0.6b": q.qwen3_tts_0_6b, "1.7b": q.qwen3_tts_1_7b}[a.synthetic](), device=dev)
-        tok = TextTokenizer.from_pretrained(None)
+        tok = TextTokenizer.from_pretrained(None, allow_stand_in=True)
     else:
         model = q.Qwen3TTS.from_pretrained(a.model_dir, device=dev)
         tok = TextTokenizer.from_pretrained(a.model_dir)

@@ -20,9 +20,12 @@ class TextTokenizer:
             self.kind = "tokenizer.json"
 
     @classmethod
-    def from_pretrained(cls, model_dir: Optional[str], tokenizer_dir: Optional[str] = None) -> "TextTokenizer":
-        """model_dir/tokenizer.json, else <tokenizer_dir>/tokenizer.json, else model_dir/../tokenizer/tokenizer.json
-        (generate_audio.rs:48-50), else the stand-in."""
+    def from_pretrained(cls, model_dir: Optional[str], tokenizer_dir: Optional[str] = None, allow_stand_in: bool = False) -> "TextTokenizer":
+        """<tokenizer_dir>/tokenizer.json, else model_dir/tokenizer.json, else model_dir/../tokenizer/tokenizer.json
+        (generate_audio.rs:48-50). A real checkpoint without a tokenizer is an ERROR, as in the reference
+        (TextTokenizer::from_pretrained, text.rs:62-110): synthesizing from stand-in ids would silently produce
+        meaningless audio. The stand-in is handed out only when the caller asks for it (`allow_stand_in`: synthetic
+        checkpoints, or no model directory at all)."""
         cands = []
         if tokenizer_dir:
             cands.append(os.path.join(tokenizer_dir, "tokenizer.json"))
@@ -31,6 +34,9 @@ class TextTokenizer:
         for c in cands:
             if os.path.exists(c):
                 return cls(c)
+        if model_dir is not None and not allow_stand_in:
+            raise FileNotFoundError("Failed to load tokenizer: no tokenizer.json in " + ", ".join(os.path.dirname(c) for c in cands) +
+                                    " (pass --tokenizer-dir, or --token-ids to bypass the tokenizer)")
         return cls(None)
 
     def encode(self, text: str) -> List[int]:

@@ -1,7 +1,8 @@
 """Kernel micro-benchmarks (development aid): GEMV shapes of the 1.7B talker / code predictor at M = 1 / 8 (Q3_BENCH_M).
 Prints µs per launch (mean of 5 graph replays, incl. the graph-internal kernel boundary) and GB/s.
-Columns: `rms1` = RMSNorm weight applied inside the consuming GEMV, `pre` = producer-side RMSNorm (pre-normed x + partial
-sums), `+prod` = the launch also writes z_out / ssq_out. Environment: Q3_GEMV_NO_HALF=1 → two-instruction x loads."""
+Columns: t-1 = the engine's tiling choice, t1 = 16-row tiles, t2 = 4-row tiles. Environment (tuning aids of the launcher):
+Q3_GEMV_NO_HALF=1 two-instruction x loads, Q3_GEMV_NO_LDS=1 no LDS-staged kernel, Q3_GEMV_BIG8=1 long-K shapes on 8 waves,
+Q3TTS_LIB=build/libq3tts_nopipe.so the build without the software-pipelined groups."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qwen3_tts_rs_amd as q
@@ -34,12 +35,9 @@ for name, N, K, epi, rmsc, prod in SHAPES:
     nbytes = N * K * 2 * (2 if epi == 3 else 1)
     row = f"{name:16s} N={N:5d} K={K:5d} {nbytes / 1e6:6.1f} MB |"
     for M in Ms:
-        variants = [("rms1" if rmsc else "base", epi, 1 if rmsc else 0)]
-        if rmsc:
-            variants.append(("pre", epi, 2))
-        if prod:
-            variants.append(("+prod", epi | 16, 0))
-        for tag, e, r in variants:
-            us = run(M, N, K, e, r)
-            row += f" M{M} {tag}: " + ("ERR" if us is None else f"{us:6.2f} us {nbytes / us / 1e3:5.0f} GB/s") + " |"
+        for tiled in (-1, 1, 2):          # the engine's choice, 16-row tiles, 4-row tiles
+            if tiled == 2 and (N >= 4096 or rmsc):
+                continue
+            us = run(M, N, K, epi, 1 if rmsc else 0, tiled)
+            row += f" M{M} t{tiled}: " + ("ERR" if us is None else f"{us:6.2f} us {nbytes / us / 1e3:5.0f} GB/s") + " |"
     print(row, flush=True)

@@ -35,6 +35,12 @@ def test_tokenizer_standin_and_tokenizer_json(tmp_path):
     tk.save(str(tmp_path / "m" / "tokenizer.json"))
     t2 = TextTokenizer.from_pretrained(str(tmp_path / "m"))
     assert t2.kind == "tokenizer.json" and t2.encode("hello world zzz") == [5, 9, 0]
+    # a real model directory WITHOUT a tokenizer is an error (the reference fails to load, text.rs:62-110) — never the stand-in
+    (tmp_path / "bare").mkdir()
+    with pytest.raises(FileNotFoundError, match="Failed to load tokenizer"):
+        TextTokenizer.from_pretrained(str(tmp_path / "bare"))
+    assert TextTokenizer.from_pretrained(str(tmp_path / "bare"), allow_stand_in=True).kind == "synthetic-wordpiece"
+    assert cli.main(["--model-dir", str(tmp_path / "bare"), "--text", "hello"]) == 2      # exits non-zero before touching the GPU
 
 
 @pytest.mark.gpu

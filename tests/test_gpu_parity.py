@@ -778,6 +778,24 @@ def test_synthesize_batch_groups_by_prefill_shape(pair):
 
 
 @pytest.mark.gpu
+def test_synthesize_batch_icl_requests_with_different_text_lengths(pair):
+    """Two ICL voice-clone requests with the same reference but different text lengths resolve to different max_length
+    caps (max(75, 6 * n_text), lib.rs:913-929): synthesize_batch must serve them in separate sessions, not fail."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(5)
+    ref = rng.integers(0, 2048, size=(4, 16)).astype(np.uint32); ref[:, 0] = rng.integers(0, 3072, 4)
+    xv = rng.standard_normal(cfg.hidden).astype(np.float32)
+    utts = [q.Utterance(synthetic_prompt(n, 3 + n), language=q.Language.Korean, xvector=xv, ref_codes=ref,
+                        ref_text_ids=synthetic_prompt(3, 4), seed=9) for n in (13, 20, 13)]
+    opts = q.SynthesisOptions(seed=9, eos_token_id=None)           # default max_length 2048 → caps 78 / 120 / 78
+    audio, timing = gm.synthesize_batch(utts, opts)
+    # decode = [reference frames ; generated] with the reference's share cut from the front (lib.rs:1022-1041)
+    assert [len(a) for a in audio] == [78 * 1920, 120 * 1920, 78 * 1920]
+    s = gm.session([utts[1]], opts); a1, _ = s.run(); s.close()
+    np.testing.assert_array_equal(audio[1].samples, a1[0].samples)
+
+
+@pytest.mark.gpu
 def test_dp_two_ranks_on_one_gpu():
     """The data-parallel start-up of bench.py with real GPU memory on both sides: 2 ranks (gloo, both on cuda:0), arena
     broadcast from rank 0, non-root finalize, identical codes and PCM on both ranks (tests/dp_same_gpu_check.py)."""
