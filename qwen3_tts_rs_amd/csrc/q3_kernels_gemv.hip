@@ -154,17 +154,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     // 16-wave workgroups have 128 VGPRs per lane — not enough to hold a group's splits — and keep the interleaved
     // per-step order.
     constexpr bool HOIST = NWAVES <= 8;
-    // two groups in flight only where the registers are there: the half-row form (M <= 8) holds half the x / norm operands
-#ifdef Q3_NO_PIPE
-    constexpr bool PIPE = false;      // development aid: A/B build without the software pipeline
-#else
-    constexpr bool PIPE = HALF;
-#endif
     if constexpr (HOIST) {
-        // Software-pipelined groups: the loads of group i + 1 are in flight while group i is split and multiplied, so a
-        // wave whose K slice is longer than one group (K >= 2048) pays ONE HBM round trip plus streaming, not one per
-        // group. The two consume sites are separate code paths on purpose: vmcnt is a static count, and a join of
-        // "next group requested" with "nothing requested" would force the wait for the current group down to vmcnt(0).
+        // (Keeping a second group's loads in flight while the first is split and multiplied — a software pipeline over the
+        // groups — was built and measured: qkv 6.22 -> 7.29 us, gate/up 13.24 -> 13.81 us at M = 8, the frame 1.4 % slower:
+        // twice the live registers cost a resident workgroup per CU; profiles/r2_gemv_variants_M8.txt.)
         struct Grp { u32x4_t wa[G], wb[G]; float4 xa[G], xb[G], na[G], nb[G]; };
         auto load_group = [&](Grp& g, int sb) {
 #pragma unroll
@@ -208,36 +201,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
                 if constexpr (NW == 2) acc1 = mfma3(g.wb[i], sp[i], acc1);
             }
         };
-        if constexpr (!PIPE) {
-            Grp A;
-            for (int sb = s0; sb < s1; sb += G) {
-                load_group(A, sb);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(A, sb);
-            }
-        } else if (s0 < s1) {
-            Grp A, B;
-            load_group(A, s0);
-            for (int sb = s0;; sb += 2 * G) {
-                if (sb + G < s1) {
-                    load_group(B, sb + G);
-                    __builtin_amdgcn_sched_barrier(0);      // keep every load issued before the first use
-                    consume(A, sb);
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
-                    consume(A, sb);
-                    break;
-                }
-                if (sb + 2 * G < s1) {
-                    load_group(A, sb + 2 * G);
-                    __builtin_amdgcn_sched_barrier(0);
-                    consume(B, sb + G);
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
-                    consume(B, sb + G);
-                    break;
-                }
-            }
+        Grp A;
+        for (int sb = s0; sb < s1; sb += G) {
+            load_group(A, sb);
+            __builtin_amdgcn_sched_barrier(0);      // keep every load of the group issued before the first use
+            consume(A, sb);
         }
     } else {
         for (int sb = s0; sb < s1; sb += G) {
