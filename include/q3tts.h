@@ -364,7 +364,7 @@ q3_status q3_dp_init(int rank, int world, const void* id, int device, q3_dp_comm
 void q3_dp_free(q3_dp_comm* c);
 q3_status q3_dp_info(const q3_dp_comm* c, int* rank, int* world);
 /* ncclBroadcast of the whole weight arena from `root` (collective); non-root ranks are marked loaded and must then
- * call q3_model_finalize themselves. world == 1: no-op. */
+ * call q3_model_finalize themselves. world == 1: the broadcast degenerates to a self-copy RCCL performs in place. */
 q3_status q3_dp_broadcast_weights(q3_dp_comm* c, q3_model* m, int root);
 /* ncclAllGather of n doubles per rank: out_host [world][n] (timings, frame counts) */
 q3_status q3_dp_allgather_f64(q3_dp_comm* c, const double* in_host, int n, double* out_host);

@@ -177,11 +177,12 @@ class Session:
             if u.xvector is not None:
                 xv = np.ascontiguousarray(u.xvector, dtype=np.float32); self._keep.append(xv)
                 r.xvector = xv.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-            if u.ref_codes is not None and u.ref_text_ids is not None:
+            if u.ref_codes is not None:          # prepended at decode even without a transcript (lib.rs:1022); ICL needs both
                 rc = np.ascontiguousarray(u.ref_codes, dtype=np.uint32).reshape(-1, 16); self._keep.append(rc)
-                rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); self._keep.append(rt)
                 r.ref_codes = rc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref = rc.shape[0]
-                r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
+                if u.ref_text_ids is not None:
+                    rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); self._keep.append(rt)
+                    r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
             o = options.to_c()
             if u.seed is not None:
                 o.seed = int(u.seed); o.has_seed = 1

@@ -46,7 +46,10 @@ void load_api() {
 }
 q3_status need_api() {
     std::call_once(api_once, load_api);
-    if (!api.ok) return q3i_set_err(Q3_RCCL_ERROR, "RCCL not available: librccl.so(.1) could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+    if (!api.ok) {
+        const char* why = dlerror();      // one call: dlerror() clears its state, a second call returns NULL
+        return q3i_set_err(Q3_RCCL_ERROR, "RCCL not available: librccl.so(.1) could not be loaded (%s)", why ? why : "missing symbols");
+    }
     return Q3_OK;
 }
 }  // namespace

@@ -370,6 +370,24 @@ static void build_manifest(q3_model* m) {
 }
 
 static q3_status check_config(const q3_config& c) {
+    // config.json is untrusted input (u64 values cast to int32 by the parser): every dimension positive and bounded
+    // before any size is computed from it
+    const struct { const char* name; int v, lo, hi; } dims[] = {
+        {"text_vocab", c.text_vocab, 1, 1 << 22}, {"text_dim", c.text_dim, 32, 1 << 15}, {"hidden", c.hidden, 32, 1 << 15}, {"inter", c.inter, 32, 1 << 17},
+        {"n_layers", c.n_layers, 1, 256}, {"n_heads", c.n_heads, 1, 256}, {"n_kv_heads", c.n_kv_heads, 1, 256},
+        {"cp_hidden", c.cp_hidden, 32, 1 << 15}, {"cp_inter", c.cp_inter, 32, 1 << 17}, {"cp_layers", c.cp_layers, 1, 64},
+        {"cp_heads", c.cp_heads, 1, 256}, {"cp_kv_heads", c.cp_kv_heads, 1, 256}, {"cp_vocab", c.cp_vocab, 2, 4096},
+        {"dec_cb_dim", c.dec_cb_dim, 1, 256}, {"dec_q_dim", c.dec_q_dim, 1, 1 << 14}, {"dec_latent", c.dec_latent, 1, 1 << 14},
+        {"dec_hidden", c.dec_hidden, 1, 1 << 14}, {"dec_layers", c.dec_layers, 1, 64}, {"dec_heads", c.dec_heads, 1, 256},
+        {"dec_inter", c.dec_inter, 1, 1 << 16}, {"dec_cb_size", c.dec_cb_size, 2, 4096}, {"dec_dim", c.dec_dim, 16, 1 << 14},
+        {"dec_up_ratios[0]", c.dec_up_ratios[0], 1, 16}, {"dec_up_ratios[1]", c.dec_up_ratios[1], 1, 16},
+        {"dec_up_rates[0]", c.dec_up_rates[0], 1, 32}, {"dec_up_rates[1]", c.dec_up_rates[1], 1, 32},
+        {"dec_up_rates[2]", c.dec_up_rates[2], 1, 32}, {"dec_up_rates[3]", c.dec_up_rates[3], 1, 32}};
+    for (const auto& d : dims)
+        if (d.v < d.lo || d.v > d.hi) return set_err(Q3_UNSUPPORTED, "config: %s = %d is outside [%d, %d]", d.name, d.v, d.lo, d.hi);
+    if (c.dec_dim % 16) return set_err(Q3_UNSUPPORTED, "config: dec_dim %d must be a multiple of 16 (four halvings)", c.dec_dim);
+    if (!(c.rms_eps > 0.0f) || !(c.dec_eps > 0.0f) || !(c.rope_theta > 1.0f) || !(c.dec_theta > 1.0f))
+        return set_err(Q3_UNSUPPORTED, "config: eps / rope theta out of range");
     if (c.head_dim != HEAD_DIM) return set_err(Q3_UNSUPPORTED, "head_dim %d unsupported (kernels are built for 128)", c.head_dim);
     if (c.dec_head_dim != 64) return set_err(Q3_UNSUPPORTED, "decoder head_dim %d unsupported (64)", c.dec_head_dim);
     if (c.hidden % 32 || c.inter % 32 || c.text_dim % 32 || c.cp_hidden % 32 || c.cp_inter % 32)
@@ -1123,6 +1141,8 @@ struct q3_session {
     float *kcache = nullptr, *vcache = nullptr, *ckcache = nullptr, *cvcache = nullptr;
     size_t kv_layer_stride = 0, ckv_layer_stride = 0;
     float *rows = nullptr, *embeds = nullptr, *xvec = nullptr; int n_rows_total = 0;
+    // prefill scratch, session-lifetime (no hipMalloc / hipFree and no extra stream syncs on the time-to-first-audio path)
+    uint32_t* ids_dev = nullptr; int *tr_dev = nullptr, *ci_dev = nullptr; float *proj_e = nullptr, *proj_h = nullptr;
     uint32_t* ref_codes_dev = nullptr;
     int *trail_base = nullptr, *trail_len = nullptr, *pad_row = nullptr;
     uint32_t* tok = nullptr; uint8_t* seen = nullptr; int *frame_idx = nullptr, *pos = nullptr, *token_count = nullptr;
@@ -1146,6 +1166,7 @@ struct q3_session {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
     std::vector<hipEvent_t> prof_pool; size_t prof_pool_next = 0;
     std::vector<ProfShape> prof_shapes;
+    ~q3_session();
 };
 
 static hipError_t run_linear(q3_session* s, const LinArgs& a) {
@@ -1404,14 +1425,18 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
             return set_err(Q3_INVALID_ARG, "speaker/language id out of range");
         if (r.xvector) q.xvec.assign(r.xvector, r.xvector + c.hidden);
         q.icl = r.mode == Q3_MODE_VOICE_CLONE && r.n_ref > 0 && r.ref_codes && r.ref_text_ids;
-        if (q.icl) {
-            if (r.n_ref_text < 0) return set_err(Q3_INVALID_ARG, "bad reference text");
+        if (r.mode == Q3_MODE_VOICE_CLONE && r.n_ref > 0 && r.ref_codes) {
+            // reference frames are prepended at decode whenever the prompt carries them — also without a reference
+            // transcript, when the prefill stays x-vector-only (lib.rs:1022: `if let Some(ref_codes) = &prompt.ref_codes`)
             q.ref_codes.assign(r.ref_codes, r.ref_codes + (size_t)r.n_ref * 16);
-            q.ref_text.assign(r.ref_text_ids, r.ref_text_ids + r.n_ref_text);
             for (int f = 0; f < r.n_ref; ++f) {
                 if (q.ref_codes[(size_t)f * 16] >= (uint32_t)c.codec_vocab) return set_err(Q3_INVALID_ARG, "reference semantic code out of range");
                 for (int g = 1; g < 16; ++g) if (q.ref_codes[(size_t)f * 16 + g] >= (uint32_t)c.cp_vocab) return set_err(Q3_INVALID_ARG, "reference acoustic code out of range");
             }
+        }
+        if (q.icl) {
+            if (r.n_ref_text < 0) return set_err(Q3_INVALID_ARG, "bad reference text");
+            q.ref_text.assign(r.ref_text_ids, r.ref_text_ids + r.n_ref_text);
             for (uint32_t id : q.ref_text) if (id >= (uint32_t)c.text_vocab) return set_err(Q3_INVALID_ARG, "reference text id %u out of range", id);
             // lib.rs:913-929 (must be identical for every sequence of the batch, checked below through s->opts)
             q.req.opts.repetition_penalty = r.opts.repetition_penalty < 1.5 ? 1.5 : r.opts.repetition_penalty;
@@ -1482,6 +1507,8 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     HIPC(s->pool.alloc(&s->rows, (size_t)rows * H));
     HIPC(s->pool.alloc(&s->embeds, (size_t)B * s->prefill_len * H));
     HIPC(s->pool.alloc(&s->xvec, (size_t)B * H));
+    HIPC(s->pool.alloc(&s->ids_dev, (size_t)rows)); HIPC(s->pool.alloc(&s->tr_dev, (size_t)B * s->prefill_len)); HIPC(s->pool.alloc(&s->ci_dev, (size_t)B * s->prefill_len));
+    HIPC(s->pool.alloc(&s->proj_e, (size_t)rows * c.text_dim)); HIPC(s->pool.alloc(&s->proj_h, (size_t)rows * c.text_dim));
     HIPC(s->pool.alloc(&s->trail_base, B)); HIPC(s->pool.alloc(&s->trail_len, B)); HIPC(s->pool.alloc(&s->pad_row, B));
     HIPC(s->pool.alloc(&s->tok, B)); HIPC(s->pool.alloc(&s->seen, (size_t)B * c.codec_vocab));
     HIPC(s->pool.alloc(&s->frame_idx, B)); HIPC(s->pool.alloc(&s->pos, B)); HIPC(s->pool.alloc(&s->token_count, B));
@@ -1502,22 +1529,28 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     return Q3_OK;
 }
 
-extern "C" void q3_session_free(q3_session* s) {
-    if (!s) return;
-    hipSetDevice(s->m->device);
-    if (s->stream) hipStreamSynchronize(s->stream);
-    if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
-    if (s->graph) hipGraphDestroy(s->graph);
-    for (auto& ev : s->prof_pool) hipEventDestroy(ev);
-    for (auto st : s->par_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
-    s->cws.release(); s->seg_ws.release();
-    for (auto& w : s->par_ws) w.release();
-    if (s->pcm_all) dev_free(s->pcm_all);
-    if (s->dec_ev) hipEventDestroy(s->dec_ev);
-    if (s->dec_stream) hipStreamDestroy(s->dec_stream);
-    if (s->stream) hipStreamDestroy(s->stream);
-    delete s;
+// Every exit path (q3_session_free, a failed q3_session_create) goes through here: streams are drained BEFORE the pool's
+// blocks return to the device cache (member destructors run after this body), so no later session is handed memory a
+// queued kernel still writes.
+q3_session::~q3_session() {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (dec_stream) (void)hipStreamSynchronize(dec_stream);
+    for (auto st : par_streams) (void)hipStreamSynchronize(st);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    for (auto& ev : prof_pool) (void)hipEventDestroy(ev);
+    for (auto st : par_streams) (void)hipStreamDestroy(st);
+    cws.release(); seg_ws.release();
+    for (auto& w : par_ws) w.release();
+    if (pcm_all) dev_free(pcm_all);
+    if (dec_ev) (void)hipEventDestroy(dec_ev);
+    if (dec_stream) (void)hipStreamDestroy(dec_stream);
+    if (stream) (void)hipStreamDestroy(stream);
 }
+
+extern "C" void q3_session_free(q3_session* s) { delete s; }
 
 extern "C" q3_status q3_session_set_debug(q3_session* s, int capture) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
@@ -1552,8 +1585,8 @@ extern "C" q3_status q3_session_prefill_len(q3_session* s, int b, int* prefill_l
 static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, float* out_rows) {
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     const int TD = c.text_dim, H = c.hidden;
-    float *e = nullptr, *h = nullptr;
-    HIPC(hipMalloc((void**)&e, (size_t)n * TD * 4)); HIPC(hipMalloc((void**)&h, (size_t)n * TD * 4));
+    if (n > s->n_rows_total) return set_err(Q3_INVALID_ARG, "text_project: %d rows exceed the session's %d", n, s->n_rows_total);
+    float *e = s->proj_e, *h = s->proj_h;      // session scratch: everything below is queued on s->stream, nothing waits
     q3_status st = Q3_OK;
     hipError_t er = launch_gather_rows_bf16(m->text_emb, ids_dev, e, n, TD, s->stream);
     if (er == hipSuccess && n >= 48 && TD % 64 == 0 && H % 64 == 0 && !s->no_chunk) {
@@ -1577,9 +1610,7 @@ static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, flo
         b2.N = H; b2.K = TD; set_w(b2, m->fc2w, M, H, TD); b2.x = h + (size_t)r0 * TD; b2.ldx = TD; b2.bias = m->fc2b; b2.y = out_rows + (size_t)r0 * H; b2.ldy = H; b2.M = M; b2.epi = EPI_NONE;
         er = launch_linear(b2, s->stream);
     }
-    if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
     if (er != hipSuccess) st = set_err(Q3_HIP_ERROR, "text projection: %s", hipGetErrorString(er));
-    hipFree(e); hipFree(h);
     return st;
 }
 
@@ -1597,7 +1628,8 @@ static q3_status prefill_gemm(q3_session* s, int S) {
     static const int rows_env = [] { const char* e = getenv("Q3_PREFILL_ROWS"); return e ? atoi(e) : 4224; }();
     int C = rows_env / B; C = C < 128 ? 128 : (C / 128) * 128;
     const int max_rows = B * (S < C ? S : C);
-    DevPool tmp;
+    struct SyncedPool : DevPool { hipStream_t st; explicit SyncedPool(hipStream_t s_) : st(s_) {} ~SyncedPool() { (void)hipStreamSynchronize(st); } };
+    SyncedPool tmp(s->stream);       // on EVERY return path the stream is drained before the blocks go back to the cache
     float *X, *QKV, *Qb, *ATT, *SUM, *ACT, *DEN;
     HIPC(tmp.alloc(&X, (size_t)max_rows * H)); HIPC(tmp.alloc(&QKV, (size_t)max_rows * (QD + 2 * KD)));
     HIPC(tmp.alloc(&Qb, (size_t)max_rows * QD)); HIPC(tmp.alloc(&ATT, (size_t)max_rows * QD));
@@ -1715,7 +1747,8 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
         }
         if (!q.xvec.empty()) memcpy(&xv[(size_t)b * H], q.xvec.data(), (size_t)H * 4);
     }
-    uint32_t* ids_dev = nullptr; int *tr_dev = nullptr, *ci_dev = nullptr;
+    uint32_t* ids_dev = s->ids_dev; int *tr_dev = s->tr_dev, *ci_dev = s->ci_dev;
+    if ((int)ids.size() != s->n_rows_total) return set_err(Q3_INVALID_ARG, "prefill: row count mismatch (%zu vs %d)", ids.size(), s->n_rows_total);
     // reference frames of ICL sequences (also needed later by the ICL decode)
     std::vector<size_t> ref_off(B, 0); size_t ref_total = 0;
     for (int b = 0; b < B; ++b) { ref_off[b] = ref_total; ref_total += s->seq[b].ref_codes.size(); }
@@ -1725,15 +1758,14 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
             if (!s->seq[b].ref_codes.empty())
                 HIPC(hipMemcpy(s->ref_codes_dev + ref_off[b], s->seq[b].ref_codes.data(), s->seq[b].ref_codes.size() * 4, hipMemcpyHostToDevice));
     }
-    HIPC(hipMalloc((void**)&ids_dev, ids.size() * 4));
-    HIPC(hipMalloc((void**)&tr_dev, text_row.size() * 4)); HIPC(hipMalloc((void**)&ci_dev, codec_id.size() * 4));
-    HIPC(hipMemcpy(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(tr_dev, text_row.data(), text_row.size() * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(ci_dev, codec_id.data(), codec_id.size() * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(s->xvec, xv.data(), xv.size() * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(s->trail_base, trail_base.data(), B * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(s->trail_len, trail_len.data(), B * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(s->pad_row, pad_row.data(), B * 4, hipMemcpyHostToDevice));
+    // uploads ride the session stream (the host vectors live until the synchronisation that ends this function)
+    HIPC(hipMemcpyAsync(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(tr_dev, text_row.data(), text_row.size() * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(ci_dev, codec_id.data(), codec_id.size() * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->xvec, xv.data(), xv.size() * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->trail_base, trail_base.data(), B * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->trail_len, trail_len.data(), B * 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->pad_row, pad_row.data(), B * 4, hipMemcpyHostToDevice, s->stream));
     q3_status st = text_project(s, ids_dev, (int)ids.size(), s->rows);
     if (st == Q3_OK) {
         hipError_t e = hipSuccess;
@@ -1741,11 +1773,9 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
             e = launch_assemble_rows(s->rows, tr_dev + (size_t)b * S, m->codec_emb, ci_dev + (size_t)b * S, s->xvec + (size_t)b * H,
                                      s->embeds + (size_t)b * S * H, S, H, s->stream,
                                      s->ref_codes_dev ? s->ref_codes_dev + ref_off[b] : nullptr, m->cp_embs_dev);
-        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
         if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "prefill assembly: %s", hipGetErrorString(e));
     }
-    hipFree(ids_dev); hipFree(tr_dev); hipFree(ci_dev);
-    Q3C(st);
+    if (st != Q3_OK) { (void)hipStreamSynchronize(s->stream); return st; }
     // 2. run_prefill_layers (talker.rs:823-841): causal attention ⇒ token-by-token decode steps
     //    and the GEMV kernels take up to 16 rows for the price of one, so each weight pass carries a CHUNK of
     //    16/B consecutive positions per sequence (q3_kernels.h AttnArgs::rows_per_seq). Bit-identical to the
@@ -1767,7 +1797,6 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     HIPC(hipMemcpyAsync(s->pos, posv.data(), B * 4, hipMemcpyHostToDevice, s->stream));
     HIPC(hipMemcpyAsync(s->frame_idx, zero.data(), B * 4, hipMemcpyHostToDevice, s->stream));
     HIPC(hipMemcpyAsync(s->token_count, zero.data(), B * 4, hipMemcpyHostToDevice, s->stream));
-    HIPC(hipStreamSynchronize(s->stream));
     SampleArgs a; fill_sample_args(s, a); a.advance = 0;
     HIPC(launch_sample(a, s->stream));
     HIPC(hipStreamSynchronize(s->stream));
@@ -1888,7 +1917,7 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
     if (f0 < 0 || f1 < f0 || f1 > s->seq[b].n_frames) return set_err(Q3_INVALID_ARG, "bad frame range [%d,%d) of %d", f0, f1, s->seq[b].n_frames);
     const int T = f1 - f0, spf = samples_per_frame(s->m->cfg);
     const SeqInfo& q = s->seq[b];
-    if (q.icl && f0 == 0 && f1 == q.n_frames) {
+    if (!q.ref_codes.empty() && f0 == 0 && f1 == q.n_frames) {
         // ICL full-utterance decode (lib.rs:1022-1041): decode [ref_frames ; generated], then cut the first
         // ref_len * samples / total_frames samples
         const int n_ref = (int)(q.ref_codes.size() / 16), total = n_ref + T;
@@ -1937,7 +1966,7 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
     const int overlap_env = [] { const char* e = getenv("Q3_DECODE_OVERLAP"); return e ? atoi(e) : 0; }();     // read per call: opt-in, tests set it per test
     static const int seg_env = [] { const char* e = getenv("Q3_DECODE_SEG"); const int v = e ? atoi(e) : 128; return v < 16 ? 16 : v; }();
     bool overlap = overlap_env != 0 && !s->debug && !s->profile && s->max_frames > seg_env;
-    for (auto& q : s->seq) if (q.icl) overlap = false;
+    for (auto& q : s->seq) if (!q.ref_codes.empty()) overlap = false;
     const int spf = samples_per_frame(s->m->cfg);
     if (!overlap) {
         Q3C(q3_session_generate(s, s->max_frames, use_graph));
@@ -1949,7 +1978,7 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
         // and fills in beside the other utterance's convolutions. Q3_DECODE_PAIRS=n: n at a time (1 = serial; A/B aid).
         static const int conc = [] { const char* e = getenv("Q3_DECODE_PAIRS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
         bool any_icl = false;
-        for (auto& q : s->seq) any_icl = any_icl || q.icl;
+        for (auto& q : s->seq) any_icl = any_icl || !q.ref_codes.empty();
         if (conc > 1 && s->B > 1 && !any_icl) {
             while ((int)s->par_ws.size() < conc - 1) {
                 s->par_ws.emplace_back();
@@ -2198,13 +2227,16 @@ extern "C" q3_status q3_talker_step(q3_session* s, const float* embeds_host, flo
     if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
     const q3_config& c = s->m->cfg;
     HIPC(hipSetDevice(s->m->device));
-    HIPC(hipMemcpyAsync(s->tb.X, embeds_host, (size_t)s->B * c.hidden * 4, hipMemcpyHostToDevice, s->stream));
-    Q3C(talker_step(s, s->pos, 0, true));
-    // advance positions by one (host-driven teacher forcing)
+    // the step writes K/V at `pos`: refuse BEFORE running when that slot does not exist (a step at pos == max_seq - 1 is valid)
     std::vector<int> posv(s->B);
     HIPC(hipStreamSynchronize(s->stream));
     HIPC(hipMemcpy(posv.data(), s->pos, s->B * 4, hipMemcpyDeviceToHost));
-    for (int& p : posv) { p += 1; if (p >= s->max_seq) return set_err(Q3_KV_OVERFLOW, "KV cache full (%d)", s->max_seq); }
+    for (int p : posv) if (p >= s->max_seq) return set_err(Q3_KV_OVERFLOW, "KV cache full (%d)", s->max_seq);
+    HIPC(hipMemcpyAsync(s->tb.X, embeds_host, (size_t)s->B * c.hidden * 4, hipMemcpyHostToDevice, s->stream));
+    Q3C(talker_step(s, s->pos, 0, true));
+    // advance positions by one (host-driven teacher forcing)
+    HIPC(hipStreamSynchronize(s->stream));
+    for (int& p : posv) p += 1;
     HIPC(hipMemcpy(s->pos, posv.data(), s->B * 4, hipMemcpyHostToDevice));
     if (hidden_host) HIPC(hipMemcpy(hidden_host, s->LASTH, (size_t)s->B * c.hidden * 4, hipMemcpyDeviceToHost));
     if (logits_host) HIPC(hipMemcpy(logits_host, s->LOGITS, (size_t)s->B * c.codec_vocab * 4, hipMemcpyDeviceToHost));

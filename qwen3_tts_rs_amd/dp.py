@@ -104,16 +104,25 @@ class NativeComm:
         return buf.raw
 
     @classmethod
-    def from_file(cls, path: str, rank: int, world: int, device: int, timeout_s: float = 120.0) -> "NativeComm":
+    def from_file(cls, path: str, rank: int, world: int, device: int, timeout_s: float = 120.0, nonce: str = "") -> "NativeComm":
+        """Rendezvous through a file: rank 0 publishes the RCCL id, the others read it. The file name carries a job nonce
+        (pass the same `nonce` on every rank: the launcher's job id / master port; default: MASTER_PORT or TORCHELASTIC_RUN_ID
+        from the environment) so that an id left behind by an earlier job, or read before rank 0 has rewritten it, can
+        never be mistaken for this job's — a mismatched id makes ncclCommInitRank hang until its timeout."""
         import time
+        nonce = nonce or os.environ.get("TORCHELASTIC_RUN_ID", "") + os.environ.get("MASTER_PORT", "")
+        path = f"{path}.{nonce}" if nonce else path
         if rank == 0:
+            if os.path.exists(path):
+                os.unlink(path)          # never leave a stale id visible while the new one is being written
             uid = cls.unique_id()
             with open(path + ".tmp", "wb") as f:
                 f.write(uid)
             os.replace(path + ".tmp", path)
         else:
             t0 = time.time()
-            while not (os.path.exists(path) and os.path.getsize(path) == 128):
+            started = t0 - 5.0           # an id older than this rank's start (minus clock slack) belongs to an earlier job
+            while not (os.path.exists(path) and os.path.getsize(path) == 128 and (nonce or os.path.getmtime(path) >= started)):
                 if time.time() - t0 > timeout_s:
                     raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s}s")
                 time.sleep(0.01)

@@ -778,6 +778,26 @@ def test_synthesize_batch_groups_by_prefill_shape(pair):
 
 
 @pytest.mark.gpu
+def test_ref_codes_without_transcript_are_prepended_at_decode(pair):
+    """A voice-clone prompt that carries reference frames but no transcript keeps the x-vector-only prefill, yet the decode
+    still runs over [reference frames ; generated] and cuts the reference's share (lib.rs:1022-1041)."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(8)
+    ref = rng.integers(0, 2048, size=(5, 16)).astype(np.uint32); ref[:, 0] = rng.integers(0, 3072, 5)
+    xv = rng.standard_normal(cfg.hidden).astype(np.float32)
+    opts = q.SynthesisOptions(max_length=9, seed=3, eos_token_id=None)
+    plain = q.Utterance(synthetic_prompt(6, 1), language=q.Language.French, xvector=xv, seed=3)
+    withref = q.Utterance(synthetic_prompt(6, 1), language=q.Language.French, xvector=xv, ref_codes=ref, seed=3)
+    s0 = gm.session([plain], opts); s0.prefill(); s0.generate(9); c0 = s0.codes(0); s0.close()
+    s1 = gm.session([withref], opts); s1.prefill(); s1.generate(9); c1 = s1.codes(0); pcm = s1.decode(0); s1.close()
+    np.testing.assert_array_equal(c0, c1)                        # same prefill, same codes (no ICL block)
+    full = om.decode(np.concatenate([ref, c1]))
+    cut = 5 * len(full) // 14
+    assert pcm.shape == (len(full) - cut,)
+    assert float(np.sqrt(np.mean((pcm - full[cut:]) ** 2))) <= 1e-3
+
+
+@pytest.mark.gpu
 def test_synthesize_batch_icl_requests_with_different_text_lengths(pair):
     """Two ICL voice-clone requests with the same reference but different text lengths resolve to different max_length
     caps (max(75, 6 * n_text), lib.rs:913-929): synthesize_batch must serve them in separate sessions, not fail."""
