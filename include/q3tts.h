@@ -305,8 +305,7 @@ q3_status q3_resample(const float* in_host, int64_t n, uint32_t sr_in, uint32_t 
  * reference audio -> log-mel (audio/mel.rs:47-59, 135-227) -> ECAPA-TDNN -> [enc_dim] embedding, the `xvector`
  * of q3_request. Config = SpeakerEncoderConfig (models/config.rs:100-174), weights = `speaker_encoder.*` of a
  * Base checkpoint's model.safetensors (kept f32 on the device; bf16/f16 sources are widened on upload).
- * The ICL half of the prompt (reference codes) needs the Mimi speech encoder, which lives in candle-transformers
- * (encoder_12hz.rs:23) — not part of this library: pass ref_codes produced elsewhere. */
+ * The ICL half of the prompt (reference codes) comes from the speech encoder below (q3_mimi_*). */
 typedef struct q3_spk_config {
     int32_t mel_dim;            /* 128 */
     int32_t enc_dim;            /* 1024 (0.6B) / 2048 (1.7B): the talker's hidden size */
@@ -347,6 +346,55 @@ q3_status q3_spk_forward(q3_speaker_encoder* e, const float* mel_host, int T, fl
 /* SpeakerEncoder::encode (speaker.rs:431-438) = mel + forward; sample_rate must be 24000 (the reference resamples
  * first, lib.rs:1156-1166 — q3_resample before calling) */
 q3_status q3_spk_encode(q3_speaker_encoder* e, const float* samples_host, int64_t n, uint32_t sample_rate, float* out_host);
+
+/* ---------------- speech-tokenizer encoder (q3_mimi.hip): ICL reference codes from raw audio ----------------
+ * Encoder12Hz (models/codec/encoder_12hz.rs:34-144) behind create_voice_clone_prompt's ICL branch (lib.rs:1172-1178):
+ * 24 kHz mono reference audio -> SEANet encoder -> 8-layer transformer -> stride-2 conv -> split residual VQ ->
+ * frames of 16 codebook indices at 12.5 Hz, the `ref_codes` of q3_request. The reference instantiates candle-transformers'
+ * Mimi (`mimi::Config::v0_1(Some(16))`, encoder_12hz.rs:73) over the HF-format `encoder.*` keys of
+ * speech_tokenizer/model.safetensors; this is the published Mimi encoder for that format (weights kept f32 on the device). */
+typedef struct q3_mimi_config {
+    int32_t n_filters;      /* 64   SEANet base width */
+    int32_t hidden;         /* 512  SEANet output / transformer width */
+    int32_t ratios[4];      /* 4, 5, 6, 8: strides of the four down-sampling stages, in encoder order (24 kHz -> 25 Hz) */
+    int32_t kernel;         /* 7 */
+    int32_t res_kernel;     /* 3 */
+    int32_t last_kernel;    /* 3 */
+    int32_t compress;       /* 2 */
+    int32_t n_layers;       /* 8 */
+    int32_t n_heads;        /* 8 */
+    int32_t head_dim;       /* 64 */
+    int32_t inter;          /* 2048 */
+    int32_t window;         /* 250: causal attention context in frames */
+    int32_t cb_size;        /* 2048 */
+    int32_t cb_dim;         /* 256 */
+    int32_t n_q;            /* 16 codebooks: */
+    int32_t n_sem;          /* 1 semantic + 15 acoustic */
+    float norm_eps;         /* 1e-5 */
+    float rope_theta;       /* 1e4 */
+} q3_mimi_config;
+typedef struct q3_speech_encoder q3_speech_encoder;
+/* mimi::Config::v0_1(Some(16)) (encoder_12hz.rs:73) */
+q3_status q3_mimi_config_default(q3_mimi_config* out);
+/* Encoder12Hz::from_weights (encoder_12hz.rs:54-117): allocates the weight arena for the config's tensor manifest; device -1 = manifest only */
+q3_status q3_mimi_create(const q3_mimi_config* cfg, int device, q3_speech_encoder** out);
+void q3_mimi_free(q3_speech_encoder* e);
+q3_status q3_mimi_get_config(const q3_speech_encoder* e, q3_mimi_config* out);
+int q3_mimi_n_tensors(const q3_speech_encoder* e);
+q3_status q3_mimi_tensor_info(const q3_speech_encoder* e, int i, const char** name, int64_t* n);
+/* data_host: n elements of src_dtype (Q3_DTYPE_F32 / Q3_DTYPE_BF16), checkpoint layout (the strided convs are re-laid on upload) */
+q3_status q3_mimi_set_tensor(q3_speech_encoder* e, const char* name, const void* data_host, int src_dtype, int64_t n);
+q3_status q3_mimi_finalize(q3_speech_encoder* e);
+/* Encoder12Hz::from_safetensors (encoder_12hz.rs:45-48): every `encoder.*` tensor of speech_tokenizer/model.safetensors, then
+ * finalize; Q3_MISSING_WEIGHT "No encoder keys found …" (encoder_12hz.rs:68-70) when the file has none */
+q3_status q3_mimi_load_safetensors(q3_speech_encoder* e, const char* path);
+/* frames for n samples: ceil over the four strides, then ceil(/2) */
+int q3_mimi_frames(const q3_mimi_config* cfg, int64_t n_samples);
+/* Encoder12Hz::encode (encoder_12hz.rs:119-144): codes_host [T][n_q] u32 (frame-major, like q3_request.ref_codes);
+ * codes_host == NULL: only *n_frames. sample_rate must be 24000 (q3_resample first). taps_host (test hook): NULL or 3 host
+ * pointers (NULL entries skipped): SEANet out [hidden][T25], transformer out [hidden][T25], down-sampled [hidden][T] */
+q3_status q3_mimi_encode(q3_speech_encoder* e, const float* samples_host, int64_t n, uint32_t sample_rate, uint32_t* codes_host,
+                         int cap_frames, int* n_frames, float** taps_host);
 
 /* ---------------- data parallelism without torch.distributed (q3_dp.cpp) ----------------
  * one process per GPU, utterance i -> rank i mod N, exactly one collective on the data path — the

@@ -184,6 +184,38 @@ void q3o_reflect_pad_1d(const float* x, int C, int T, int pl, int pr, float* out
 int q3o_spk_forward(q3o_spk* s, const float* mel /*[mel_dim][T]*/, int T, float* out /*[enc_dim]*/, float** taps);
 int q3o_spk_encode(q3o_spk* s, const float* samples, int n, float* out);
 
+/* ---- speech-tokenizer encoder (q3_oracle_mimi.c): encoder_12hz.rs:34-144 over candle-transformers' Mimi = the published
+ * Mimi encoder (HF transformers models/mimi/modeling_mimi.py) ---- */
+typedef struct q3o_mimi_config {
+    int32_t n_filters;      /* 64 */
+    int32_t hidden;         /* 512 */
+    int32_t ratios[4];      /* encoder order: 4, 5, 6, 8 */
+    int32_t kernel;         /* 7 */
+    int32_t res_kernel;     /* 3 */
+    int32_t last_kernel;    /* 3 */
+    int32_t compress;       /* 2 */
+    int32_t n_layers;       /* 8 */
+    int32_t n_heads;        /* 8 */
+    int32_t head_dim;       /* 64 */
+    int32_t inter;          /* 2048 */
+    int32_t window;         /* 250 */
+    int32_t cb_size;        /* 2048 */
+    int32_t cb_dim;         /* 256 */
+    int32_t n_q;            /* 16 */
+    int32_t n_sem;          /* 1 */
+    float norm_eps;         /* 1e-5 */
+    float rope_theta;       /* 1e4 */
+} q3o_mimi_config;
+typedef struct q3o_mimi q3o_mimi;
+q3o_mimi* q3o_mimi_new(const q3o_mimi_config* cfg);
+void q3o_mimi_free(q3o_mimi* m);
+const char* q3o_mimi_last_error(const q3o_mimi* m);
+int q3o_mimi_set_tensor(q3o_mimi* m, const char* name, const float* data, int64_t n);     /* names as in speech_tokenizer/model.safetensors ("encoder.…") */
+int q3o_mimi_frames(const q3o_mimi_config* cfg, int64_t n_samples);
+/* codes [T][n_q]; taps NULL or 4 pointers (NULL entries skipped): SEANet out [hidden][T25], transformer out [hidden][T25], downsampled
+ * [hidden][T], per-decision squared-distance margins [T][n_q] */
+int q3o_mimi_encode(q3o_mimi* m, const float* samples, int64_t n, uint32_t* codes, float** taps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,14 @@ class CSpkConfig(ctypes.Structure):      # q3_spk_config (SpeakerEncoderConfig, 
                 ("res2net_scale", ctypes.c_int32), ("se_channels", ctypes.c_int32), ("sample_rate", ctypes.c_int32)]
 
 
+class CMimiConfig(ctypes.Structure):     # q3_mimi_config (mimi::Config::v0_1(Some(16)), encoder_12hz.rs:73)
+    _fields_ = [("n_filters", ctypes.c_int32), ("hidden", ctypes.c_int32), ("ratios", ctypes.c_int32 * 4), ("kernel", ctypes.c_int32),
+                ("res_kernel", ctypes.c_int32), ("last_kernel", ctypes.c_int32), ("compress", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+                ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("inter", ctypes.c_int32), ("window", ctypes.c_int32),
+                ("cb_size", ctypes.c_int32), ("cb_dim", ctypes.c_int32), ("n_q", ctypes.c_int32), ("n_sem", ctypes.c_int32),
+                ("norm_eps", ctypes.c_float), ("rope_theta", ctypes.c_float)]
+
+
 class CTiming(ctypes.Structure):
     _fields_ = [("prefill_ms", ctypes.c_double), ("generation_ms", ctypes.c_double), ("decode_ms", ctypes.c_double),
                 ("generation_frames", ctypes.c_int32)]
@@ -128,6 +136,17 @@ SYMBOLS = {
     "q3_spk_mel": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, P(c_int)]),
     "q3_spk_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, P(c_void_p)]),
     "q3_spk_encode": (c_int, [c_void_p, c_void_p, ctypes.c_int64, ctypes.c_uint32, c_void_p]),
+    "q3_mimi_config_default": (c_int, [P(CMimiConfig)]),
+    "q3_mimi_create": (c_int, [P(CMimiConfig), c_int, P(c_void_p)]),
+    "q3_mimi_free": (None, [c_void_p]),
+    "q3_mimi_get_config": (c_int, [c_void_p, P(CMimiConfig)]),
+    "q3_mimi_n_tensors": (c_int, [c_void_p]),
+    "q3_mimi_tensor_info": (c_int, [c_void_p, c_int, P(c_char_p), P(ctypes.c_int64)]),
+    "q3_mimi_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int, ctypes.c_int64]),
+    "q3_mimi_finalize": (c_int, [c_void_p]),
+    "q3_mimi_load_safetensors": (c_int, [c_void_p, c_char_p]),
+    "q3_mimi_frames": (c_int, [P(CMimiConfig), ctypes.c_int64]),
+    "q3_mimi_encode": (c_int, [c_void_p, c_void_p, ctypes.c_int64, ctypes.c_uint32, c_void_p, c_int, P(c_int), P(c_void_p)]),
 }
 
 for _name, (_res, _args) in SYMBOLS.items():

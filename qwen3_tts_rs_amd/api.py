@@ -381,6 +381,14 @@ class Qwen3TTS:
             cfg_path = os.path.join(str(model_dir), "config.json")
             scfg = SpeakerEncoderConfig.from_json(cfg_path)[0] if os.path.exists(cfg_path) else SpeakerEncoderConfig(enc_dim=m.config.hidden)
             m.attach_speaker_encoder(SpeakerEncoder.from_safetensors(st, scfg, device))
+        # the speech tokenizer file carries the Mimi encoder under `encoder.*` (lib.rs:251-258, encoder_12hz.rs:54-71)
+        from .speech_encoder import SpeechEncoder
+        tok = os.path.join(str(model_dir), "speech_tokenizer", "model.safetensors")
+        if not os.path.exists(tok):
+            tok = os.path.join(os.path.dirname(os.path.abspath(str(model_dir))), "speech_tokenizer", "model.safetensors")
+        if device >= 0 and os.path.exists(tok) and \
+                lib.q3_safetensors_info(tok.encode(), b"encoder.downsample.conv.weight", ctypes.byref(probe), None, 0, None) == 0:
+            m.attach_speech_encoder(SpeechEncoder.from_safetensors(tok, None, device))
         return m
 
     # ---- voice cloning front end (lib.rs:1049-1190) ----
@@ -397,13 +405,18 @@ class Qwen3TTS:
     def has_speaker_encoder(self) -> bool:
         return self.speaker_encoder is not None
 
-    def has_speech_encoder(self) -> bool:              # lib.rs:1049-1051 — the Mimi encoder is not part of this library
-        return False
+    speech_encoder = None        # SpeechEncoder (Mimi), attached by from_pretrained when speech_tokenizer/model.safetensors has encoder.* keys
+
+    def attach_speech_encoder(self, enc):
+        self.speech_encoder = enc
+
+    def has_speech_encoder(self) -> bool:              # lib.rs:1049-1051
+        return self.speech_encoder is not None
 
     def create_voice_clone_prompt(self, ref_audio: "AudioBuffer", ref_text_ids=None, ref_codes=None):
-        """create_voice_clone_prompt (lib.rs:1132-1190). x_vector_only when `ref_text_ids` is None. The ICL variant needs
-        the reference audio's codec frames: the reference computes them with the Mimi encoder of candle-transformers
-        (encoder_12hz.rs:23), which this library does not contain — pass `ref_codes` computed elsewhere."""
+        """create_voice_clone_prompt (lib.rs:1132-1190). x_vector_only when `ref_text_ids` is None; with a transcript the
+        reference audio is also encoded to codec frames by the speech encoder (Encoder12Hz, encoder_12hz.rs:119-144) for
+        ICL. `ref_codes` (optional) overrides that encoder with frames computed elsewhere."""
         from .speaker import VoiceClonePrompt
         if self.speaker_encoder is None:
             hint = {ModelType.CustomVoice: " CustomVoice models use preset speakers (synthesize_with_voice), not voice cloning. "
@@ -418,8 +431,10 @@ class Qwen3TTS:
         if ref_text_ids is None:
             return VoiceClonePrompt(emb)
         if ref_codes is None:
-            raise _lib.Q3Error(7, "ICL voice cloning requires a speech encoder, but it was not loaded. Pass ref_codes, or use "
-                                  "x_vector_only mode by passing ref_text_ids=None.")
+            if self.speech_encoder is None:         # lib.rs:1172-1178
+                raise _lib.Q3Error(7, "ICL voice cloning requires a speech encoder, but it was not loaded. Ensure the speech tokenizer "
+                                      "weights contain encoder keys, or use x_vector_only mode by passing ref_text=None.")
+            ref_codes = self.speech_encoder.encode(ref_audio.samples, ref_audio.sample_rate)      # [T_frames, 16]
         return VoiceClonePrompt(emb, np.ascontiguousarray(ref_codes, dtype=np.uint32), np.asarray(ref_text_ids, dtype=np.uint32))
 
     def synthesize_voice_clone_prompt(self, text_ids, prompt, language: "Language", options=None):

@@ -4,8 +4,9 @@
 audio_seed{S}_frames{N}.bin f32 LE, metadata_seed{S}_frames{N}.json; generate_audio.rs:724-813).
 
 Differences, all explicit: `--synthetic {tiny,0.6b,1.7b}` runs without a checkpoint (seeded random weights — there is
-no network here); `--token-ids` / `--instruct-ids` bypass the tokenizer; `--ref-audio` needs the speaker / speech
-encoders, which stay on the Rust side — pass `--xvector-npy` / `--ref-codes-bin` instead."""
+no network here); `--token-ids` / `--instruct-ids` bypass the tokenizer; `--ref-audio` runs the speaker encoder (and, with
+`--ref-text`, the speech encoder for ICL) of a Base checkpoint on the GPU — `--xvector-npy` / `--ref-codes-bin` inject
+precomputed ones instead."""
 import argparse
 import json
 import os
@@ -81,10 +82,6 @@ def main(argv=None) -> int:
     if a.x_vector_only and a.ref_text:
         print("error: --x-vector-only and --ref-text are contradictory.\n  x_vector_only uses only the speaker embedding (no ICL).", file=sys.stderr)
         return 2
-    if a.ref_audio and a.ref_text and not a.ref_codes_bin:
-        print("error: ICL voice cloning (--ref-audio + --ref-text) needs the reference audio's codec frames; the Mimi speech encoder "
-              "is not part of this engine — pass --ref-codes-bin (codes_*.bin written by the reference), or use --x-vector-only", file=sys.stderr)
-        return 2
     dev = parse_device(a.device)
     speaker, language = q.Speaker.from_str(a.speaker), q.Language.from_str(a.language)
     frames = max_frames_from_args(a)
@@ -95,6 +92,8 @@ def main(argv=None) -> int:
         if a.ref_audio:      # a Base-style synthetic model: seeded ECAPA-TDNN of the matching embedding width
             scfg = q.tiny_speaker_config(cfg.hidden) if a.synthetic == "tiny" else q.SpeakerEncoderConfig(enc_dim=cfg.hidden)
             model.attach_speaker_encoder(q.SpeakerEncoder.from_synthetic(scfg, device=dev))
+            if a.ref_text and not a.ref_codes_bin:      # ICL from raw audio: seeded speech encoder (Mimi shapes)
+                model.attach_speech_encoder(q.SpeechEncoder.from_synthetic(q.tiny_speech_config() if a.synthetic == "tiny" else None, device=dev))
         tok = TextTokenizer.from_pretrained(None, a.tokenizer_dir, allow_stand_in=True)     # --synthetic: the labelled stand-in
     else:
         # a real checkpoint needs its real tokenizer (the reference fails to load without one, text.rs:62-110) unless every
@@ -123,7 +122,12 @@ def main(argv=None) -> int:
         print(f"Reference audio: {a.ref_audio} ({ref.duration():.2f}s, {ref.sample_rate} Hz)")
         print("Mode: ICL (reference codes + text)" if a.ref_text else "Mode: x_vector_only (no reference text)")
         try:
-            utt.xvector = model.create_voice_clone_prompt(ref).speaker_embedding
+            if a.ref_text and not a.ref_codes_bin and not a.x_vector_only:
+                # ICL from raw audio: speaker embedding + codec frames of the reference clip (lib.rs:1132-1190)
+                prompt = model.create_voice_clone_prompt(ref, ref_text_ids=tok.encode(a.ref_text))
+                utt.xvector, utt.ref_codes, utt.ref_text_ids = prompt.speaker_embedding, prompt.ref_codes, prompt.ref_text_ids
+            else:
+                utt.xvector = model.create_voice_clone_prompt(ref).speaker_embedding
         except api._lib.Q3Error as e:
             print(f"error: {e}", file=sys.stderr)
             return 2

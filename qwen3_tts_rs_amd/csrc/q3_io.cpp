@@ -470,6 +470,40 @@ extern "C" q3_status q3_spk_load_safetensors(q3_speaker_encoder* enc, const char
     return q3_spk_finalize(enc);
 }
 
+// Encoder12Hz::from_safetensors (encoder_12hz.rs:45-48, 54-71): the `encoder.*` tensors of speech_tokenizer/model.safetensors
+extern "C" q3_status q3_mimi_load_safetensors(q3_speech_encoder* enc, const char* path) {
+    if (!enc || !path) return q3i_set_err(Q3_INVALID_ARG, "q3_mimi_load_safetensors: null argument");
+    StFile f; Q3I_CHECK(st_open(path, f));
+    bool any = false;
+    for (auto& kv : f.entries) if (kv.first.rfind("encoder.", 0) == 0) { any = true; break; }
+    if (!any) return q3i_set_err(Q3_MISSING_WEIGHT, "No encoder keys found (expected keys starting with 'encoder.')");
+    const int nt = q3_mimi_n_tensors(enc);
+    for (int i = 0; i < nt; ++i) {
+        const char* name; int64_t n_expect;
+        Q3I_CHECK(q3_mimi_tensor_info(enc, i, &name, &n_expect));
+        const StEntry* e = f.find(name);
+        if (!e) return q3i_set_err(Q3_MISSING_WEIGHT, "Missing weight: %s", name);
+        int64_t n = 1;
+        for (int64_t d : e->shape) n *= d;
+        const int es = dtype_size(e->dtype);
+        if (!es) return q3i_set_err(Q3_UNSUPPORTED, "%s: tensor %s has unsupported dtype %s", path, name, e->dtype.c_str());
+        if ((uint64_t)n * (uint64_t)es != e->e - e->b) return q3i_set_err(Q3_IO, "%s: tensor %s: shape does not match its byte range", path, name);
+        if (n != n_expect) return q3i_set_err(Q3_INVALID_ARG, "%s: tensor %s has %lld elements, expected %lld", path, name, (long long)n, (long long)n_expect);
+        const uint8_t* src = f.data + e->b;
+        if (e->dtype == "F32") { Q3I_CHECK(q3_mimi_set_tensor(enc, name, src, Q3_DTYPE_F32, n)); continue; }
+        if (e->dtype == "BF16") { Q3I_CHECK(q3_mimi_set_tensor(enc, name, src, Q3_DTYPE_BF16, n)); continue; }
+        std::vector<float> tmp((size_t)n);
+        if (e->dtype == "F16") {
+            const uint16_t* h = (const uint16_t*)src;
+            for (int64_t j = 0; j < n; ++j) tmp[(size_t)j] = f16_to_f32(h[j]);
+        } else {
+            for (int64_t j = 0; j < n; ++j) { double d; memcpy(&d, src + 8 * j, 8); tmp[(size_t)j] = (float)d; }
+        }
+        Q3I_CHECK(q3_mimi_set_tensor(enc, name, tmp.data(), Q3_DTYPE_F32, n));
+    }
+    return q3_mimi_finalize(enc);
+}
+
 // ------------------------------------------------------------------------------------------------
 // safetensors → model
 // ------------------------------------------------------------------------------------------------

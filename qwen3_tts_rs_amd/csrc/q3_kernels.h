@@ -157,7 +157,7 @@ struct ConvArgs {
     const float* snake_a = nullptr; const float* snake_b = nullptr;   // SnakeBeta applied to x on load
     const float* resid = nullptr;    // y += resid
     const float* scale = nullptr;    // y = resid + scale[c] * conv   (layer scale / gamma), needs resid
-    int act = 0;                     // 1 = GELU(erf), 2 = clamp(-1,1), 3 = ReLU, 4 = tanh(ReLU), 5 = sigmoid
+    int act = 0;                     // 1 = GELU(erf), 2 = clamp(-1,1), 3 = ReLU, 4 = tanh(ReLU), 5 = sigmoid, 6 = ELU
     const float* post_a = nullptr; const float* post_ib = nullptr;   // SnakeBeta of the CONSUMER applied to the output
     float* y2 = nullptr;             // if set: y = raw output, y2 = activated output; else y = activated output
     const void* wpk = nullptr;       // bf16x3-packed copy of w (launch_pack_conv_w) → bf16 matrix-core kernel; else f32 MFMA

@@ -42,12 +42,14 @@ __device__ __forceinline__ float snake_f(float x, float a, float ib) { return __
 constexpr int CV_CO = 32, CV_T = 128, CV_CI = 16, CV_MAXK = 7, CV_MAXHALO = 54;
 
 // epilogue activations: 1 GELU(erf) (ConvNeXt), 2 clamp (applied after the residual, see the kernels), and the speaker
-// encoder's (speaker.rs:53-61, 136-138, 327-329): 3 ReLU, 4 ReLU then tanh, 5 sigmoid = 1 / (exp(-x) + 1)
+// encoder's (speaker.rs:53-61, 136-138, 327-329): 3 ReLU, 4 ReLU then tanh, 5 sigmoid = 1 / (exp(-x) + 1); the speech
+// encoder's (Mimi SEANet): 6 ELU
 __device__ __forceinline__ float conv_act(float v, int act) {
     if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (act == 3) return fmaxf(v, 0.0f);
     if (act == 4) return tanhf(fmaxf(v, 0.0f));
     if (act == 5) return 1.0f / (expf(-v) + 1.0f);
+    if (act == 6) return v > 0.0f ? v : expf(v) - 1.0f;
     return v;
 }
 

@@ -188,7 +188,67 @@ def main():
 
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: v.shape for k, v in out.items()})
+    mimi_fixture()
+
+
+def test_clip(n, seed):
+    """deterministic speech-like test signal in [-0.6, 0.6]"""
+    t = np.arange(n) / 24000.0
+    rng = np.random.default_rng(seed)
+    x = 0.3 * np.sin(2 * np.pi * 180.0 * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 2.5 * t)) + 0.15 * np.sin(2 * np.pi * 1250.0 * t + 0.7) + \
+        0.05 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def mimi_fixture():
+    """ICL reference-audio encoder: the repo's seeded synthetic speech-encoder checkpoint loaded into HF's MimiModel
+    (transformers.models.mimi), stage taps + codes for a tiny and the full-size configuration."""
+    from qwen3_tts_rs_amd.speech_encoder import SpeechEncoder, SpeechEncoderConfig, tiny_speech_config, synthetic_speech_checkpoint
+    res = {}
+    for tag, scfg, n in (("tiny", tiny_speech_config(), 2000), ("full", SpeechEncoderConfig(), 30000)):
+        enc = SpeechEncoder(scfg, device=-1)
+        W = {name: torch.from_numpy(arr.copy()) for name, arr in synthetic_speech_checkpoint(enc, SEED)}
+        enc.close()
+        prod = int(np.prod(scfg.ratios))
+        mcfg = MimiConfig(sampling_rate=24000, frame_rate=24000 / prod / 2, audio_channels=1, hidden_size=scfg.hidden, num_filters=scfg.n_filters,
+                          num_residual_layers=1, upsampling_ratios=list(reversed(scfg.ratios)), kernel_size=scfg.kernel, last_kernel_size=scfg.last_kernel,
+                          residual_kernel_size=scfg.res_kernel, dilation_growth_rate=2, use_causal_conv=True, pad_mode="constant", compress=scfg.compress,
+                          codebook_size=scfg.cb_size, codebook_dim=scfg.cb_dim, vector_quantization_hidden_dimension=scfg.cb_dim,
+                          num_quantizers=scfg.n_q, num_semantic_quantizers=scfg.n_sem, num_hidden_layers=scfg.n_layers, intermediate_size=scfg.inter,
+                          num_attention_heads=scfg.n_heads, num_key_value_heads=scfg.n_heads, head_dim=scfg.head_dim, hidden_act="gelu",
+                          norm_eps=scfg.norm_eps, rope_theta=scfg.rope_theta, sliding_window=scfg.window, attention_bias=False, use_conv_shortcut=False,
+                          upsample_groups=scfg.hidden)
+        mcfg._attn_implementation = "eager"
+        mm = MM.MimiModel(mcfg).eval()
+        sd = mm.state_dict(); got = 0
+        for k in sd:
+            name = "encoder." + k
+            if name in W:
+                assert W[name].numel() == sd[k].numel(), (name, W[name].numel(), tuple(sd[k].shape))
+                sd[k] = W[name].reshape(sd[k].shape).clone(); got += 1
+        assert got == len(W), (got, len(W))
+        mm.load_state_dict(sd)
+        for m_ in mm.modules():
+            if isinstance(m_, MM.MimiEuclideanCodebook):
+                m_._embed = None
+        x = torch.from_numpy(test_clip(n, 7))[None, None]
+        emb = mm.encoder(x)
+        tr = mm.encoder_transformer(emb.transpose(1, 2))[0].transpose(1, 2)
+        ds = mm.downsample(tr)
+        codes = mm.quantizer.encode(ds, scfg.n_q)                                # [K][1][T]
+        codes2 = mm.encode(x, num_quantizers=scfg.n_q).audio_codes                # the public entry point agrees
+        assert torch.equal(codes[:, 0], codes2[0])
+        res[f"mimi_{tag}_n"] = np.array([n])
+        res[f"mimi_{tag}_seanet"] = emb[0].numpy(); res[f"mimi_{tag}_transformer"] = tr[0].numpy(); res[f"mimi_{tag}_downsample"] = ds[0].numpy()
+        res[f"mimi_{tag}_codes"] = codes[:, 0].transpose(0, 1).numpy().astype(np.uint32)        # [T][n_q]
+        print(tag, {k: v.shape for k, v in res.items() if tag in k})
+    path = os.path.join(os.path.dirname(OUT), "hf_mimi.npz")
+    np.savez_compressed(path, **res)
+    print("wrote", path)
 
 
 if __name__ == "__main__":
-    main()
+    if "mimi" in sys.argv[1:]:
+        mimi_fixture()
+    else:
+        main()

@@ -12,7 +12,7 @@ LIB = os.path.join(ORACLE_DIR, "libq3oracle.so")
 
 
 def build_oracle():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("q3_oracle.c", "q3_oracle_spk.c", "q3_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("q3_oracle.c", "q3_oracle_spk.c", "q3_oracle_mimi.c", "q3_oracle.h")]
     if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libq3oracle.so"], stdout=subprocess.DEVNULL)
 
@@ -362,3 +362,68 @@ class OracleSpeakerEncoder:
     def close(self):
         if self._h and olib is not None:
             olib.q3o_spk_free(self._h); self._h = None
+
+
+# ---- speech-tokenizer encoder (oracle/q3_oracle_mimi.c) ----
+class OMimiConfig(ctypes.Structure):
+    _fields_ = [("n_filters", ctypes.c_int32), ("hidden", ctypes.c_int32), ("ratios", ctypes.c_int32 * 4), ("kernel", ctypes.c_int32),
+                ("res_kernel", ctypes.c_int32), ("last_kernel", ctypes.c_int32), ("compress", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+                ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("inter", ctypes.c_int32), ("window", ctypes.c_int32),
+                ("cb_size", ctypes.c_int32), ("cb_dim", ctypes.c_int32), ("n_q", ctypes.c_int32), ("n_sem", ctypes.c_int32),
+                ("norm_eps", ctypes.c_float), ("rope_theta", ctypes.c_float)]
+
+
+olib.q3o_mimi_new.restype = vp; olib.q3o_mimi_new.argtypes = [ctypes.POINTER(OMimiConfig)]
+olib.q3o_mimi_free.argtypes = [vp]
+olib.q3o_mimi_last_error.restype = ctypes.c_char_p; olib.q3o_mimi_last_error.argtypes = [vp]
+olib.q3o_mimi_set_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_int64]
+olib.q3o_mimi_frames.argtypes = [ctypes.POINTER(OMimiConfig), ctypes.c_int64]
+olib.q3o_mimi_encode.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.POINTER(vp)]
+
+
+def to_omimi_config(cfg) -> OMimiConfig:
+    """cfg: qwen3_tts_rs_amd.SpeechEncoderConfig (same field names)"""
+    c = OMimiConfig()
+    for f, _ in OMimiConfig._fields_:
+        v = getattr(cfg, f)
+        if f == "ratios":
+            c.ratios = (ctypes.c_int32 * 4)(*v)
+        else:
+            setattr(c, f, v)
+    return c
+
+
+class OracleSpeechEncoder:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._c = to_omimi_config(cfg)
+        self._h = olib.q3o_mimi_new(ctypes.byref(self._c))
+
+    def set_tensor(self, name, arr):
+        a = np.ascontiguousarray(arr, np.float32)
+        assert olib.q3o_mimi_set_tensor(self._h, name.encode(), _fp(a), a.size) == 0
+
+    def frames(self, n_samples):
+        return olib.q3o_mimi_frames(ctypes.byref(self._c), n_samples)
+
+    def encode(self, samples, taps=False):
+        x = np.ascontiguousarray(samples, np.float32)
+        T = self.frames(x.size)
+        codes = np.zeros((T, self.cfg.n_q), np.uint32)
+        tl = None; tp = None
+        if taps:
+            T25 = x.size
+            for r in self.cfg.ratios:
+                T25 = -(-T25 // r)
+            tl = [np.empty((self.cfg.hidden, T25), np.float32), np.empty((self.cfg.hidden, T25), np.float32), np.empty((self.cfg.hidden, T), np.float32),
+                  np.empty((T, self.cfg.n_q), np.float32)]
+            tp = (vp * 4)(*[_fp(t) for t in tl])
+        n = olib.q3o_mimi_encode(self._h, _fp(x), x.size, _fp(codes), tp)
+        if n < 0:
+            raise RuntimeError(olib.q3o_mimi_last_error(self._h).decode())
+        assert n == T
+        return (codes, tl) if taps else codes
+
+    def close(self):
+        if self._h and olib is not None:
+            olib.q3o_mimi_free(self._h); self._h = None

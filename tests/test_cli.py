@@ -70,7 +70,12 @@ def test_cli_end_to_end_synthetic(tmp_path):
     assert rc == 0
     c3 = np.fromfile(tmp_path / "o3" / "codes_seed7_frames5.bin", dtype="<i8").reshape(5, 16)
     assert not np.array_equal(c3, codes[:5])          # the speaker embedding conditions the prefill
-    assert cli.main(["--synthetic", "tiny", "--ref-audio", str(tmp_path / "ref.wav"), "--ref-text", "hi"]) == 2      # ICL: no Mimi encoder here
+    # ICL from raw audio (--ref-audio + --ref-text): speaker embedding + codec frames of the clip from the speech encoder
+    rc = cli.main(["--synthetic", "tiny", "--text", "The quick brown fox", "--frames", "5", "--no-eos", "--seed", "7",
+                   "--output-dir", str(tmp_path / "o4"), "--ref-audio", str(tmp_path / "ref.wav"), "--ref-text", "hello there"])
+    assert rc == 0
+    c4 = np.fromfile(tmp_path / "o4" / "codes_seed7_frames5.bin", dtype="<i8").reshape(5, 16)
+    assert not np.array_equal(c4, c3)                 # the ICL block changes the prefill
     assert cli.main(["--synthetic", "tiny", "--ref-audio", "x.wav", "--instruct", "deep voice"]) == 2
     assert cli.main(["--synthetic", "tiny", "--x-vector-only"]) == 2 and cli.main(["--synthetic", "tiny", "--ref-text", "hi"]) == 2
 

@@ -70,3 +70,46 @@ def test_talker_layers_match_hf_qwen3_decoder_layer():
     assert _rel(hid, fx["talker_last_hidden"]) <= 2e-5, _rel(hid, fx["talker_last_hidden"])
     assert np.abs(lg - fx["talker_logits"]).max() <= 2e-5 * max(1.0, float(np.abs(fx["talker_logits"]).max()))
     s.close(); om.close()
+
+
+def _speech_oracle(scfg):
+    from qwen3_tts_rs_amd.speech_encoder import SpeechEncoder, synthetic_speech_checkpoint
+    enc = SpeechEncoder(scfg, device=-1)              # manifest-only handle: names / sizes (no GPU)
+    o = O.OracleSpeechEncoder(scfg)
+    for name, arr in synthetic_speech_checkpoint(enc, SEED):
+        o.set_tensor(name, arr)
+    enc.close()
+    return o
+
+
+def _clip(n, seed):          # the generator's test signal (tests/make_golden_hf.py::test_clip)
+    t = np.arange(n) / 24000.0
+    rng = np.random.default_rng(seed)
+    x = 0.3 * np.sin(2 * np.pi * 180.0 * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 2.5 * t)) + 0.15 * np.sin(2 * np.pi * 1250.0 * t + 0.7) + \
+        0.05 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def test_speech_encoder_matches_hf_mimi():
+    """ICL reference-audio encoder (encoder_12hz.rs:34-144 over candle's Mimi): oracle/q3_oracle_mimi.c against Hugging
+    Face's MimiModel on the same seeded weights — SEANet output, transformer output, down-sampled latents, and the 16
+    codebook indices per frame (a differing index is tolerated only where the oracle's own decision margin is tiny)."""
+    import qwen3_tts_rs_amd as q
+    fx = np.load(os.path.join(os.path.dirname(FX), "hf_mimi.npz"))
+    for tag, scfg in (("tiny", q.tiny_speech_config()), ("full", q.SpeechEncoderConfig())):
+        n = int(fx[f"mimi_{tag}_n"][0])
+        o = _speech_oracle(scfg)
+        codes, taps = o.encode(_clip(n, 7), taps=True)
+        assert _rel(taps[0], fx[f"mimi_{tag}_seanet"]) <= 2e-5, (tag, _rel(taps[0], fx[f"mimi_{tag}_seanet"]))
+        assert _rel(taps[1], fx[f"mimi_{tag}_transformer"]) <= 5e-5, (tag, _rel(taps[1], fx[f"mimi_{tag}_transformer"]))
+        assert _rel(taps[2], fx[f"mimi_{tag}_downsample"]) <= 5e-5, (tag, _rel(taps[2], fx[f"mimi_{tag}_downsample"]))
+        ref = fx[f"mimi_{tag}_codes"]
+        assert codes.shape == ref.shape
+        bad = 0
+        for t in range(codes.shape[0]):
+            if not (codes[t] == ref[t]).all():
+                l = int(np.argmin(codes[t] == ref[t]))            # first differing layer; later layers follow from it
+                assert taps[3][t, l] <= 1e-4 * max(1.0, float(np.abs(taps[2]).max()) ** 2), (tag, t, l, float(taps[3][t, l]))
+                bad += 1
+        assert bad <= max(1, codes.shape[0] // 20), (tag, bad)
+        o.close()
