@@ -93,7 +93,7 @@ def main(argv=None) -> int:
             scfg = q.tiny_speaker_config(cfg.hidden) if a.synthetic == "tiny" else q.SpeakerEncoderConfig(enc_dim=cfg.hidden)
             model.attach_speaker_encoder(q.SpeakerEncoder.from_synthetic(scfg, device=dev))
             if a.ref_text and not a.ref_codes_bin:      # ICL from raw audio: seeded speech encoder (Mimi shapes)
-                model.attach_speech_encoder(q.SpeechEncoder.from_synthetic(q.tiny_speech_config() if a.synthetic == "tiny" else None, device=dev))
+                model.attach_speech_encoder(q.SpeechEncoder.from_synthetic(None, device=dev))     # 16 codebooks, whatever the talker's size
         tok = TextTokenizer.from_pretrained(None, a.tokenizer_dir, allow_stand_in=True)     # --synthetic: the labelled stand-in
     else:
         # a real checkpoint needs its real tokenizer (the reference fails to load without one, text.rs:62-110) unless every

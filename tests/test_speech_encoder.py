@@ -89,7 +89,10 @@ def test_icl_prompt_from_raw_audio(tmp_path):
     from safetensors.torch import load_file, save_file
     from common import write_checkpoint_dir
     from qwen3_tts_rs_amd.speech_encoder import synthetic_speech_checkpoint
-    cfg = q.tiny()
+    t = q.tiny()          # tiny talker / code predictor, full-size decoder (config.json carries the talker's shapes only)
+    cfg = q.Q3Config(text_dim=t.text_dim, hidden=t.hidden, inter=t.inter, n_layers=t.n_layers, n_heads=t.n_heads, n_kv_heads=t.n_kv_heads,
+                     cp_hidden=t.cp_hidden, cp_inter=t.cp_inter, cp_layers=t.cp_layers, cp_heads=t.cp_heads, cp_kv_heads=t.cp_kv_heads,
+                     name="tiny-lm-full-decoder")
     scfg = q.tiny_speaker_config(cfg.hidden)
     write_checkpoint_dir(cfg, str(tmp_path), model_type="base", speaker_cfg=scfg, extra=False)
     # add the (full-size) speech encoder to the speech tokenizer file, as the released checkpoints have it
