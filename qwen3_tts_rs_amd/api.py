@@ -388,7 +388,10 @@ class Qwen3TTS:
             tok = os.path.join(os.path.dirname(os.path.abspath(str(model_dir))), "speech_tokenizer", "model.safetensors")
         if device >= 0 and os.path.exists(tok) and \
                 lib.q3_safetensors_info(tok.encode(), b"encoder.downsample.conv.weight", ctypes.byref(probe), None, 0, None) == 0:
-            m.attach_speech_encoder(SpeechEncoder.from_safetensors(tok, None, device))
+            try:        # non-fatal, as try_load_speech_encoder (lib.rs:1362-1388): without it only ICL cloning is unavailable
+                m.attach_speech_encoder(SpeechEncoder.from_safetensors(tok, None, device))
+            except _lib.Q3Error:
+                pass
         return m
 
     # ---- voice cloning front end (lib.rs:1049-1190) ----

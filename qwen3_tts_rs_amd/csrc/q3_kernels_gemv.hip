@@ -125,7 +125,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     constexpr int G = (NW == 2 || RMS) ? 4 : 6;
     __shared__ __attribute__((aligned(16))) float red[NWAVES][NW][256];
     __shared__ float ssq[NWAVES][4][16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // Which K slice a wave takes ROTATES with the workgroup index: every workgroup reads the same activation vector, and
+    // with a fixed wave -> slice map all 256 CUs ask the L2 for the same lines in the same order at the same time (one
+    // L2 channel serves them all). Partial sums are stored by SLICE index, so the reduction order — and every bit of the
+    // result — is unchanged.
+#ifdef Q3_NO_ROTATE
+    const int wave = tid >> 6;
+#else
+    const int wave = ((tid >> 6) + blockIdx.x) % NWAVES;
+#endif
     const int m = lane & 15, kg = lane >> 4;
     const int S = a.Kpad >> 5;                       // k-steps of 32
     const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
@@ -372,7 +381,12 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
     constexpr int NWAVES = 8, G = 4;
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float lds[NWAVES * ZB + NWAVES * 16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef Q3_NO_ROTATE
+    const int wave = tid >> 6;
+#else
+    const int wave = ((tid >> 6) + blockIdx.x) % NWAVES;        // K slice rotates with the workgroup (see k_gemv_mfma)
+#endif
     const int m = lane & 15, kg = lane >> 4;
     const int S = a.Kpad >> 5;                       // k-steps of 32
     const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
@@ -545,7 +559,12 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     __shared__ float red[8][NW][MG][4][4];
     __shared__ float ssq[8][MG][4];
     const int nwv = blockDim.x >> 6;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef Q3_NO_ROTATE
+    const int wave = tid >> 6;
+#else
+    const int wave = ((tid >> 6) + blockIdx.x) % nwv;           // K slice rotates with the workgroup (see k_gemv_mfma)
+#endif
     const int j = lane & 3, kb = lane >> 2;
     const int S = a.Kpad >> 7;                       // k-steps of 128
     const int s0 = (wave * S) / nwv, s1 = ((wave + 1) * S) / nwv;

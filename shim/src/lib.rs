@@ -193,7 +193,10 @@ impl Qwen3TTS {
             let mut mc = Q3MimiConfig::default();
             check(unsafe { q3_mimi_config_default(&mut mc) })?;
             check(unsafe { q3_mimi_create(&mc, device.0, &mut me.speech) })?;
-            check(unsafe { q3_mimi_load_safetensors(me.speech, tok.as_ptr()) })?;
+            if unsafe { q3_mimi_load_safetensors(me.speech, tok.as_ptr()) } != 0 {       // non-fatal (lib.rs:1362-1388): ICL just stays unavailable
+                unsafe { q3_mimi_free(me.speech) };
+                me.speech = std::ptr::null_mut();
+            }
         }
         Ok(me)
     }

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(512) void k_persist(const u32x4_t* __restrict__ w, 
 }
 
 // the same stage as its own kernel (plain loads / stores; the kernel boundary is the barrier)
-template <int NLW>
+// ROT: every workgroup starts its walk over the shared activation vector at a different offset (L2 channel hot-spot probe)
+template <int NLW, int ROT>
 __global__ __launch_bounds__(512) void k_stage(const u32x4_t* __restrict__ w, const float* __restrict__ xin, float* xout, int nwg_slice) {
     __shared__ float red[8];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(512) void k_stage(const u32x4_t* __restrict__ w, co
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < XN / 4 / 512; ++i) {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(xin + (i * 512 + tid) * 4);
+        const int slot = ROT ? ((i * 512 + tid + (int)blockIdx.x * 67) & (XN / 4 - 1)) : (i * 512 + tid);
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(xin + slot * 4);
         acc += v[0] + v[1] + v[2] + v[3];
     }
     unsigned h = 0;
@@ -228,14 +230,18 @@ int main() {
         if (timed(nm, STAGES, REPS, st, [&] { hipLaunchKernelGGL((k_persist<NLW, 0>), dim3(WGS), dim3(512), 0, st, w, stage_vec, slots, xring, bar, STAGES, out); }, bar)) return 1; \
         snprintf(nm, sizeof nm, "C persistent stage, XCD barrier    %5.1f MB weights/stage", stage_vec * 16 / 1e6);                       \
         if (timed(nm, STAGES, REPS, st, [&] { hipLaunchKernelGGL((k_persist<NLW, 1>), dim3(WGS), dim3(512), 0, st, w, stage_vec, slots, xring, bar, STAGES, out); }, bar)) return 1; \
+        for (int rot = 0; rot < 2; ++rot) {                                                                                                \
         hipGraph_t g; hipGraphExec_t ge;                                                                                                   \
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));                                                                         \
-        for (int s = 0; s < STAGES; ++s)                                                                                                   \
-            hipLaunchKernelGGL((k_stage<NLW>), dim3(WGS), dim3(512), 0, st, w + (size_t)(s % slots) * stage_vec, xring + (size_t)(s & 1) * XN, xring + (size_t)((s + 1) & 1) * XN, XN / WGS); \
+        for (int s = 0; s < STAGES; ++s) {                                                                                                 \
+            if (rot) hipLaunchKernelGGL((k_stage<NLW, 1>), dim3(WGS), dim3(512), 0, st, w + (size_t)(s % slots) * stage_vec, xring + (size_t)(s & 1) * XN, xring + (size_t)((s + 1) & 1) * XN, XN / WGS); \
+            else hipLaunchKernelGGL((k_stage<NLW, 0>), dim3(WGS), dim3(512), 0, st, w + (size_t)(s % slots) * stage_vec, xring + (size_t)(s & 1) * XN, xring + (size_t)((s + 1) & 1) * XN, XN / WGS); \
+        }                                                                                                                                  \
         CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));                                             \
-        snprintf(nm, sizeof nm, "D one kernel per stage (hipGraph)  %5.1f MB weights/stage", stage_vec * 16 / 1e6);                        \
+        snprintf(nm, sizeof nm, "D one kernel per stage (hipGraph)%s %5.1f MB weights/stage", rot ? ", rotated x" : "            ", stage_vec * 16 / 1e6); \
         if (timed(nm, STAGES, REPS, st, [&] { (void)hipGraphLaunch(ge, st); }, bar)) return 1;                                             \
         hipGraphExecDestroy(ge); hipGraphDestroy(g);                                                                                       \
+        }                                                                                                                                  \
     }
     STAGE_CASE(1) STAGE_CASE(2) STAGE_CASE(4) STAGE_CASE(6) STAGE_CASE(8)
     return 0;
