@@ -34,7 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="1.7b", choices=["1.7b", "0.6b", "tiny"])
-    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU (one session; up to 64)")
+    ap.add_argument("--also-batches", default="", help="comma-separated extra batch sizes whose frames/s are reported beside the headline (e.g. 32,64)")
     ap.add_argument("--frames", type=int, default=640, help="frames generated per utterance (eos disabled)")
     ap.add_argument("--prompt-tokens", type=int, default=512)
     ap.add_argument("--workload", default="customvoice", choices=["customvoice", "voicedesign4k", "xvector"],
@@ -235,6 +236,18 @@ def main():
     except Exception as e:   # latency extras must never kill the headline line
         lat["error"] = str(e)
 
+    # ---- wider sessions on the same GPU (serving view): frames/s of one step at other batch sizes ----
+    wide = {}
+    for bb in [int(x) for x in args.also_batches.split(",") if x.strip()]:
+        try:
+            uw = [make_utt(i) for i in range(bb)]
+            for rep in range(2):            # first pass warms the session-shape cache
+                sw = model.session(uw, opts); tw0 = time.perf_counter(); tw = sw.run_timing_only(use_graph=use_graph); tw1 = time.perf_counter(); sw.close()
+            wide[str(bb)] = {"frames_per_s": tw.generation_frames / (tw1 - tw0), "ms_per_frame": tw.generation_ms / args.frames,
+                             "stage_ms": {"prefill_ms": tw.prefill_ms, "generation_ms": tw.generation_ms, "decode_ms": tw.decode_ms}}
+        except Exception as e:
+            wide[str(bb)] = {"error": str(e)}
+
     # ---- CPU baseline: the oracle (port of the candle-CPU F32 path) on this host, bounded sample ----
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -294,7 +307,7 @@ def main():
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,
                                                         "gbps": (bcast_bytes / bcast_s / 1e9) if bcast_s > 0 else None},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "other_batches": wide,
     }
     print(json.dumps(out))
 

@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 #define Q3_ABI_VERSION 1
+#define Q3_MAX_BATCH 64      /* sequences per session (rows of the decode GEMVs: 16-column MFMA tiles x 4) */
 
 typedef enum q3_status {
     Q3_OK = 0,

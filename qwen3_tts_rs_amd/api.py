@@ -19,6 +19,7 @@ from ._lib import lib, check, COptions, CRequest, CTiming
 from .config import Q3Config
 from . import synth
 
+MAX_BATCH = 64                 # Q3_MAX_BATCH (include/q3tts.h): sequences per session
 CODEC_EOS_TOKEN_ID = 2150      # lib.rs:1466
 SAMPLES_PER_FRAME = 1920       # lib.rs:1469
 
@@ -550,8 +551,8 @@ class Qwen3TTS:
         audio: List[Optional[AudioBuffer]] = [None] * len(utts)
         tot = SynthesisTiming(0.0, 0.0, 0, 0.0)
         for idx in groups.values():
-            for k in range(0, len(idx), 16):                    # a session holds up to 16 sequences
-                part = idx[k:k + 16]
+            for k in range(0, len(idx), MAX_BATCH):             # a session holds up to Q3_MAX_BATCH (64) sequences
+                part = idx[k:k + MAX_BATCH]
                 s = self.session([utts[i] for i in part], options)
                 try:
                     a, t = s.run()

@@ -211,6 +211,7 @@ static inline bool short_k_wide(int N, int K) { return K <= 1024 && N >= 2048; }
 static inline int pick_mode(const TW& w, int M, int N, int K) {
     static const bool no4 = getenv("Q3_GEMV_NO_MFMA4") != nullptr;     // tuning aid: 16-row tiles wherever both images exist (M > 2)
     if (w.t2 && !w.t1) return 2;
+    if (M > 16 && w.t1) return 1;             // wide batches: k_gemv_wide works on the 16-row tiles
     if (no4 && w.t1 && M > 2) return 1;
     if (w.t2 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) return 2;
     return 1;
@@ -1399,7 +1400,7 @@ static bool opts_equal_sampling(const q3_options& a, const q3_options& b) {
 extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out) {
     if (!m || !reqs || !out) return set_err(Q3_INVALID_ARG, "q3_session_create: null argument");
     if (!m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
-    if (batch < 1 || batch > 16) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..16 per GPU)", batch);
+    if (batch < 1 || batch > Q3_MAX_BATCH) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..%d sequences per session)", batch, Q3_MAX_BATCH);
     HIPC(hipSetDevice(m->device));
     const q3_config& c = m->cfg;
     std::unique_ptr<q3_session> s(new q3_session());
@@ -1482,7 +1483,7 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     const int B = batch, H = c.hidden, CH = c.cp_hidden;
     auto alloc_lm = [&](LmBuf& b, const LmDims& d, int nsplit) -> hipError_t {
         const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM;
-        const size_t R = 16;     // rows: up to 16 (multi-row steps), >= B
+        const size_t R = batch > 16 ? (size_t)up16(batch) : 16;     // rows: up to 16 for multi-row steps (B <= 16), else one row per sequence
         hipError_t e;
         if ((e = s->pool.alloc(&b.X, R * d.H)) != hipSuccess) return e;
         if ((e = s->pool.alloc(&b.SUM, R * d.H)) != hipSuccess) return e;
@@ -1496,7 +1497,7 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     HIPC(alloc_lm(s->cb, cp_dims(c), 1));
     HIPC(s->pool.alloc(&s->LASTH, (size_t)B * H));
     HIPC(s->pool.alloc(&s->LOGITS, (size_t)B * c.codec_vocab));
-    HIPC(s->pool.alloc(&s->CP_IN, (size_t)16 * H));
+    HIPC(s->pool.alloc(&s->CP_IN, (size_t)(B > 16 ? up16(B) : 16) * H));
     HIPC(s->pool.alloc(&s->CP_LOGITS, (size_t)15 * B * c.cp_vocab));
     s->kv_layer_stride = (size_t)B * c.n_kv_heads * s->max_seq * HEAD_DIM;
     HIPC(s->pool.alloc(&s->kcache, s->kv_layer_stride * c.n_layers));
@@ -2382,16 +2383,18 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
     HIPC(hipSetDevice(device));
     DevPool pool;
     float *x, *y, *b = nullptr; uint16_t* w;
-    const int mode = (N < 4096 && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;
+    // the engine's own choice (pick_mode): 4-row tiles for narrow projections at small M — not for short-K wide ones, not beyond 16 rows
+    const int mode = (M <= 16 && N < 4096 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;
     const size_t wt_elems = tiled_elems(mode, N, K);
     std::vector<uint16_t> wt(wt_elems);
     retile_bf16(w_host, N, K, wt.data(), mode);
     HIPC(pool.alloc(&x, (size_t)M * K)); HIPC(pool.alloc(&y, (size_t)M * N)); HIPC(pool.alloc(&w, wt_elems));
     HIPC(hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(w, wt.data(), wt_elems * 2, hipMemcpyHostToDevice));
     if (bias_host) { HIPC(pool.alloc(&b, (size_t)N)); HIPC(hipMemcpy(b, bias_host, (size_t)N * 4, hipMemcpyHostToDevice)); }
-    for (int m0 = 0; m0 < M; m0 += 16) {
+    const int step = mode == 1 ? Q3_MAX_BATCH : 16;          // up to 64 rows per launch on the 16-row tiles (k_gemv_wide beyond 16)
+    for (int m0 = 0; m0 < M; m0 += step) {
         LinArgs a;
-        a.W = w; a.N = N; a.K = K; a.x = x + (size_t)m0 * K; a.ldx = K; a.bias = b; a.y = y + (size_t)m0 * N; a.ldy = N; a.M = (M - m0) < 16 ? (M - m0) : 16; a.epi = EPI_NONE;
+        a.W = w; a.N = N; a.K = K; a.x = x + (size_t)m0 * K; a.ldx = K; a.bias = b; a.y = y + (size_t)m0 * N; a.ldy = N; a.M = (M - m0) < step ? (M - m0) : step; a.epi = EPI_NONE;
         a.tiled = mode; a.Kpad = kpad_for(mode, K);
         HIPC(launch_linear(a, 0));
     }
@@ -2449,20 +2452,20 @@ extern "C" q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap
 // ------------------------------------------------------------------------------------------------
 extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                                      double* avg_us) {
-    if (M < 1 || M > 16 || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
-    if (tiled < 0) tiled = (N < 4096 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
+    if (M < 1 || M > Q3_MAX_BATCH || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
+    if (tiled < 0) tiled = (M <= 16 && N < 4096 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
     HIPC(hipSetDevice(device));
     DevPool pool;
     const size_t welems = tiled == 2 ? tiled_elems(2, N, K) : tiled_elems(1, N, K);
     const int nmat = epi == EPI_SWIGLU ? 2 : 1;
     uint16_t* w; float *x, *y, *nw, *res;
     HIPC(pool.alloc(&w, welems * nmat * n_copies));
-    HIPC(pool.alloc(&x, (size_t)16 * K)); HIPC(pool.alloc(&y, (size_t)16 * N)); HIPC(pool.alloc(&nw, (size_t)K)); HIPC(pool.alloc(&res, (size_t)16 * N));
+    HIPC(pool.alloc(&x, (size_t)Q3_MAX_BATCH * K)); HIPC(pool.alloc(&y, (size_t)Q3_MAX_BATCH * N)); HIPC(pool.alloc(&nw, (size_t)K)); HIPC(pool.alloc(&res, (size_t)Q3_MAX_BATCH * N));
     {   // random-ish bf16 weights / f32 activations (never zeros: DVFS, guide §5.4 rule 25)
         std::vector<uint16_t> hw(welems);
         q3_synth_fill(1, "bench.w", Q3_DTYPE_BF16, 0.02f, 0.0f, (int64_t)welems, hw.data());
         for (int c = 0; c < nmat * n_copies; ++c) HIPC(hipMemcpy(w + (size_t)c * welems, hw.data(), welems * 2, hipMemcpyHostToDevice));
-        std::vector<float> hx((size_t)16 * K), hn((size_t)K, 1.0f);
+        std::vector<float> hx((size_t)Q3_MAX_BATCH * K), hn((size_t)K, 1.0f);
         q3_synth_fill(2, "bench.x", Q3_DTYPE_F32, 1.0f, 0.0f, (int64_t)hx.size(), hx.data());
         HIPC(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(nw, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));

@@ -125,16 +125,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     constexpr int G = (NW == 2 || RMS) ? 4 : 6;
     __shared__ __attribute__((aligned(16))) float red[NWAVES][NW][256];
     __shared__ float ssq[NWAVES][4][16];
-    const int tid = threadIdx.x, lane = tid & 63;
-    // Which K slice a wave takes ROTATES with the workgroup index: every workgroup reads the same activation vector, and
-    // with a fixed wave -> slice map all 256 CUs ask the L2 for the same lines in the same order at the same time (one
-    // L2 channel serves them all). Partial sums are stored by SLICE index, so the reduction order — and every bit of the
-    // result — is unchanged.
-#ifdef Q3_NO_ROTATE
-    const int wave = tid >> 6;
-#else
-    const int wave = ((tid >> 6) + blockIdx.x) % NWAVES;
-#endif
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (Rotating the wave -> K-slice map with the workgroup index, so that the 256 CUs do not all walk the shared activation
+    // vector in the same order, was tried against an L2-channel hot-spot theory: no change on any shape or on the frame —
+    // profiles/r2_gemv_variants_M8.txt.)
     const int m = lane & 15, kg = lane >> 4;
     const int S = a.Kpad >> 5;                       // k-steps of 32
     const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
@@ -381,12 +375,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
     constexpr int NWAVES = 8, G = 4;
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float lds[NWAVES * ZB + NWAVES * 16];
-    const int tid = threadIdx.x, lane = tid & 63;
-#ifdef Q3_NO_ROTATE
-    const int wave = tid >> 6;
-#else
-    const int wave = ((tid >> 6) + blockIdx.x) % NWAVES;        // K slice rotates with the workgroup (see k_gemv_mfma)
-#endif
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
     const int S = a.Kpad >> 5;                       // k-steps of 32
     const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
@@ -559,12 +548,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     __shared__ float red[8][NW][MG][4][4];
     __shared__ float ssq[8][MG][4];
     const int nwv = blockDim.x >> 6;
-    const int tid = threadIdx.x, lane = tid & 63;
-#ifdef Q3_NO_ROTATE
-    const int wave = tid >> 6;
-#else
-    const int wave = ((tid >> 6) + blockIdx.x) % nwv;           // K slice rotates with the workgroup (see k_gemv_mfma)
-#endif
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 3, kb = lane >> 2;
     const int S = a.Kpad >> 7;                       // k-steps of 128
     const int s0 = (wave * S) / nwv, s1 = ((wave + 1) * S) / nwv;
@@ -765,7 +749,175 @@ hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide batches (16 < M <= 64): one session carries up to 64 sequences, so a weight tile streamed from HBM once serves
+// MT = ceil(M / 16) column tiles. A workgroup = 8 waves owns one 16-row weight tile (two for SwiGLU) and the waves
+// split K as in the kernels above; per k-step a wave brings the 16*MT activation rows in with row-contiguous loads
+// (one instruction = 8 rows x 128 B), applies the norm weight / accumulates sum(x^2) on that form, parks them in its
+// own LDS staging buffer (36-float pitch: the 16 rows of a ds_read_b128 phase land on distinct 4-bank groups) and reads
+// the MFMA B operand of every column tile back; the weight tiles of 4 k-steps are requested ahead, the x rows of the
+// next k-step are in flight while the current one is multiplied. The launch is bound by the L2 -> CU traffic of x
+// (M*K*4 bytes per workgroup against 32*K bytes of weights): ~2.4x the M = 8 time for 8x the rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int WS = 36;                      // staging pitch in floats (32 k + 4 pad)
+
+template <int EPI, bool RMS, int MT>
+__global__ __launch_bounds__(512) void k_gemv_wide(LinArgs a) {
+    constexpr int NWAVES = 8, G = 4, NX = 2 * MT;           // NX x-load instructions per k-step (8 rows each)
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int ZW = 16 * MT * WS;                        // staging floats per wave
+    constexpr int RED = NWAVES * NW * MT * 256, STG = NWAVES * ZW;
+    __shared__ __attribute__((aligned(16))) float lds[(RED > STG ? RED : STG) + NWAVES * 16 * MT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int S = a.Kpad >> 5;
+    const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
+    const size_t tile_base = (size_t)blockIdx.x * S * 64 + lane;
+    const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + tile_base;
+    const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : wp;
+    float* __restrict__ zb = lds + wave * ZW;
+    float* __restrict__ ssq = lds + (RED > STG ? RED : STG);          // [NWAVES][16*MT], outside the aliased area
+    const int xr8 = lane >> 3, xc = (lane & 7) * 4;                    // x loads: row xr8 + 8j, floats xc .. xc+3 of the k-step
+
+    // epilogue operands requested up front: thread (col = tid >> 4 in 0..31, row = tid & 15) serves columns col + 32*j
+    constexpr int NE = (MT + 1) / 2;
+    float pre_b = 0.0f, pre_r[NE];
+    {
+        const int n = blockIdx.x * 16 + (tid & 15);
+        if (n < a.N && a.bias) pre_b = a.bias[n];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int col = (tid >> 4) + 32 * j;
+            pre_r[j] = 0.0f;
+            if constexpr (EPI == EPI_RESID) if (col < a.M && n < a.N) pre_r[j] = a.resid[(size_t)col * a.ldr + n];
+        }
+    }
+    f32x4_t acc[NW][MT];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[w][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float ss[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) ss[j] = 0.0f;
+
+    auto xload = [&](float4 (&xv)[NX], float4& nv, int s) {
+        const int k0 = s * 32 + xc;
+        const bool kok = k0 < a.K;                                   // K % 4 == 0: a float4 is all in or all out
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int row = xr8 + 8 * j;
+            xv[j] = (kok && row < a.M) ? *reinterpret_cast<const float4*>(a.x + (size_t)row * a.ldx + k0) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (RMS) nv = kok ? *reinterpret_cast<const float4*>(a.norm_w + k0) : float4{0.f, 0.f, 0.f, 0.f};
+    };
+    for (int sb = s0; sb < s1; sb += G) {
+        u32x4_t wa[G], wb[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);       // ragged last group: duplicate load, never consumed
+            wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+            if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
+        }
+        float4 xc0[NX], xc1[NX], n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
+        xload(xc0, n0, sb);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = sb + i;
+            if (s >= s1) break;                                      // wave-uniform
+            float4 (&cur)[NX] = (i & 1) ? xc1 : xc0; float4 (&nxt)[NX] = (i & 1) ? xc0 : xc1;
+            float4& ncur = (i & 1) ? n1 : n0; float4& nnxt = (i & 1) ? n0 : n1;
+            if (i + 1 < G && s + 1 < s1) xload(nxt, nnxt, s + 1);    // next k-step's rows in flight under this one's MFMAs
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                float4 v = cur[j];
+                if constexpr (RMS) {
+                    ss[j] = fmaf(v.x, v.x, ss[j]); ss[j] = fmaf(v.y, v.y, ss[j]); ss[j] = fmaf(v.z, v.z, ss[j]); ss[j] = fmaf(v.w, v.w, ss[j]);
+                    v.x *= ncur.x; v.y *= ncur.y; v.z *= ncur.z; v.w *= ncur.w;
+                }
+                *reinterpret_cast<float4*>(zb + (xr8 + 8 * j) * WS + xc) = v;
+            }
+            // wave-private buffer: the writes above are visible to this wave's reads below in program order (LDS is in-order per wave)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float* zr = zb + (16 * t + m) * WS + kg * 8;
+                const float4 b0 = *reinterpret_cast<const float4*>(zr), b1 = *reinterpret_cast<const float4*>(zr + 4);
+                const float xv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                const Split3 sp = split3(xv);
+                acc[0][t] = mfma3(wa[i], sp, acc[0][t]);
+                if constexpr (NW == 2) acc[1][t] = mfma3(wb[i], sp, acc[1][t]);
+            }
+        }
+    }
+    if constexpr (RMS) {
+        // per-row sum(x^2) of this wave's K slice: the 8 lanes with equal lane >> 3 share a row
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            float v = ss[j];
+            v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            if ((lane & 7) == 0) ssq[wave * 16 * MT + xr8 + 8 * j] = v;
+        }
+    }
+    __syncthreads();                                  // every wave is done with its staging buffer: `red` aliases it
+    float* __restrict__ red = lds;                    // [NWAVES][NW][MT][256], layout [col m][row]
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            *reinterpret_cast<f32x4_t*>(&red[((wave * NW + w) * MT + t) * 256 + m * 16 + kg * 4]) = acc[w][t];
+    __syncthreads();
+    const int row = tid & 15, n = blockIdx.x * 16 + row;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int col = (tid >> 4) + 32 * j;              // batch column 0 .. 16*MT-1
+        if (col >= 16 * MT || col >= a.M) continue;
+        const int t = col >> 4, idx = (col & 15) * 16 + row;
+        float v = 0.0f, v2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            v += red[((w * NW + 0) * MT + t) * 256 + idx];
+            if constexpr (NW == 2) v2 += red[((w * NW + 1) * MT + t) * 256 + idx];
+        }
+        if constexpr (RMS) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) tot += ssq[w * 16 * MT + col];
+            const float den = sqrtf(tot / (float)a.K + a.eps);
+            v = v / den;
+            if constexpr (NW == 2) v2 = v2 / den;
+        }
+        if (n < a.N) {
+            if (a.bias) v = v + pre_b;
+            if constexpr (EPI == EPI_RESID) v = pre_r[j] + v;
+            if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+            if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+            a.y[(size_t)col * a.ldy + n] = v;
+        }
+    }
+}
+
+template <int EPI, bool RMS>
+static hipError_t launch_gemv_wide_t(const LinArgs& a, hipStream_t st) {
+    const int tiles = (a.N + 15) / 16, mt = (a.M + 15) / 16;
+    if (mt <= 2) hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 2>), dim3(tiles), dim3(512), 0, st, a);
+    else if (mt == 3) hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 3>), dim3(tiles), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 4>), dim3(tiles), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+static hipError_t launch_gemv_wide(const LinArgs& a, hipStream_t st) {
+    if (a.tiled != 1 || a.Kpad % 32 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 17 || a.M > 64 || a.N < 1) return hipErrorInvalidValue;
+    const bool rms = a.norm_w != nullptr;
+    switch (a.epi) {
+        case EPI_NONE: return rms ? launch_gemv_wide_t<EPI_NONE, true>(a, st) : launch_gemv_wide_t<EPI_NONE, false>(a, st);
+        case EPI_RESID: return rms ? hipErrorInvalidValue : launch_gemv_wide_t<EPI_RESID, false>(a, st);
+        case EPI_SILU: return rms ? hipErrorInvalidValue : launch_gemv_wide_t<EPI_SILU, false>(a, st);
+        case EPI_SWIGLU: return rms ? launch_gemv_wide_t<EPI_SWIGLU, true>(a, st) : launch_gemv_wide_t<EPI_SWIGLU, false>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st) {
+    if (a.M > 16) return launch_gemv_wide(a, st);
     if (a.Kpad % 32 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
         return hipErrorInvalidValue;
     const bool rms = a.norm_w != nullptr;

@@ -115,6 +115,30 @@ def test_b8_b16_graph_codes(gm17, B, sampling):
     assert len(rep) <= max(1, B // 8), rep          # near-ties are rare: at most one per eight sequences
 
 
+def test_b32_session_1_7b(gm17):
+    """One session carrying 32 utterances at 1.7B (wide-batch GEMV, two attention splits): the 16 sequences the oracle fixture
+    holds are compared with it, the other 16 with their own 8-utterance sessions (HIP vs HIP, bit-exact)."""
+    ref = np.load(os.path.join(G, "bench_1_7b_codes.npz"))["default_codes"]
+    opts = q.SynthesisOptions(max_length=N_FRAMES, eos_token_id=None, seed=42)
+    utts = [bench_utt(i) for i in range(32)]
+    s = gm17.session(utts, opts); s.prefill(); s.generate(N_FRAMES, use_graph=True)
+    codes = [s.codes(b) for b in range(32)]
+    s.close()
+    bad = []
+    for b in range(16):
+        if not (codes[b] == ref[b]).all():
+            ok, rep = _adjudicate("1.7b", utts[b], opts, codes[b], f"1_7b_b32_seq{b}")
+            assert ok, rep
+            bad.append(rep)
+    assert len(bad) <= 2, bad
+    for g0 in (16, 24):
+        s8 = gm17.session(utts[g0:g0 + 8], opts); s8.prefill(); s8.generate(N_FRAMES, use_graph=True)
+        same = sum(int((s8.codes(i) == codes[g0 + i]).all()) for i in range(8))
+        s8.close()
+        assert same >= 7, (g0, same)        # different GEMV kernels (M = 8 vs M = 32): a near-tie may flip one sequence
+    _dump("bench_parity_1_7b_b32.json", {"oracle_near_ties": bad})
+
+
 def test_teacher_forced_m8(gm17):
     """talker step + code predictor at M = 8 rows, full width: RMS-fused / SwiGLU / residual epilogues, the split attention
     and its merge, compared logit by logit with the oracle's values for 8 DIFFERENT sequences."""

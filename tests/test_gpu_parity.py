@@ -28,7 +28,10 @@ def _dump(name, obj):
 
 # ---------------------------------------------------------------- ops
 @pytest.mark.parametrize("M,N,K", [(1, 64, 64), (1, 1000, 1024), (2, 4096, 2048), (4, 2048, 6144), (8, 3072, 2048),
-                                   (8, 1024, 3072), (3, 520, 136), (5, 12288, 2048), (11, 256, 512)])
+                                   (8, 1024, 3072), (3, 520, 136), (5, 12288, 2048), (11, 256, 512),
+                                   # wide batches (k_gemv_wide: 2, 3 and 4 column tiles, ragged row counts, K tails)
+                                   (17, 4096, 2048), (32, 1024, 3072), (33, 2048, 1024), (48, 3072, 2048), (64, 2048, 6144),
+                                   (64, 520, 136), (40, 64, 64)])
 def test_linear_matches_oracle(M, N, K):
     rng = np.random.default_rng(M * 1000 + N + K)
     x = rng.standard_normal((M, K)).astype(np.float32)
@@ -247,17 +250,25 @@ def test_eos_and_min_new_tokens(pair):
         s.close(); osess.close()
 
 
-def test_batch_equals_single(pair):
-    """Every sequence of a batch behaves exactly like its own batch-1 run (bit-exact codes)."""
+@pytest.mark.parametrize("B", [5, 17, 33, 64])
+def test_batch_equals_single(pair, B):
+    """Every sequence of a batch behaves exactly like its own batch-1 run (bit-exact codes) — up to the 64 sequences of one
+    session (B > 16: the wide-batch GEMV with 2 / 3 / 4 column tiles, one prefill position per step)."""
     cfg, gm, om = pair
-    utts = [_utts("custom", 11, index=i, hidden=cfg.hidden) for i in range(5)]
+    utts = [_utts("custom", 11, index=i, hidden=cfg.hidden) for i in range(B)]
+    for i, u in enumerate(utts):
+        u.seed = 100 + i
     opts = q.SynthesisOptions(max_length=12, seed=1, eos_token_id=None)
     sb = gm.session(utts, opts); sb.prefill(); sb.generate(12, use_graph=True)
-    for i, u in enumerate(utts):
-        s1 = gm.session([u], opts); s1.prefill(); s1.generate(12, use_graph=False)
+    for i in sorted(set([0, 1, B // 2, B - 2, B - 1])):
+        s1 = gm.session([utts[i]], opts); s1.prefill(); s1.generate(12, use_graph=False)
         assert (sb.codes(i) == s1.codes(0)).all(), i
         s1.close()
+    audio, _ = gm.session(utts, opts).run()
+    assert len(audio) == B and all(len(a) == 12 * 1920 for a in audio)
     sb.close()
+    with pytest.raises(_lib.Q3Error, match="unsupported"):
+        gm.session([utts[0]] * 65, opts)
 
 
 @pytest.mark.parametrize("T", [1, 2, 10])
