@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="1.7b", choices=["1.7b", "0.6b", "tiny"])
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU (one session; up to 64)")
-    ap.add_argument("--also-batches", default="", help="comma-separated extra batch sizes whose frames/s are reported beside the headline (e.g. 32,64)")
+    ap.add_argument("--also-batches", default="64", help="comma-separated extra batch sizes whose frames/s are reported beside the headline (e.g. 32,64)")
     ap.add_argument("--frames", type=int, default=640, help="frames generated per utterance (eos disabled)")
     ap.add_argument("--prompt-tokens", type=int, default=512)
     ap.add_argument("--workload", default="customvoice", choices=["customvoice", "voicedesign4k", "xvector"],
@@ -194,11 +194,16 @@ def main():
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             pmc_path = os.path.join(ROOT, "profiles", cand); break
     if args.model == "1.7b" and pmc_path:
-        pmc = json.load(open(pmc_path))
-        traffic = pmc.get("mean_bytes_per_launch")
-        if traffic is None and "shapes" in pmc:
-            vals = [v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc["shapes"].values()]
-            traffic = float(np.mean(vals)) if vals else None
+        pmc = json.load(open(pmc_path)).get("shapes", {})
+        by_dims = {(v["N"], v["K"], v["epi"]): v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc.values() if "N" in v}
+        tsum = tcnt = 0.0
+        for (Mr, N, K, epi, rms, produce, tiled, count) in shapes:      # weighted by the engine's launches per frame
+            if (N, K, epi) in by_dims:
+                tsum += by_dims[(N, K, epi)] * (count // pf); tcnt += count // pf
+        if tcnt >= 0.9 * launches:
+            traffic = tsum / tcnt
+        elif pmc:                                                       # older profile without dims: plain mean over its shapes
+            traffic = float(np.mean([v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc.values()]))
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": os.path.basename(pmc_path) if (traffic and pmc_path) else None,
                 "kernel": "k_gemv_mfma / k_gemv_mfma4 / k_gemv_lds (bf16-weight MFMA GEMV family, M = batch)",
