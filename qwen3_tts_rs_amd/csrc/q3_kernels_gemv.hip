@@ -156,6 +156,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     // (the VALU-heavy part) of the whole group then runs under the weight latency and only the MFMAs wait for HBM.
     // 16-wave workgroups have 128 VGPRs per lane — not enough to hold a group's splits — and keep the interleaved
     // per-step order.
+    // (With the half-row form the hoisted order also fits the 16-wave register budget; measured on the down-proj: 10.96 ->
+    // 11.80 us hoisted, 11.27 us with only the x requests moved ahead of the weight requests — the interleaved order stays.)
     constexpr bool HOIST = NWAVES <= 8;
     if constexpr (HOIST) {
         // (Keeping a second group's loads in flight while the first is split and multiplied — a software pipeline over the
