@@ -1619,7 +1619,7 @@ static q3_status text_project(q3_session* s, const uint32_t* ids_dev, int n, flo
 // layer as GEMMs over the decode path's tiled weight image + a query-blocked causal attention (q3_kernels_prefill.hip).
 // Leaves the KV cache filled for positions [0, S) and LASTH / LOGITS of the last position, like the chunked decode-step
 // schedule it replaces for S >= 48.
-static q3_status prefill_gemm(q3_session* s, int S) {
+static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {      // positions [0, S) of the S_all-position prompts
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     const LmDims d = talker_dims(c);
     const int B = s->B, H = d.H, QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM, I = d.I;
@@ -1647,7 +1647,7 @@ static q3_status prefill_gemm(q3_session* s, int S) {
     static const bool no_planes = getenv("Q3_GEMM_NO_PLANES") != nullptr;
     const bool planes = !no_planes && H % 8 == 0 && QD % 8 == 0 && I % 8 == 0;
     const int kmax = std::max(kp(H), std::max(kp(QD), kp(I)));
-    const size_t plane_elems = (size_t)max_rows * kmax;
+    const size_t plane_elems = (size_t)((max_rows + 127) / 128 * 128) * kmax;      // whole 128-row tiles (GemmArgs::xp)
     uint16_t* XP = nullptr;
     if (planes) HIPC(tmp.alloc(&XP, plane_elems * 3));
     auto split = [&](GemmArgs& g) -> hipError_t {
@@ -1660,7 +1660,7 @@ static q3_status prefill_gemm(q3_session* s, int S) {
         ch = (S - t0) < C ? (S - t0) : C;
         const int rows = B * ch;
         for (int b = 0; b < B; ++b)
-            HIPC(launch_copy_rows(s->embeds + ((size_t)b * S + t0) * H, H, X + (size_t)b * ch * H, H, ch, H, s->stream));
+            HIPC(launch_copy_rows(s->embeds + ((size_t)b * S_all + t0) * H, H, X + (size_t)b * ch * H, H, ch, H, s->stream));
         for (int i = 0; i < d.layers; ++i) {
             const LayerW& w = m->tl[i];
             HIPC(launch_row_den(X, H, DEN, rows, H, d.eps, s->stream));
@@ -1689,6 +1689,7 @@ static q3_status prefill_gemm(q3_session* s, int S) {
             HIPC(split(dn)); HIPC(launch_lm_gemm(dn, s->stream));
         }
     }
+    if (!with_head) { HIPC(hipStreamSynchronize(s->stream)); return Q3_OK; }      // the caller runs the remaining positions
     // head on each sequence's last position (row b*ch + ch-1 of the last chunk): final norm -> LASTH, codec_head -> LOGITS
     HIPC(launch_rmsnorm(X + (size_t)(ch - 1) * H, ch * H, m->norm, s->LASTH, H, B, H, c.rms_eps, s->stream));
     LinArgs h;
@@ -1784,10 +1785,20 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     static const int gemm_min = [] { const char* e = getenv("Q3_PREFILL_GEMM_MIN"); return e ? atoi(e) : 48; }();   // 0 disables the GEMM path
     const bool tiles_ok = (d_nh_ok(c));
     const int chunk = s->no_chunk ? 1 : (16 / B > 0 ? 16 / B : 1);
+    // The GEMM path works in 128-position tiles and its grids are sized to fill the chip in whole rounds (4096
+    // positions: 256 / 512 / 1536 workgroups of 256 CUs' worth); a few positions past the last full tile would cost every
+    // GEMM another round (4105 positions: +9 ... +50 % per GEMM). Up to Q3_PREFILL_TAIL_PASSES (default 2) weight
+    // passes' worth of trailing positions therefore go through the decode-step schedule below instead (about 1 ms
+    // per pass at 4k context), which appends to the same KV cache.
+    static const int tail_passes = [] { const char* e = getenv("Q3_PREFILL_TAIL_PASSES"); return e ? atoi(e) : 2; }();
+    int t_begin = 0;
     if (!s->no_chunk && !s->debug && gemm_min > 0 && S >= gemm_min && tiles_ok) {
-        Q3C(prefill_gemm(s, S));
-    } else
-    for (int t0 = 0; t0 < S; t0 += chunk) {
+        const int r = S % 128;
+        const int Sg = (S >= 1024 && r > 0 && (r + chunk - 1) / chunk <= tail_passes) ? S - r : S;
+        Q3C(prefill_gemm(s, S, Sg, Sg == S));
+        t_begin = Sg;
+    }
+    for (int t0 = t_begin; t0 < S; t0 += chunk) {
         const int ch = (S - t0) < chunk ? (S - t0) : chunk;
         for (int b = 0; b < B; ++b)
             HIPC(launch_copy_rows(s->embeds + ((size_t)b * S + t0) * H, H, s->tb.X + (size_t)b * ch * H, H, ch, H, s->stream));

@@ -44,6 +44,8 @@ struct GemmArgs {
     // optional: x (times norm_w when set) already split into its three exact bf16 terms by launch_split_rows —
     // [3][plane_elems] bf16, row pitch Kpad. The GEMM then stages plain copies instead of redoing the split in every
     // one of its N/64 workgroup columns.
+    // The buffer must be readable for whole 128-row tiles: rows M .. ceil(M/128)*128 of every plane are fetched (any
+    // content) by the LDS-DMA geometry and never stored.
     const uint16_t* xp = nullptr; size_t xp_plane = 0;
     int n_split = 1;                                             // set by launch_lm_gemm: N range cut into this many XCD work units per M tile
 };

@@ -371,11 +371,185 @@ __global__ __launch_bounds__(256) void k_lm_gemm2(GemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third GEMM geometry (pre-split inputs, Kpad % 128 == 0): 8 waves (4 x 2), workgroup tile (256 / NW) weight rows x 128
+// activation rows, wave tile 64 x 64 as in the second geometry. What changes is the data movement:
+//   * the three activation planes of a 64-k stage go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 6 pieces of
+//     1 KB per wave and stage), no staging registers and no ds_write pass; the LDS image is lane-linear, so the
+//     bank swizzle (16-byte slot c of row r lives in slot c ^ (r & 7)) is applied to each lane's SOURCE address and
+//     again on the fragment reads: the four 16-lane groups of a ds_read_b128 then touch 16 distinct slots;
+//   * two LDS buffers (96 KB) and two register sets of weight fragments: stage s+1 is requested before the MFMAs of
+//     stage s and waited for (vmcnt(0)) after them, ONE barrier per stage instead of two;
+//   * 256 weight rows share one set of planes: per 64-k stage and CU the texture path moves 112 KB under
+//     2 x 96 MFMAs per SIMD (3072 clk) instead of 160 KB (two 128 x 128 workgroups).
+// Per accumulator the MFMA order is the second geometry's (k-step, then lo, mid, hi), so results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int G3_PLANE = 128 * 128;            // bytes per plane per buffer: 128 activation rows x 64 k x 2 B
+constexpr int G3_BUF = 3 * G3_PLANE;
+
+template <int EPI, bool RMS, int V = 1>          // V = 1: fragment reads pinned one group ahead of the MFMAs; 0 (A/B aid): hipcc's order
+__global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int RT = 4 / NW;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G3_BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keeps addresses scalar
+    const int mj = lane & 15, kg = lane >> 4;
+    const int wr = wave & 3, wc = wave >> 2;          // waves w and w + 4 (one SIMD) share their weight fragments
+    int mt, ntile;
+    {   // XCD-aware work order of the second geometry: a unit = one M tile x one n_split-th of the N tiles
+        const int nMt = (a.M + 127) / 128, nNt = a.N / (256 / NW), Q = a.n_split, per = nNt / Q;
+        const int lin = (int)blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        const int u = xcd + 8 * (j / per);
+        if (u >= nMt * Q) return;
+        mt = u / Q; ntile = (u - mt * Q) * per + j % per;
+    }
+    const int m0 = mt * 128, rt0 = ntile * (4 * RT) + wr * RT;
+    const int S = a.Kpad >> 5, nst = a.Kpad >> 6;      // nst is even (launcher: Kpad % 128 == 0)
+
+    pf32x4_t acc[NW][RT][4];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[w][r][c] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // LDS-DMA role: piece q = wave + 8 i (i < 6) is rows (q % 16) * 8 .. +8 of plane q / 16; lane l lands in 16-byte
+    // slot l of the piece = row l / 8, slot l % 8, and therefore fetches source slot (l % 8) ^ (row & 7). Rows past M
+    // are read like any other (the planes buffer holds whole 128-row tiles: GemmArgs::xp) and never stored.
+    const unsigned xoff = (unsigned)(((lane >> 3) * a.Kpad + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);     // bytes, per lane
+    const unsigned char* const xbase = reinterpret_cast<const unsigned char*>(a.xp) + (size_t)m0 * a.Kpad * 2;
+    auto stage_x = [&](int st, int buf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = wave + 8 * i, pl = q >> 4, rg = q & 15;
+            const unsigned char* src = xbase + ((size_t)pl * a.xp_plane + (size_t)rg * 8 * a.Kpad + (size_t)st * 64) * 2;   // scalar
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + xoff),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * G3_BUF + pl * G3_PLANE + rg * 1024),
+                                             16, 0, 0);
+        }
+    };
+    const unsigned char* const w1 = reinterpret_cast<const unsigned char*>(a.W) + (size_t)rt0 * S * 1024;
+    const unsigned char* const w2 = reinterpret_cast<const unsigned char*>(NW == 2 ? a.W2 : a.W) + (size_t)rt0 * S * 1024;
+    const unsigned aoff = (unsigned)lane * 16;
+    auto load_A = [&](pu32x4_t (&A)[NW][RT][2], int st) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const size_t off = ((size_t)r * S + st * 2 + ks) * 1024;                                 // scalar
+                A[0][r][ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4_t*>(w1 + off + aoff));
+                if constexpr (NW == 2) A[1][r][ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4_t*>(w2 + off + aoff));
+            }
+    };
+    // fragment reads: lane (mj, kg) of column tile c wants row wc*64 + c*16 + mj, source slot ks*4 + kg at its swizzled
+    // place; (row & 7) = mj & 7 because wc*64 + c*16 is a multiple of 8
+    const unsigned fb = (unsigned)((wc * 64 + mj) * 128);
+    const unsigned fo0 = fb + (unsigned)(((0 + kg) ^ (mj & 7)) * 16), fo1 = fb + (unsigned)(((4 + kg) ^ (mj & 7)) * 16);
+    auto load_B = [&](pu32x4_t (&B)[4], int buf, int g) {          // group g = ks * 3 + (2 - pl): k-step, then lo, mid, hi
+        const int ks = g / 3, pl = 2 - g % 3;
+        const unsigned char* p = smem + buf * G3_BUF + pl * G3_PLANE + (ks ? fo1 : fo0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) B[c] = *reinterpret_cast<const pu32x4_t*>(p + c * (16 * 128));
+    };
+    auto mfma_group = [&](const pu32x4_t (&A)[NW][RT][2], const pu32x4_t (&B)[4], int g) {
+        const int ks = g / 3;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[w][r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8_t, A[w][r][ks]),
+                                                                          __builtin_bit_cast(pbf16x8_t, B[c]), acc[w][r][c], 0, 0, 0);
+    };
+    auto compute = [&](const pu32x4_t (&A)[NW][RT][2], int buf) {
+        pu32x4_t Ba[4], Bb[4];                          // fragment reads run one group ahead of the MFMAs
+        auto pin = [] { if constexpr (V == 1) __builtin_amdgcn_sched_barrier(0); };
+        load_B(Ba, buf, 0); pin();
+        load_B(Bb, buf, 1); pin(); mfma_group(A, Ba, 0); pin();
+        load_B(Ba, buf, 2); pin(); mfma_group(A, Bb, 1); pin();
+        load_B(Bb, buf, 3); pin(); mfma_group(A, Ba, 2); pin();
+        load_B(Ba, buf, 4); pin(); mfma_group(A, Bb, 3); pin();
+        load_B(Bb, buf, 5); pin(); mfma_group(A, Ba, 4); pin();
+        mfma_group(A, Bb, 5);
+    };
+
+    pu32x4_t A0[NW][RT][2], A1[NW][RT][2];
+    stage_x(0, 0); load_A(A0, 0);
+    for (int st = 0; st < nst; st += 2) {
+        // stage st sits in buffer 0 / A0 once every wave's requests have landed; the barrier also says that every wave
+        // is done reading buffer 1 (stage st - 1), which the next requests overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage_x(st + 1, 1); load_A(A1, st + 1);
+        compute(A0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 2 < nst) { stage_x(st + 2, 0); load_A(A0, st + 2); }
+        compute(A1, 1);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int m = m0 + wc * 64 + c * 16 + mj;
+        if (m >= a.M) continue;
+        const float den = RMS ? a.den[m] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int n = (rt0 + r) * 16 + kg * 4;
+            if (n >= a.N) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[0][r][c][e];
+                float v2 = NW == 2 ? acc[NW - 1][r][c][e] : 0.0f;
+                if constexpr (RMS) { v = v / den; if constexpr (NW == 2) v2 = v2 / den; }
+                if (a.bias) v = v + a.bias[n + e];
+                if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n + e] + v;
+                if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+                if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+                o[e] = v;
+            }
+            *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.Kpad % 32 || a.K % 4 || a.K > a.Kpad || a.ldx % 4 || a.ldy % 4 || a.N % 64 || a.M < 1 || !a.W) return hipErrorInvalidValue;
     const bool rms = a.norm_w != nullptr;
     if (rms && !a.den) return hipErrorInvalidValue;
     static const bool geo1 = getenv("Q3_GEMM_GEO1") != nullptr;          // A/B aid: the 64 x 128 geometry
+    // geometry 3 (256-row workgroup tiles, LDS-DMA, one barrier per stage) when it fills the chip: one workgroup per CU,
+    // so its grid wants >= 256 workgroups; Q3_GEMM_GEO=2 / 3 forces a geometry (A/B aid, read per call)
+    if (a.xp && !geo1) {
+        const char* ge = getenv("Q3_GEMM_GEO");
+        const int force = ge ? atoi(ge) : 0;
+        const int nt3 = a.epi == EPI_SWIGLU ? 128 : 256;
+        const bool ok3 = a.Kpad % 128 == 0 && a.N % nt3 == 0;
+        const int nMt = (a.M + 127) / 128;
+        if (ok3 && force != 2 && (force == 3 || nMt * (a.N / nt3) >= 224)) {
+            static const int q_env = [] { const char* e = getenv("Q3_GEMM3_NSPLIT"); return e ? atoi(e) : 0; }();
+            const int nNt = a.N / nt3;
+            int Q = q_env > 0 ? q_env : (nNt >= 16 ? nNt / 8 : 1);
+            while (Q > 1 && nNt % Q) --Q;
+            GemmArgs b = a; b.n_split = Q;
+            const int units = nMt * Q, rounds = (units + 7) / 8;
+            dim3 g3(8 * rounds * (nNt / Q));
+            const char* ve = getenv("Q3_GEMM3_V");
+            const bool v1 = !ve || atoi(ve) == 1;          // pinned fragment prefetch: 60.4 vs 61.5 ms per 4105-position prefill
+#define Q3_GEMM3(E, R) do { if (v1) hipLaunchKernelGGL((k_lm_gemm3<E, R, 1>), g3, dim3(512), 0, st, b); else hipLaunchKernelGGL((k_lm_gemm3<E, R, 0>), g3, dim3(512), 0, st, b); } while (0)
+            switch (a.epi) {
+                case EPI_NONE: if (rms) Q3_GEMM3(EPI_NONE, true); else Q3_GEMM3(EPI_NONE, false); return hipGetLastError();
+                case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM3(EPI_RESID, false); return hipGetLastError();
+                case EPI_SILU: if (rms) return hipErrorInvalidValue; Q3_GEMM3(EPI_SILU, false); return hipGetLastError();
+                case EPI_SWIGLU: if (!rms || !a.W2) return hipErrorInvalidValue; Q3_GEMM3(EPI_SWIGLU, true); return hipGetLastError();
+                default: return hipErrorInvalidValue;
+            }
+#undef Q3_GEMM3
+        }
+    }
     if (a.xp && !geo1) {
         const int nt = a.epi == EPI_SWIGLU ? 64 : 128;
         if (a.N % nt == 0) {
