@@ -1644,6 +1644,13 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
     const bool kv_split = !no_split && !gen2_attn && S >= 1024;
     float* PART = nullptr;
     if (kv_split) HIPC(tmp.alloc(&PART, (size_t)max_rows * d.nh * 2 * PART_STRIDE));
+    // bf16-matrix-core attention (k_attn_prefill_x3) over per-layer bf16x3 planes of the cached K/V; Q3_PREFILL_ATTN_X3=0
+    // keeps the f32-MFMA generation (A/B aid, read per call)
+    const char* x3e = getenv("Q3_PREFILL_ATTN_X3");
+    const bool attn_x3 = !gen2_attn && !(x3e && atoi(x3e) == 0) && S >= 256;
+    unsigned char* KVP = nullptr;
+    const int kvp_tiles = (S + 31) / 32;
+    if (attn_x3) HIPC(tmp.alloc(&KVP, (size_t)B * d.nkv * kvp_tiles * KVP_TILE_BYTES));
     static const bool no_planes = getenv("Q3_GEMM_NO_PLANES") != nullptr;
     const bool planes = !no_planes && H % 8 == 0 && QD % 8 == 0 && I % 8 == 0;
     const int kmax = std::max(kp(H), std::max(kp(QD), kp(I)));
@@ -1674,6 +1681,10 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
             t.max_seq = s->max_seq; t.qbuf = Qb; t.part = nullptr; t.out = ATT; t.ld_out = QD;
             t.B = rows; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = 1; t.rows_per_seq = ch;
             HIPC(launch_qknorm_rope_kv(t, s->stream));
+            if (attn_x3) {
+                HIPC(launch_kv_planes(t.kcache, t.vcache, s->max_seq, B * d.nkv, t0 + ch, kvp_tiles, KVP, s->stream));
+                t.kvp = KVP; t.kvp_tiles = kvp_tiles;
+            }
             if (kv_split) { t.part = PART; t.n_splits = 2; }
             HIPC(launch_attn_prefill(t, s->stream));
             if (kv_split) HIPC(launch_attn_merge(t, s->stream));

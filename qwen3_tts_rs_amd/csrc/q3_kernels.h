@@ -80,7 +80,14 @@ struct AttnArgs {
     // multi-row steps (chunked prefill, 2-token code-predictor pass): B counts ROWS; row r belongs to sequence
     // r / rows_per_seq and sits at position base_pos(sequence) + r % rows_per_seq. 0/1 = one row per sequence.
     int rows_per_seq;
+    // prefill only: K/V of every cached position as bf16x3 planes in 32-key tiles (launch_kv_planes), kvp_tiles tiles
+    // allocated per (sequence, kv head); selects the bf16-matrix-core attention when set
+    const unsigned char* kvp = nullptr; int kvp_tiles = 0;
 };
+constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
+// planes of positions [0, n_pos) of every (sequence, kv head) pair, from the f32 cache launch_qknorm_rope_kv filled
+hipError_t launch_kv_planes(const float* kcache, const float* vcache, int max_seq, int n_pairs, int n_pos, int tiles_alloc,
+                            unsigned char* kvp, hipStream_t st);
 hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st);

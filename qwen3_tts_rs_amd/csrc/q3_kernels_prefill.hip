@@ -974,12 +974,282 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fourth generation: the same transposed flash attention on the bf16 matrix cores. The f32-input MFMA above runs at
+// the f32 VECTOR rate (157 TFLOP/s); v_mfma_f32_32x32x16_bf16 is 16x that. Every f32 operand is written as its exact
+// three-term bf16 split x = h + m + l and a product a·b is taken as the six MFMA terms
+//     ah·bh + ah·bm + am·bh + am·bm + ah·bl + al·bh          (dropped: am·bl, al·bm, al·bl <= 2^-24 |a||b|)
+// accumulated in f32 — 6/16 of the f32-MFMA time for the same ~1 ulp-of-f32 products.
+//   * K and V of the cached positions are split ONCE per layer by k_kv_planes into 32-key tiles
+//     [pair][tile][K h,m,l | Vᵀ h,m,l][8 KB]: K rows [key][128 d], V transposed [d][32 keys] with the keys of a tile in
+//     the order the S accumulator hands them to the second product (below), so both are plain 16-byte fragment reads;
+//   * workgroup = 8 waves on one (sequence, kv head, 256/NREP query rows): a K/V tile (48 KB) is staged once for 256
+//     query vectors by LDS-DMA, double-buffered, one barrier per tile (the structure of k_lm_gemm3); bank swizzles on
+//     the source side: K slot ^= key & 15, Vᵀ slot ^= (d >> 2) & 3;
+//   * Sᵀ = K·Qᵀ: Q lives in registers as its three planes (96 VGPRs); 48 MFMAs per tile and wave. Register r of the
+//     accumulator is key (r&3) + 8(r>>2) + 4·(lane/32) of query lane%32, so after the per-lane online softmax the
+//     probabilities of registers 8t .. 8t+7 ARE the B operand of k-step t of Oᵀ = Vᵀ·Pᵀ once split into planes —
+//     k_kv_planes stores V's keys in exactly that order (position p of a tile = key (p&3) + 8(2(p>>4) + ((p>>2)&1)) +
+//     4((p>>3)&1)); 48 MFMAs for the second product.
+// ------------------------------------------------------------------------------------------------
+constexpr int X3_PLANE = 32 * HEAD_DIM * 2;          // bytes of one plane of one 32-key tile
+constexpr int X3_TILE = 6 * X3_PLANE;                // K h, m, l, Vᵀ h, m, l
+typedef __attribute__((ext_vector_type(16))) float pf32x16b_t;
+
+__global__ __launch_bounds__(256) void k_kv_planes(const float* __restrict__ kcache, const float* __restrict__ vcache, int max_seq,
+                                                   int n_pos, int tiles_alloc, unsigned char* __restrict__ kvp) {
+    __shared__ float sV[32 * 129];
+    const int tile = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x;
+    const size_t cache_base = (size_t)pair * max_seq * HEAD_DIM;
+    unsigned char* dst = kvp + ((size_t)pair * tiles_alloc + tile) * X3_TILE;
+    const int key = tid >> 3, dc = (tid & 7) * 16;
+    const int p = tile * 32 + key;
+    const bool ok = p < n_pos;                                   // positions past the prompt: zeros (masked by causality anyway)
+    float kv[16], vv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float4 kf = ok ? *reinterpret_cast<const float4*>(kcache + cache_base + (size_t)p * HEAD_DIM + dc + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vf = ok ? *reinterpret_cast<const float4*>(vcache + cache_base + (size_t)p * HEAD_DIM + dc + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kv[4 * t] = kf.x; kv[4 * t + 1] = kf.y; kv[4 * t + 2] = kf.z; kv[4 * t + 3] = kf.w;
+        vv[4 * t] = vf.x; vv[4 * t + 1] = vf.y; vv[4 * t + 2] = vf.z; vv[4 * t + 3] = vf.w;
+    }
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+        pu32x4_t h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; psplit3_pair(kv[8 * h8 + 2 * e], kv[8 * h8 + 2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+        unsigned char* o = dst + key * 256 + (dc + 8 * h8) * 2;
+        *reinterpret_cast<pu32x4_t*>(o) = h;
+        *reinterpret_cast<pu32x4_t*>(o + X3_PLANE) = m;
+        *reinterpret_cast<pu32x4_t*>(o + 2 * X3_PLANE) = l;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sV[key * 129 + dc + e] = vv[e];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = tid + 256 * i, d = item >> 2, slot = item & 3;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pp = slot * 8 + e;
+            const int kk = (pp & 3) + 8 * (2 * (pp >> 4) + ((pp >> 2) & 1)) + 4 * ((pp >> 3) & 1);
+            v[e] = sV[kk * 129 + d];
+        }
+        pu32x4_t h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; psplit3_pair(v[2 * e], v[2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+        unsigned char* o = dst + 3 * X3_PLANE + d * 64 + slot * 16;
+        *reinterpret_cast<pu32x4_t*>(o) = h;
+        *reinterpret_cast<pu32x4_t*>(o + X3_PLANE) = m;
+        *reinterpret_cast<pu32x4_t*>(o + 2 * X3_PLANE) = l;
+    }
+}
+hipError_t launch_kv_planes(const float* kcache, const float* vcache, int max_seq, int n_pairs, int n_pos, int tiles_alloc,
+                            unsigned char* kvp, hipStream_t st) {
+    const int tiles = (n_pos + 31) / 32;
+    if (tiles < 1 || tiles > tiles_alloc || n_pos > max_seq) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_kv_planes, dim3(tiles, n_pairs), dim3(256), 0, st, kcache, vcache, max_seq, n_pos, tiles_alloc, kvp);
+    return hipGetLastError();
+}
+
+template <int NREP>
+__global__ __launch_bounds__(512) void k_attn_prefill_x3(AttnArgs a) {
+    constexpr int ROWS_WG = 256 / NREP;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * X3_TILE];
+    const int halves = a.n_splits == 2 ? 2 : 1;
+    int blk, half, kvh, seq, pair;
+    {   // XCD-aware 1-D grid of the third generation: a (sequence, kv head) pair is served by one XCD; long blocks first
+        const int nb = (rps_blocks(a.rows_per_seq, ROWS_WG)) * halves, npairs = (a.B / a.rows_per_seq) * a.nkv;
+        const int lin = (int)blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        pair = xcd + 8 * (j / nb);
+        if (pair >= npairs) return;
+        const int bid = nb - 1 - j % nb;
+        blk = bid / halves; half = bid - blk * halves; kvh = pair % a.nkv; seq = pair / a.nkv;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rps = a.rows_per_seq;
+    const int base_pos = a.pos_dev ? a.pos_dev[seq] : a.pos_static;
+    const int head = kvh * NREP + (wave % NREP);
+    const int r0 = blk * ROWS_WG + (wave / NREP) * 32;         // first chunk row of this wave
+    const int wg_rows = (rps - blk * ROWS_WG) < ROWS_WG ? (rps - blk * ROWS_WG) : ROWS_WG;
+    const int wg_last_pos = base_pos + blk * ROWS_WG + wg_rows - 1;
+    const int n_tiles = wg_last_pos / 32 + 1;
+    const float scale = 0.08838834764831845f;
+
+    // Q planes as the B operand: lane (query li, lk), k-step t holds d = 16t + 8·lk .. +8
+    pu32x4_t qh[8], qm[8], ql[8];
+    {
+        const int i = r0 + li;
+        const bool ok = i < rps;
+        const float* src = a.qbuf + ((size_t)(seq * rps + (ok ? i : 0)) * a.nh + head) * HEAD_DIM + lk * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float4 f0 = ok ? *reinterpret_cast<const float4*>(src + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 f1 = ok ? *reinterpret_cast<const float4*>(src + 16 * t + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t h, m, l;
+            psplit3_pair(f0.x, f0.y, h, m, l); qh[t][0] = h; qm[t][0] = m; ql[t][0] = l;
+            psplit3_pair(f0.z, f0.w, h, m, l); qh[t][1] = h; qm[t][1] = m; ql[t][1] = l;
+            psplit3_pair(f1.x, f1.y, h, m, l); qh[t][2] = h; qm[t][2] = m; ql[t][2] = l;
+            psplit3_pair(f1.z, f1.w, h, m, l); qh[t][3] = h; qm[t][3] = m; ql[t][3] = l;
+        }
+    }
+    pf32x16b_t O[4];                                           // Oᵀ tile b: register r = d 32b + (r&3) + 8(r>>2) + 4·lk of query li
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[b][r] = 0.0f;
+    float m = -INFINITY, lsum = 0.0f;
+    const int qpos = base_pos + r0 + li;
+    const int my_first_pos = base_pos + r0, my_last_pos = base_pos + r0 + 31;
+
+    // LDS-DMA role: wave w moves 1-KB block w of each of the six planes (K: keys 4w .. 4w+3, Vᵀ: d 16w .. 16w+15)
+    const unsigned char* const tiles = a.kvp + (size_t)pair * a.kvp_tiles * X3_TILE;
+    const int skey = wave * 4 + (lane >> 4), sd = wave * 16 + (lane >> 2);
+    const unsigned koff = (unsigned)(skey * 256 + (((lane & 15) ^ (skey & 15)) << 4));
+    const unsigned voff = (unsigned)(sd * 64 + (((lane & 3) ^ ((sd >> 2) & 3)) << 4));
+    auto stage = [&](int tile, int buf) {
+        const unsigned char* src = tiles + (size_t)tile * X3_TILE;                    // scalar
+        unsigned char* dst = smem + buf * X3_TILE + wave * 1024;
+#pragma unroll
+        for (int pl = 0; pl < 6; ++pl)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pl * X3_PLANE + (pl < 3 ? koff : voff)),
+                                             (__attribute__((address_space(3))) void*)(dst + pl * X3_PLANE), 16, 0, 0);
+    };
+    // fragment reads. K (A operand of Sᵀ): lane (key li, lk), k-step t: slot 2t + lk of row li, swizzled by li & 15.
+    // Vᵀ (A operand of Oᵀ): lane (d = 32b + li, lk), k-step t: slot 2t + lk of row d, swizzled by (li >> 2) & 3.
+    const unsigned kfrag = (unsigned)(li * 256), ksw = (unsigned)(li & 15);
+    const unsigned vfrag = (unsigned)(3 * X3_PLANE + li * 64), vsw = (unsigned)((li >> 2) & 3);
+
+    const int h0 = (n_tiles + 1) / 2;
+    const int t_begin = (halves == 2 && half == 1) ? h0 : 0, t_end = (halves == 2 && half == 0) ? h0 : n_tiles;
+    if (t_begin < t_end) stage(t_begin, 0);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int buf = (tile - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // this tile has landed; the other buffer's reads are done
+        if (tile + 1 < t_end) stage(tile + 1, buf ^ 1);
+        if (tile * 32 > my_last_pos) continue;                 // wave-uniform: every key of the tile is in this wave's future
+        const unsigned char* sb = smem + buf * X3_TILE;
+        pf32x16b_t S0, S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S0[r] = 0.0f; S1[r] = 0.0f; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned so = kfrag + (((unsigned)(2 * t + lk) ^ ksw) << 4);
+            const pbf16x8_t kh = __builtin_bit_cast(pbf16x8_t, *reinterpret_cast<const pu32x4_t*>(sb + so));
+            const pbf16x8_t km = __builtin_bit_cast(pbf16x8_t, *reinterpret_cast<const pu32x4_t*>(sb + X3_PLANE + so));
+            const pbf16x8_t kl = __builtin_bit_cast(pbf16x8_t, *reinterpret_cast<const pu32x4_t*>(sb + 2 * X3_PLANE + so));
+            S0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, __builtin_bit_cast(pbf16x8_t, qh[t]), S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, __builtin_bit_cast(pbf16x8_t, qm[t]), S1, 0, 0, 0);
+            S0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, __builtin_bit_cast(pbf16x8_t, qh[t]), S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, __builtin_bit_cast(pbf16x8_t, qm[t]), S1, 0, 0, 0);
+            S0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, __builtin_bit_cast(pbf16x8_t, ql[t]), S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, __builtin_bit_cast(pbf16x8_t, qh[t]), S1, 0, 0, 0);
+        }
+        // register r of this lane = (key tile·32 + (r&3) + 8(r>>2) + 4·lk, query li): scale, causal mask, online softmax
+        const bool need_mask = tile * 32 + 31 > my_first_pos;
+        float S[16];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int keypos = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            float sv = (S0[r] + S1[r]) * scale;
+            if (need_mask && keypos > qpos) sv = -INFINITY;
+            S[r] = sv; cm = fmaxf(cm, sv);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);                         // finite from tile 0 on: key 0 is visible to every query
+        const float corr = expf(m - mn);
+        float ps = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float pe = expf(S[r] - mn); S[r] = pe; ps += pe; }
+        lsum = lsum * corr + ps;
+        m = mn;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[b][r] *= corr;
+        // Pᵀ planes: registers 8t .. 8t+7 are the eight keys of k-step t this lane supplies
+        pu32x4_t ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h, mm, l;
+                psplit3_pair(S[8 * t + 2 * e], S[8 * t + 2 * e + 1], h, mm, l);
+                ph[t][e] = h; pm[t][e] = mm; pl[t][e] = l;
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp) {                   // two d tiles at a time: their MFMAs alternate accumulators
+                pbf16x8_t vh[2], vm[2], vl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned vo = vfrag + (unsigned)((2 * bp + u) * 32 * 64) + (((unsigned)(2 * t + lk) ^ vsw) << 4);
+                    vh[u] = __builtin_bit_cast(pbf16x8_t, *reinterpret_cast<const pu32x4_t*>(sb + vo));
+                    vm[u] = __builtin_bit_cast(pbf16x8_t, *reinterpret_cast<const pu32x4_t*>(sb + X3_PLANE + vo));
+                    vl[u] = __builtin_bit_cast(pbf16x8_t, *reinterpret_cast<const pu32x4_t*>(sb + 2 * X3_PLANE + vo));
+                }
+                const pbf16x8_t Ph = __builtin_bit_cast(pbf16x8_t, ph[t]), Pm = __builtin_bit_cast(pbf16x8_t, pm[t]), Pl = __builtin_bit_cast(pbf16x8_t, pl[t]);
+                pf32x16b_t& Oa = O[2 * bp]; pf32x16b_t& Ob = O[2 * bp + 1];
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[0], Ph, Oa, 0, 0, 0);    // small terms first
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[1], Ph, Ob, 0, 0, 0);
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[0], Pl, Oa, 0, 0, 0);
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[1], Pl, Ob, 0, 0, 0);
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm[0], Pm, Oa, 0, 0, 0);
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm[1], Pm, Ob, 0, 0, 0);
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm[0], Ph, Oa, 0, 0, 0);
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm[1], Ph, Ob, 0, 0, 0);
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[0], Pm, Oa, 0, 0, 0);
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[1], Pm, Ob, 0, 0, 0);
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[0], Ph, Oa, 0, 0, 0);
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[1], Ph, Ob, 0, 0, 0);
+            }
+    }
+    const float den = lsum + __shfl_xor(lsum, 32);
+    const int row = r0 + li;
+    if (row >= rps) return;
+    if (halves == 2) {                                         // partial record: O (relative to m), m, l — k_attn_merge's format
+        float* rec = a.part + (((size_t)(seq * rps + row) * a.nh + head) * 2 + half) * PART_STRIDE;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                float* o = rec + 32 * b + 8 * q4 + 4 * lk;     // PART_STRIDE = 130 floats: 8-byte aligned records only
+                *reinterpret_cast<float2*>(o) = make_float2(O[b][4 * q4], O[b][4 * q4 + 1]);
+                *reinterpret_cast<float2*>(o + 2) = make_float2(O[b][4 * q4 + 2], O[b][4 * q4 + 3]);
+            }
+        if (lk == 0) { rec[HEAD_DIM] = m; rec[HEAD_DIM + 1] = den; }
+        return;
+    }
+    float* dst = a.out + (size_t)(seq * rps + row) * a.ld_out + head * HEAD_DIM;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            *reinterpret_cast<float4*>(dst + 32 * b + 8 * q4 + 4 * lk) =
+                make_float4(O[b][4 * q4] / den, O[b][4 * q4 + 1] / den, O[b][4 * q4 + 2] / den, O[b][4 * q4 + 3] / den);
+}
+
 hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st) {
     const int nrep = a.nh / a.nkv;
     const int rps = a.rows_per_seq;
     if (rps < 1 || a.B % rps) return hipErrorInvalidValue;
     static const bool valu = getenv("Q3_PREFILL_ATTN_VALU") != nullptr;      // A/B aid: the VALU kernel
     if (!valu && (nrep == 1 || nrep == 2 || nrep == 4)) {
+        if (a.kvp) {                                              // bf16x3 generation: 256/nrep query rows per workgroup
+            const int rows_x3 = 256 / nrep;
+            const int nb = ((rps + rows_x3 - 1) / rows_x3) * ((a.n_splits == 2 && a.part) ? 2 : 1);
+            const int npairs = (a.B / rps) * a.nkv, rounds = (npairs + 7) / 8;
+            dim3 gx((unsigned)(8 * rounds) * nb);
+            if (nrep == 1) hipLaunchKernelGGL((k_attn_prefill_x3<1>), gx, dim3(512), 0, st, a);
+            else if (nrep == 2) hipLaunchKernelGGL((k_attn_prefill_x3<2>), gx, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_prefill_x3<4>), gx, dim3(512), 0, st, a);
+            return hipGetLastError();
+        }
         const int rows_wg = 128 / nrep;
         dim3 grid((rps + rows_wg - 1) / rows_wg, a.nkv, a.B / rps);
         static const bool gen2 = getenv("Q3_PREFILL_ATTN_GEN2") != nullptr;  // A/B aid: the S = Q·Kᵀ generation

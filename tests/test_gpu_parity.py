@@ -604,15 +604,15 @@ def test_streaming_continuous_mode_is_seamless(pair, chunk):
 @pytest.mark.parametrize("size", ["0.6b", "1.7b"])
 def test_full_size_gemm_prefill(size):
     """Long-prompt prefill (S >= 48: the GEMM + query-blocked attention path of q3_kernels_prefill.hip) at production
-    widths: VoiceDesign with 200 instruct tokens, two sequences of different text in one batch; last hidden state,
+    widths: VoiceDesign with 300 instruct tokens (>= 256 positions: the bf16x3 flash attention), two sequences of different text in one batch; last hidden state,
     first-token logits and 4 frames of codes against the oracle."""
     cfg = q.qwen3_tts_0_6b() if size == "0.6b" else q.qwen3_tts_1_7b()
     gm, om = model_pair(cfg, seed=synth.DEFAULT_SEED)
-    utts = [q.Utterance(synthetic_prompt(12, i), language=q.Language.German, instruct_ids=synthetic_prompt(200, 30 + i), seed=5 + i) for i in range(2)]
+    utts = [q.Utterance(synthetic_prompt(12, i), language=q.Language.German, instruct_ids=synthetic_prompt(300, 30 + i), seed=5 + i) for i in range(2)]
     opts = q.SynthesisOptions(max_length=4, seed=5, eos_token_id=None)
     s = gm.session(utts, opts, debug=False); s.prefill()
     S, _ = s.prefill_len(0)
-    assert S >= 200
+    assert S >= 300
     for b in range(2):
         osess = O.OracleSession(om, utts[b], opts)
         hid = s.get(1, (cfg.hidden,), b=b); ohid, olg = osess.prefill_out()
