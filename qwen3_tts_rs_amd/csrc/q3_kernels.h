@@ -48,6 +48,7 @@ struct GemmArgs {
     // content) by the LDS-DMA geometry and never stored.
     const uint16_t* xp = nullptr; size_t xp_plane = 0;
     int n_split = 1;                                             // set by launch_lm_gemm: N range cut into this many XCD work units per M tile
+    int sup_m = 4, sup_n = 8;                                    // set by launch_lm_gemm (third geometry): M x N tiles of the super-tile one XCD runs at a time
 };
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st);
 // planes[pl][row][k] (pitch Kpad, zero beyond K) = pl-th bf16 term of x[row][k] * (norm_w ? norm_w[k] : 1); K % 8 == 0

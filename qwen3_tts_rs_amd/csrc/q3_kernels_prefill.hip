@@ -17,6 +17,7 @@
 #include "q3_kernels.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace q3 {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void k_lm_gemm2(GemmArgs a) {
 constexpr int G3_PLANE = 128 * 128;            // bytes per plane per buffer: 128 activation rows x 64 k x 2 B
 constexpr int G3_BUF = 3 * G3_PLANE;
 
-template <int EPI, bool RMS, int V = 1>          // V = 1: fragment reads pinned one group ahead of the MFMAs; 0 (A/B aid): hipcc's order
+template <int EPI, bool RMS, int V = 2>          // schedule: 2 interleaved (below); A/B aids: 1 = fragment reads pinned one group ahead, 0 = hipcc's order
 __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int RT = 4 / NW;
@@ -397,12 +398,20 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
     const int mj = lane & 15, kg = lane >> 4;
     const int wr = wave & 3, wc = wave >> 2;          // waves w and w + 4 (one SIMD) share their weight fragments
     int mt, ntile;
-    {   // XCD-aware work order of the second geometry: a unit = one M tile x one n_split-th of the N tiles
-        const int nMt = (a.M + 127) / 128, nNt = a.N / (256 / NW), Q = a.n_split, per = nNt / Q;
+    {   // XCD-aware work order. Workgroup b runs on XCD b % 8, one workgroup per CU, so the 32 workgroups an XCD runs at
+        // a time are 32 consecutive values of b / 8. They form one SUPER-TILE of sup_m M tiles x sup_n N tiles and walk
+        // K together: per 64-k stage the XCD's L2 fetches sup_m plane pieces (48 KB each) and sup_n weight pieces
+        // (32 KB) for 32 workgroups - 448 KB at 4 x 8 - where units of one M tile x 8 N tiles (the second geometry's
+        // order) fetched 4 x 48 + 32 x 32 = 1216 KB: the four concurrent units had four different N ranges. Super-tiles
+        // go round-robin over the XCDs with the M group running fastest, so with 8 M groups an XCD keeps its M group
+        // (planes L2/MALL-warm) while it walks the N groups.
+        const int nMt = (a.M + 127) / 128, nNt = a.N / (256 / NW);
+        const int nMg = (nMt + a.sup_m - 1) / a.sup_m, nNg = (nNt + a.sup_n - 1) / a.sup_n, per = a.sup_m * a.sup_n;
         const int lin = (int)blockIdx.x, xcd = lin & 7, j = lin >> 3;
-        const int u = xcd + 8 * (j / per);
-        if (u >= nMt * Q) return;
-        mt = u / Q; ntile = (u - mt * Q) * per + j % per;
+        const int sup = xcd + 8 * (j / per), w = j % per;
+        if (sup >= nMg * nNg) return;
+        mt = (sup % nMg) * a.sup_m + w / a.sup_n; ntile = (sup / nMg) * a.sup_n + w % a.sup_n;
+        if (mt >= nMt || ntile >= nNt) return;
     }
     const int m0 = mt * 128, rt0 = ntile * (4 * RT) + wr * RT;
     const int S = a.Kpad >> 5, nst = a.Kpad >> 6;      // nst is even (launcher: Kpad % 128 == 0)
@@ -439,8 +448,8 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const size_t off = ((size_t)r * S + st * 2 + ks) * 1024;                                 // scalar
-                A[0][r][ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4_t*>(w1 + off + aoff));
-                if constexpr (NW == 2) A[1][r][ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4_t*>(w2 + off + aoff));
+                A[0][r][ks] = *reinterpret_cast<const pu32x4_t*>(w1 + off + aoff);
+                if constexpr (NW == 2) A[1][r][ks] = *reinterpret_cast<const pu32x4_t*>(w2 + off + aoff);
             }
     };
     // fragment reads: lane (mj, kg) of column tile c wants row wc*64 + c*16 + mj, source slot ks*4 + kg at its swizzled
@@ -478,6 +487,70 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
 
     pu32x4_t A0[NW][RT][2], A1[NW][RT][2];
     stage_x(0, 0); load_A(A0, 0);
+    if constexpr (V == 2) {
+        // Interleaved schedule: the barrier releases all 8 waves at once, so anything issued in a block of its own (the
+        // next stage's 6 LDS-DMA pieces and 8 weight-fragment loads, the next group's 4 fragment reads) is time in which
+        // no wave of the CU feeds the matrix cores. Here every group of 16 MFMAs is cut into 4 chunks and each chunk is
+        // followed by at most two of those instructions, which issue in the shadow of the chunk's MFMAs; all requests
+        // of the next stage are out by the middle of the current one.
+        auto step = [&](const pu32x4_t (&Ac)[NW][RT][2], pu32x4_t (&An)[NW][RT][2], int buf, int stn) {
+            pu32x4_t Ba[4], Bb[4];
+            auto read_B = [&](pu32x4_t& d, int g, int c) {
+                const int ks = g / 3, pl = 2 - g % 3;
+                d = *reinterpret_cast<const pu32x4_t*>(smem + buf * G3_BUF + pl * G3_PLANE + (ks ? fo1 : fo0) + c * (16 * 128));
+            };
+            auto piece = [&](int i) {
+                const int q = wave + 8 * i, pl = q >> 4, rg = q & 15;
+                const unsigned char* src = xbase + ((size_t)pl * a.xp_plane + (size_t)rg * 8 * a.Kpad + (size_t)stn * 64) * 2;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + xoff),
+                                                 (__attribute__((address_space(3))) void*)(smem + (buf ^ 1) * G3_BUF + pl * G3_PLANE + rg * 1024),
+                                                 16, 0, 0);
+            };
+            auto fetch_A = [&](int idx) {
+                const int w = NW == 2 ? idx >> 2 : 0, r = NW == 2 ? (idx >> 1) & 1 : idx >> 1, ks = idx & 1;
+                const size_t off = ((size_t)r * S + stn * 2 + ks) * 1024;
+                // plain (cached) loads: the sup_m workgroups of a super-tile column share these fragments through the L2
+                // (nontemporal: 49.4 instead of 46.1 ms per 4105-position prefill at 4 x 8)
+                An[w][r][ks] = *reinterpret_cast<const pu32x4_t*>((w ? w2 : w1) + off + aoff);
+            };
+            auto chunk = [&](const pu32x4_t (&B)[4], int g, int j) {          // column tile j x the wave's 4 row tiles:
+                const int ks = g / 3;                                         // needs B[j] only, read a whole group earlier
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        acc[w][r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8_t, Ac[w][r][ks]),
+                                                                              __builtin_bit_cast(pbf16x8_t, B[j]), acc[w][r][j], 0, 0, 0);
+            };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) read_B(Ba[c], 0, c);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gp = 0; gp < 3; ++gp)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int g = 2 * gp + h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (h == 0) chunk(Ba, g, j); else chunk(Bb, g, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g < 5) { if (h == 0) read_B(Bb[j], g + 1, j); else read_B(Ba[j], g + 1, j); }
+                        if (g < 3 && (j & 1) == 0) piece(2 * g + (j >> 1));
+                        if (g < 4 && (j & 1) == 1) fetch_A(2 * g + (j >> 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        };
+        for (int st = 0; st < nst; st += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            step(A0, A1, 0, st + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            step(A1, A0, 1, st + 2 < nst ? st + 2 : nst - 1);      // past the end: a spare request of the last stage, never read
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA may outlive the workgroup
+    } else
     for (int st = 0; st < nst; st += 2) {
         // stage st sits in buffer 0 / A0 once every wave's requests have landed; the barrier also says that every wave
         // is done reading buffer 1 (stage st - 1), which the next requests overwrite
@@ -530,16 +603,18 @@ hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
         const bool ok3 = a.Kpad % 128 == 0 && a.N % nt3 == 0;
         const int nMt = (a.M + 127) / 128;
         if (ok3 && force != 2 && (force == 3 || nMt * (a.N / nt3) >= 224)) {
-            static const int q_env = [] { const char* e = getenv("Q3_GEMM3_NSPLIT"); return e ? atoi(e) : 0; }();
-            const int nNt = a.N / nt3;
-            int Q = q_env > 0 ? q_env : (nNt >= 16 ? nNt / 8 : 1);
-            while (Q > 1 && nNt % Q) --Q;
-            GemmArgs b = a; b.n_split = Q;
-            const int units = nMt * Q, rounds = (units + 7) / 8;
-            dim3 g3(8 * rounds * (nNt / Q));
+            // super-tile shape: 4 x 8 when the grid fills the chip; fewer M tiles per super-tile for small problems so
+            // that every XCD still gets work (Q3_GEMM3_SUP="m,n" overrides, A/B aid)
+            const int nNt = a.N / nt3, T = nMt * nNt;
+            GemmArgs b = a;
+            b.sup_n = nNt < 8 ? nNt : 8;
+            b.sup_m = (T / 8 + b.sup_n - 1) / b.sup_n; b.sup_m = b.sup_m < 1 ? 1 : (b.sup_m > 4 ? 4 : b.sup_m);
+            if (const char* se = getenv("Q3_GEMM3_SUP")) { int m_ = 0, n_ = 0; if (sscanf(se, "%d,%d", &m_, &n_) == 2 && m_ > 0 && n_ > 0) { b.sup_m = m_; b.sup_n = n_; } }
+            const int nsup = ((nMt + b.sup_m - 1) / b.sup_m) * ((nNt + b.sup_n - 1) / b.sup_n);
+            dim3 g3((unsigned)(8 * ((nsup + 7) / 8) * b.sup_m * b.sup_n));
             const char* ve = getenv("Q3_GEMM3_V");
-            const bool v1 = !ve || atoi(ve) == 1;          // pinned fragment prefetch: 60.4 vs 61.5 ms per 4105-position prefill
-#define Q3_GEMM3(E, R) do { if (v1) hipLaunchKernelGGL((k_lm_gemm3<E, R, 1>), g3, dim3(512), 0, st, b); else hipLaunchKernelGGL((k_lm_gemm3<E, R, 0>), g3, dim3(512), 0, st, b); } while (0)
+            const int vsel = ve ? atoi(ve) : 2;            // 0 hipcc's order, 1 pinned fragment prefetch, 2 interleaved (default)
+#define Q3_GEMM3(E, R) do { if (vsel == 2) hipLaunchKernelGGL((k_lm_gemm3<E, R, 2>), g3, dim3(512), 0, st, b); else if (vsel == 1) hipLaunchKernelGGL((k_lm_gemm3<E, R, 1>), g3, dim3(512), 0, st, b); else hipLaunchKernelGGL((k_lm_gemm3<E, R, 0>), g3, dim3(512), 0, st, b); } while (0)
             switch (a.epi) {
                 case EPI_NONE: if (rms) Q3_GEMM3(EPI_NONE, true); else Q3_GEMM3(EPI_NONE, false); return hipGetLastError();
                 case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM3(EPI_RESID, false); return hipGetLastError();
