@@ -347,7 +347,8 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     // per-output-row epilogue operands (bias, layer scale, the consumer's SnakeBeta pair), fetched once per workgroup:
     // read from global inside the store loop they cannot be hoisted over the stores and cost a round trip per row
     __shared__ float s_prm[4][CO_WG];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: keeps tile / weight addresses scalar
     const int li = lane & 31, lk = lane >> 5;
     const int wco = wave % WCO, wt = wave / WCO;
     // XCD-aware tile order (1-D grid of nt x nco tiles): workgroup b runs on XCD b % 8, each XCD has its own L2, and the
@@ -418,28 +419,38 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         __syncthreads();
         // stage [W rows][32 ci] of x. Work item = (time row, channel octet): consecutive threads take consecutive rows
         // (coalesced global reads along t), 8 loads in flight, split, one 16-byte LDS store per plane.
-        for (int it = tid; it < W * 4; it += NT) {
-            const int q = it / W, tt = it - q * W;
-            const int t = t0 - halo + tt, ca = ci0 + q * 8;
-            float v[8];
-            if (t >= 0 && t < a.L && ca < a.cin) {             // cin % 8 == 0: the octet is all in or all out
+        // (Requesting all of a thread's items up front — one round trip per stage instead of one per item — changed
+        // nothing at 128 co x 128 t and cost the 96-co geometry its third wave per SIMD: 1034 -> 1368 us.)
+        // (work items = (64-row chunk, channel octet), dealt round-robin to the waves: wave-uniform, so no division by the
+        // runtime tile width and scalar channel-row addresses)
+        const int n_items = 4 * ((W + 63) >> 6);
+        for (int c = wave; c < n_items; c += WCO * WT) {
+            const int q = c & 3, tt = (c >> 2) * 64 + lane;
+            const int ca = ci0 + q * 8;
+            const bool cok = ca < a.cin;                            // cin % 8 == 0: the octet is all in or all out
+            const float* xr = a.x + (size_t)(cok ? ca : 0) * a.L;
+            const int t = t0 - halo + tt;
+            if (tt < W) {
+                float v[8];
+                if (cok && t >= 0 && t < a.L) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = a.x[(size_t)(ca + e) * a.L + t];
-                if (a.snake_a) {
+                    for (int e = 0; e < 8; ++e) v[e] = xr[(size_t)e * a.L + t];
+                    if (a.snake_a) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = snake_f(v[e], a.snake_a[ca + e], a.snake_ib[ca + e]);
+                        for (int e = 0; e < 8; ++e) v[e] = snake_f(v[e], a.snake_a[ca + e], a.snake_ib[ca + e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
                 }
-            } else {
+                cu32x4_t h, m, l;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+                for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; split3_pair(v[2 * e], v[2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+                unsigned char* row = smem + (unsigned)tt * XP + q * 16;
+                *reinterpret_cast<cu32x4_t*>(row) = h;
+                *reinterpret_cast<cu32x4_t*>(row + plane) = m;
+                *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
             }
-            cu32x4_t h, m, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; split3_pair(v[2 * e], v[2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
-            unsigned char* row = smem + (size_t)tt * XP + q * 16;
-            *reinterpret_cast<cu32x4_t*>(row) = h;
-            *reinterpret_cast<cu32x4_t*>(row + plane) = m;
-            *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
         }
         __syncthreads();
         // steps (kk, c16l) flattened; the weight fragments of step s+1 are requested before the MFMAs of step s
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
             cu32x4_t B[T_M][3];
 #pragma unroll
             for (int tm = 0; tm < T_M; ++tm) {
-                const unsigned char* bp = smem + (size_t)(wt * (32 * T_M) + tm * 32 + li + kk * a.dil) * XP + c16l * 32 + lk * 16;
+                const unsigned char* bp = smem + (unsigned)((wt * (32 * T_M) + tm * 32 + li + kk * a.dil) * XP + c16l * 32 + lk * 16);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) B[tm][pl] = *reinterpret_cast<const cu32x4_t*>(bp + pl * plane);
             }
@@ -634,6 +645,11 @@ static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) 
 template <int K>
 static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) {
     const long big_tiles = (long)((a.L + 127) / 128) * (a.cout / 128) * phases;
+    // 96- and 192-channel layers with taps: wave tiles of 128 time columns (T_M = 4) — a weight fragment serves 4 column
+    // tiles instead of 2, half the fragment traffic through the texture path per MFMA (k = 7: 1182 -> 1034 us; the
+    // 128-co geometry needs 256 VGPRs for it and loses). Q3_CONV_TM4=0: the T_M = 2 geometry (A/B aid)
+    static const int geo = [] { const char* e = getenv("Q3_CONV_TM4"); return e ? atoi(e) : 1; }();
+    if (geo && K >= 2 && a.L >= 4096 && (a.cout == 192 || a.cout == 96)) return launch_bf16x3_v<K, 1, 4, 3, 1>(a, phases, st);
     // 1x1 convs with a residual (second conv of every residual unit) are bound by their epilogue traffic, not by x
     // staging: the single-co-tile 64 co x 128 t geometry with batched residual loads wins at every width
     if (K == 1 && a.resid && a.cout % 64 == 0 && a.cout != 96 && big_tiles >= 192) return launch_bf16x3_v<K, 1, 2, 2, 2>(a, phases, st);
