@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void k_attn_merge2(AttnArgs a) {
 }
 
 hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st) {
-    if (a.n_splits == 2 && (long)a.B * a.nh >= 4096 && a.ld_out % 2 == 0) {
+    if (a.n_splits == 2 && a.ld_out % 2 == 0) {       // every two-record merge, whatever its size: a prompt prefilled in one pass or in several gets the same bits
         hipLaunchKernelGGL(k_attn_merge2, dim3((unsigned)(((long)a.B * a.nh + 3) / 4)), dim3(256), 0, st, a);
         return hipGetLastError();
     }

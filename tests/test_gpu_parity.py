@@ -648,6 +648,35 @@ def test_full_size_gemm_prefill(size):
 
 
 @pytest.mark.gpu
+def test_long_prompt_batch_equals_single():
+    """Two 2111-position prompts in one session (0.6B width): 4224-row budget => two GEMM passes per layer (2048 + 63
+    positions per sequence, the second one attending over the first one's K/V planes), then every sequence must match
+    its own batch-1 run (first logits bit for bit, codes equal) — rows of the prefill GEMMs, the bf16x3 flash attention and the 128-tile / tail
+    split are all per-sequence independent. Also a 4105-position pair: GEMM passes over 4096 positions + a 9-position
+    decode-step tail at 8 rows per sequence."""
+    gm = q.Qwen3TTS.from_synthetic(q.qwen3_tts_0_6b(), seed=synth.DEFAULT_SEED)
+    opts = q.SynthesisOptions(max_length=6, seed=3, eos_token_id=None)
+    for n_ins in (2102, 4096):
+        utts = [q.Utterance(synthetic_prompt(12, i), language=q.Language.German, instruct_ids=synthetic_prompt(n_ins, 50 + i), seed=20 + i) for i in range(2)]
+        sb = gm.session(utts, opts); sb.prefill()
+        assert sb.prefill_len(0)[0] == n_ins + 9
+        lb = [sb.get(2, (gm.config.codec_vocab,), b=b).copy() for b in range(2)]
+        sb.generate(6, use_graph=True)
+        for b in range(2):
+            s1 = gm.session([utts[b]], opts); s1.prefill()
+            l1 = s1.get(2, (gm.config.codec_vocab,), b=0)
+            # GEMM-only prefill: the same bits. With a decode-step tail the KV-split count of the decode attention is a
+            # function of the session's batch size (as in every decode step), so only the decisions must agree.
+            if n_ins == 2102: assert np.array_equal(l1, lb[b]), (n_ins, b)
+            else: assert np.abs(l1 - lb[b]).max() <= 1e-4, (n_ins, b, np.abs(l1 - lb[b]).max())
+            s1.generate(6, use_graph=False)
+            assert np.array_equal(s1.codes(0), sb.codes(b)), (n_ins, b)
+            s1.close()
+        sb.close()
+    gm.close()
+
+
+@pytest.mark.gpu
 def test_native_rccl_comm_world1(pair, tmp_path):
     """q3_dp_* (the C-ABI data-parallel boundary): RCCL resolved at run time, communicator from a
     file-shipped unique id, the arena broadcast and the timing all-gather run through real RCCL calls (world size 1 on
