@@ -339,10 +339,14 @@ __device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t
 // sequences, one wave per segment) can reproduce, so both kernels give a position the same bits.
 __host__ __device__ __forceinline__ bool conv_segmented(int k, int cin) { return k == 1 && (cin & 511) == 0; }
 
-template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false, bool SEG = false>
+// CIS = input channels per LDS stage: 32, or 128 for the 1x1 convs on 64-column tiles (with a single tap a 32-channel
+// stage is two 16-channel MFMA steps between two barriers and a global round trip).
+// LDS row pitch = CIS x 2 B + 16: an odd number of 16-byte slots, so the 16 rows of a ds_read_b128 group spread over all.
+template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false, bool SEG = false, int CIS = 32>
 __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x3(ConvDev a) {     // waves per SIMD the register budget must allow
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
+    constexpr int XPB = CIS * 2 + 16, NOCT = CIS / 8;           // LDS bytes per time row per plane; channel octets per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [3 planes][W rows][XP bytes]
     // per-output-row epilogue operands (bias, layer scale, the consumer's SnakeBeta pair), fetched once per workgroup:
     // read from global inside the store loop they cannot be hoisted over the stores and cost a round trip per row
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         s_prm[3][i] = (a.post_a && ok) ? a.post_ib[o] : 0.0f;
     }
     const int halo = (K - 1) * a.dil, W = T_WG + halo;
-    const size_t plane = (size_t)W * XP;
+    const size_t plane = (size_t)W * XPB;
     const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk) + (size_t)bz * a.wpk_phase_stride;
     const int ooff = a.ooff + bz * a.ooff_phase;
     const int nc16 = a.cin >> 4;
@@ -411,8 +415,8 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     };
     // (Requesting the NEXT stage's x into registers right after the publishing barrier, so that its round trip runs under
     // the MFMAs, was tried and lost: 24 more live VGPRs cost more than the hidden latency — 640-frame decode 30.4 -> 33 ms.)
-    for (int ci0 = 0; ci0 < a.cin; ci0 += 32) {
-        const int n16 = (a.cin - ci0) >= 32 ? 2 : 1;
+    for (int ci0 = 0; ci0 < a.cin; ci0 += CIS) {
+        const int n16 = (a.cin - ci0) >= CIS ? CIS / 16 : (a.cin - ci0) >> 4;
         // the first weight fragments of the stage do not depend on the staging: request them before the barrier
         cu32x4_t A0[CO_M][3], A1[CO_M][3];
         load_A(A0, ci0, 0, 0);
@@ -423,9 +427,9 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         // nothing at 128 co x 128 t and cost the 96-co geometry its third wave per SIMD: 1034 -> 1368 us.)
         // (work items = (64-row chunk, channel octet), dealt round-robin to the waves: wave-uniform, so no division by the
         // runtime tile width and scalar channel-row addresses)
-        const int n_items = 4 * ((W + 63) >> 6);
+        const int n_items = NOCT * ((W + 63) >> 6);
         for (int c = wave; c < n_items; c += WCO * WT) {
-            const int q = c & 3, tt = (c >> 2) * 64 + lane;
+            const int q = c % NOCT, tt = (c / NOCT) * 64 + lane;
             const int ca = ci0 + q * 8;
             const bool cok = ca < a.cin;                            // cin % 8 == 0: the octet is all in or all out
             const float* xr = a.x + (size_t)(cok ? ca : 0) * a.L;
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
                 cu32x4_t h, m, l;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; split3_pair(v[2 * e], v[2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
-                unsigned char* row = smem + (unsigned)tt * XP + q * 16;
+                unsigned char* row = smem + (unsigned)tt * XPB + q * 16;
                 *reinterpret_cast<cu32x4_t*>(row) = h;
                 *reinterpret_cast<cu32x4_t*>(row + plane) = m;
                 *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
             cu32x4_t B[T_M][3];
 #pragma unroll
             for (int tm = 0; tm < T_M; ++tm) {
-                const unsigned char* bp = smem + (unsigned)((wt * (32 * T_M) + tm * 32 + li + kk * a.dil) * XP + c16l * 32 + lk * 16);
+                const unsigned char* bp = smem + (unsigned)((wt * (32 * T_M) + tm * 32 + li + kk * a.dil) * XPB + c16l * 32 + lk * 16);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) B[tm][pl] = *reinterpret_cast<const cu32x4_t*>(bp + pl * plane);
             }
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
             if (s0 + 2 < n_steps) { const int kk = (s0 + 2) / n16; load_A(A0, ci0, kk, (s0 + 2) - kk * n16); }
             do_step(A1, s0 + 1);
         }
-        if (SEG && ((ci0 + 32) & 127) == 0) {                    // segment boundary: total += segment sum
+        if (SEG && ((ci0 + CIS) & 127) == 0) {                    // segment boundary: total += segment sum
 #pragma unroll
             for (int i = 0; i < SM; ++i)
 #pragma unroll
@@ -630,16 +634,32 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
 template <int K, int CO_M, int T_M, int WCO, int WT>
 static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
-    const size_t lds = (size_t)3 * (T_WG + (K - 1) * a.dil) * XP;
+    constexpr bool K1 = K == 1;
+    // 1x1 convs on 64-column tiles (the pre-transformer / ConvNeXt linears): 128 channels per stage, 33 -> 29 and
+    // 75 -> 68 us per launch; on 128-column tiles 64 channels per stage LOST (326 -> 476 us: the residual convs are
+    // bound by their epilogue traffic, and the bigger stage only delays it). Q3_CONV_CIS32=1: 32 everywhere (A/B aid)
+    static const bool cis32 = getenv("Q3_CONV_CIS32") != nullptr;
+    constexpr int CIS1 = T_WG <= 64 ? 128 : 32;
+    const bool wide = K1 && CIS1 > 32 && !cis32 && a.cin >= 2 * CIS1;
+    const size_t lds = (size_t)3 * (T_WG + (K - 1) * a.dil) * ((wide ? CIS1 : 32) * 2 + 16);
     dim3 grid(((a.L + T_WG - 1) / T_WG) * (a.cout / CO_WG) * phases);         // tile order: see the kernel
     ConvDev ap = a; ap.phases = phases;
-    constexpr bool K1 = K == 1;
     const bool segm = conv_segmented(a.k, a.cin);
-    if (K1 && segm) {
-        if (CO_M == 1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1, K1>), grid, dim3(64 * WCO * WT), lds, st, ap);
-        else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, false, K1>), grid, dim3(64 * WCO * WT), lds, st, ap);
-    } else if (CO_M == 1 && K1 && a.resid) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, CO_M == 1 && K1>), grid, dim3(64 * WCO * WT), lds, st, ap);
-    else hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, dim3(64 * WCO * WT), lds, st, ap);
+    const dim3 blk(64 * WCO * WT);
+    if constexpr (K1) {
+        const bool pre = CO_M == 1 && a.resid;
+#define Q3_CV(P, S, C) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, P, S, C>), grid, blk, lds, st, ap)
+        if (wide) {
+            if (segm) { if (pre) Q3_CV(CO_M == 1, true, CIS1); else Q3_CV(false, true, CIS1); }
+            else { if (pre) Q3_CV(CO_M == 1, false, CIS1); else Q3_CV(false, false, CIS1); }
+        } else {
+            if (segm) { if (pre) Q3_CV(CO_M == 1, true, 32); else Q3_CV(false, true, 32); }
+            else { if (pre) Q3_CV(CO_M == 1, false, 32); else Q3_CV(false, false, 32); }
+        }
+#undef Q3_CV
+    } else {
+        hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, blk, lds, st, ap);
+    }
     return hipGetLastError();
 }
 template <int K>
@@ -699,6 +719,43 @@ __global__ __launch_bounds__(256) void k_conv_out1(ConvDev a) {
     a.y[t] = v;
 }
 
+// the same for k = 7, dilation 1, L % 4 == 0: four consecutive outputs per thread from three aligned float4 loads per
+// channel (x[t-8 .. t+3]) instead of 28 scalar ones — the scalar kernel is bound by its 670 load instructions per output
+// (0.62 ms per 640-frame decode for a 472 MB read). Per output the same fmaf chain (channels, then taps, ascending).
+__global__ __launch_bounds__(256) void k_conv_out1_v4(ConvDev a) {
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t >= a.L) return;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < a.cin; ++c) {
+        const float* xr = a.x + (size_t)c * a.L + t;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p0 = t >= 8 ? *reinterpret_cast<const float4*>(xr - 8) : z;
+        const float4 p1 = t >= 4 ? *reinterpret_cast<const float4*>(xr - 4) : z;
+        const float4 p2 = *reinterpret_cast<const float4*>(xr);
+        float v[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+        if (a.snake_a) {
+            const float sa = a.snake_a[c], sib = a.snake_ib[c];
+#pragma unroll
+            for (int i = 2; i < 12; ++i) v[i] = snake_f(v[i], sa, sib);      // snake(0) = 0: positions before the start stay 0
+        }
+        float w[7];
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) w[kk] = a.w[(size_t)c * 7 + kk];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) acc[j] = fmaf(w[kk], v[j + kk + 2], acc[j]);
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = acc[j] + (a.b ? a.b[0] : 0.0f);
+        if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
+        o[j] = v;
+    }
+    *reinterpret_cast<float4*>(a.y + t) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
     if (c.k > CV_MAXK || (c.k - 1) * c.dil > CV_MAXHALO || c.L <= 0) return hipErrorInvalidValue;
     ConvDev a{};
@@ -708,7 +765,9 @@ hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
     a.post_a = c.post_a; a.post_ib = c.post_ib; a.y2 = c.y2;
     a.wpk = c.wpk; a.wpk_phase_stride = 0;
     if (c.cout == 1) {
-        hipLaunchKernelGGL(k_conv_out1, dim3((c.L + 255) / 256), dim3(256), 0, st, a);
+        if (c.k == 7 && c.dil == 1 && c.L % 4 == 0 && (((uintptr_t)c.x | (uintptr_t)c.y) & 15) == 0)
+            hipLaunchKernelGGL(k_conv_out1_v4, dim3((c.L / 4 + 255) / 256), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_conv_out1, dim3((c.L + 255) / 256), dim3(256), 0, st, a);
     } else if (hipError_t e = launch_conv_bf16x3(a, 1, st); e != hipErrorNotSupported) {
         return e;
     } else if (hipError_t e = launch_conv_mfma(a, 1, st); e != hipErrorNotSupported) {
