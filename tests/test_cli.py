@@ -122,7 +122,11 @@ def test_committed_bench_line_follows_the_contract():
     """The bench line committed under profiles/ (written by bench.py on the GPU box) carries every field the driver's
     contract names, with the roofline and cpu_baseline objects."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.loads(open(os.path.join(root, "profiles", "r1_bench_n1_b8.json")).read().strip().splitlines()[-1])
+    for name in ("r1_bench_n1_b8.json", "r2_bench_n1_b8.json"):
+        _check_bench_line(json.loads(open(os.path.join(root, "profiles", name)).read().strip().splitlines()[-1]))
+
+
+def _check_bench_line(d):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
