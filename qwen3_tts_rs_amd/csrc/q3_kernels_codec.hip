@@ -347,6 +347,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     constexpr int XPB = CIS * 2 + 16, NOCT = CIS / 8;           // LDS bytes per time row per plane; channel octets per stage
+    constexpr int NA = 2;                                         // ring of weight-fragment register sets (3: no faster, +24 VGPRs)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [3 planes][W rows][XP bytes]
     // per-output-row epilogue operands (bias, layer scale, the consumer's SnakeBeta pair), fetched once per workgroup:
     // read from global inside the store loop they cannot be hoisted over the stores and cost a round trip per row
@@ -418,47 +419,59 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     for (int ci0 = 0; ci0 < a.cin; ci0 += CIS) {
         const int n16 = (a.cin - ci0) >= CIS ? CIS / 16 : (a.cin - ci0) >> 4;
         // the first weight fragments of the stage do not depend on the staging: request them before the barrier
-        cu32x4_t A0[CO_M][3], A1[CO_M][3];
-        load_A(A0, ci0, 0, 0);
+        const int n_steps = K * n16;
+        cu32x4_t A[NA][CO_M][3];
+#pragma unroll
+        for (int u = 0; u < NA - 1; ++u)
+            if (u < n_steps) load_A(A[u], ci0, u / n16, u % n16);
         __syncthreads();
         // stage [W rows][32 ci] of x. Work item = (time row, channel octet): consecutive threads take consecutive rows
         // (coalesced global reads along t), 8 loads in flight, split, one 16-byte LDS store per plane.
-        // (Requesting all of a thread's items up front — one round trip per stage instead of one per item — changed
-        // nothing at 128 co x 128 t and cost the 96-co geometry its third wave per SIMD: 1034 -> 1368 us.)
-        // (work items = (64-row chunk, channel octet), dealt round-robin to the waves: wave-uniform, so no division by the
-        // runtime tile width and scalar channel-row addresses)
+        // Work items = (64-row chunk, channel octet), dealt round-robin to the waves: wave-uniform, so no division by the
+        // runtime tile width and scalar channel-row addresses. A wave's items are requested in batches of up to NB, ALL
+        // their loads unconditional (clamped addresses, zeroed by a select afterwards): a load guarded by a run-time
+        // condition makes hipcc branch around it and wait for it, one memory round trip per item.
+        constexpr int NB = 3;
         const int n_items = NOCT * ((W + 63) >> 6);
-        for (int c = wave; c < n_items; c += WCO * WT) {
-            const int q = c % NOCT, tt = (c / NOCT) * 64 + lane;
-            const int ca = ci0 + q * 8;
-            const bool cok = ca < a.cin;                            // cin % 8 == 0: the octet is all in or all out
-            const float* xr = a.x + (size_t)(cok ? ca : 0) * a.L;
-            const int t = t0 - halo + tt;
-            if (tt < W) {
-                float v[8];
-                if (cok && t >= 0 && t < a.L) {
+        for (int c0 = wave; c0 < n_items; c0 += NB * WCO * WT) {
+            float v[NB][8];
+            bool ok[NB];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = xr[(size_t)e * a.L + t];
-                    if (a.snake_a) {
+            for (int i = 0; i < NB; ++i) {
+                const int c = c0 + i * WCO * WT;
+                const int q = c % NOCT, tt = (c / NOCT) * 64 + lane;
+                const int ca = ci0 + q * 8, t = t0 - halo + tt;
+                ok[i] = c < n_items && tt < W && ca < a.cin && t >= 0 && t < a.L;     // cin % 8 == 0: the octet is all in or all out
+                const int cc = ca < a.cin ? ca : a.cin - 8, tc = t < 0 ? 0 : (t < a.L ? t : a.L - 1);
+                const float* xr = a.x + (size_t)cc * a.L + tc;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = snake_f(v[e], a.snake_a[ca + e], a.snake_ib[ca + e]);
-                    }
-                } else {
+                for (int e = 0; e < 8; ++e) v[i][e] = xr[(size_t)e * a.L];
+            }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+            for (int i = 0; i < NB; ++i) {
+                const int c = c0 + i * WCO * WT;
+                if (c >= n_items) break;                             // wave-uniform
+                const int q = c % NOCT, tt = (c / NOCT) * 64 + lane;
+                const int ca = ci0 + q * 8;
+                if (a.snake_a && ca < a.cin) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[i][e] = snake_f(v[i][e], a.snake_a[ca + e], a.snake_ib[ca + e]);
                 }
-                cu32x4_t h, m, l;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; split3_pair(v[2 * e], v[2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
-                unsigned char* row = smem + (unsigned)tt * XPB + q * 16;
-                *reinterpret_cast<cu32x4_t*>(row) = h;
-                *reinterpret_cast<cu32x4_t*>(row + plane) = m;
-                *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
+                for (int e = 0; e < 8; ++e) v[i][e] = ok[i] ? v[i][e] : 0.0f;
+                if (tt < W) {
+                    cu32x4_t h, m, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; split3_pair(v[i][2 * e], v[i][2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+                    unsigned char* row = smem + (unsigned)tt * XPB + q * 16;
+                    *reinterpret_cast<cu32x4_t*>(row) = h;
+                    *reinterpret_cast<cu32x4_t*>(row + plane) = m;
+                    *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
+                }
             }
         }
         __syncthreads();
-        // steps (kk, c16l) flattened; the weight fragments of step s+1 are requested before the MFMAs of step s
-        const int n_steps = K * n16;
+        // steps (kk, c16l) flattened; the weight fragments of step s + NA - 1 are requested before the MFMAs of step s
         auto do_step = [&](const cu32x4_t (&A)[CO_M][3], int s) {
             const int kk = s / n16, c16l = s - kk * n16;
             cu32x4_t B[T_M][3];
@@ -473,12 +486,14 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
 #pragma unroll
                 for (int tm = 0; tm < T_M; ++tm) acc[cm][tm] = mfma6(A[cm], B[tm], acc[cm][tm]);
         };
-        for (int s0 = 0; s0 < n_steps; s0 += 2) {
-            if (s0 + 1 < n_steps) { const int kk = (s0 + 1) / n16; load_A(A1, ci0, kk, (s0 + 1) - kk * n16); }
-            do_step(A0, s0);
-            if (s0 + 1 >= n_steps) break;
-            if (s0 + 2 < n_steps) { const int kk = (s0 + 2) / n16; load_A(A0, ci0, kk, (s0 + 2) - kk * n16); }
-            do_step(A1, s0 + 1);
+        for (int s0 = 0; s0 < n_steps; s0 += NA) {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int st = s0 + u, sp = st + NA - 1;           // step st runs from ring slot u; step sp is requested
+                if (st >= n_steps) break;
+                if (sp < n_steps) load_A(A[(u + NA - 1) % NA], ci0, sp / n16, sp % n16);
+                do_step(A[u], st);
+            }
         }
         if (SEG && ((ci0 + CIS) & 127) == 0) {                    // segment boundary: total += segment sum
 #pragma unroll
