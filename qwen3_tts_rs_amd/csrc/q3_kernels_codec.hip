@@ -343,11 +343,11 @@ __host__ __device__ __forceinline__ bool conv_segmented(int k, int cin) { return
 // stage is two 16-channel MFMA steps between two barriers and a global round trip).
 // LDS row pitch = CIS x 2 B + 16: an odd number of 16-byte slots, so the 16 rows of a ds_read_b128 group spread over all.
 template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false, bool SEG = false, int CIS = 32>
-__global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x3(ConvDev a) {     // waves per SIMD the register budget must allow
+__global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) void k_conv_bf16x3(ConvDev a) {     // waves per SIMD the register budget must allow
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     constexpr int XPB = CIS * 2 + 16, NOCT = CIS / 8;           // LDS bytes per time row per plane; channel octets per stage
-    constexpr int NA = 2;                                         // ring of weight-fragment register sets (3: no faster, +24 VGPRs)
+    constexpr int NA = 2;                                         // ring of weight-fragment register sets (3, two steps of prefetch: 918 -> 934 us)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [3 planes][W rows][XP bytes]
     // per-output-row epilogue operands (bias, layer scale, the consumer's SnakeBeta pair), fetched once per workgroup:
     // read from global inside the store loop they cannot be hoisted over the stores and cost a round trip per row
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
     }
     const int halo = (K - 1) * a.dil, W = T_WG + halo;
     const size_t plane = (size_t)W * XPB;
+    const unsigned plane32 = (unsigned)W * XPB, bfrag = (unsigned)((wt * (32 * T_M) + li) * XPB + lk * 16);
     const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk) + (size_t)bz * a.wpk_phase_stride;
     const int ooff = a.ooff + bz * a.ooff_phase;
     const int nc16 = a.cin >> 4;
@@ -406,12 +407,20 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
                 for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.0f;
     }
 
+    // weight fragments through a buffer descriptor: lane offset in a VGPR, tile offset in an SGPR — no address VALU per
+    // load (as 64-bit pointer arithmetic the six loads of a step cost 13 VALU instructions, six of them 64-bit multiplies,
+    // issued with the matrix pipe empty)
+    const uint64_t wpa = reinterpret_cast<uint64_t>(wpk);          // wave-uniform, but derived through VALU (tile order): tell the compiler
+    const uint64_t wpu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wpa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)wpa);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wpu), 0, 0x7fffffff, 0x00020000);
+    const int co32 = __builtin_amdgcn_readfirstlane(co0 >> 5);
     auto load_A = [&](cu32x4_t (&A)[CO_M][3], int ci0, int kk, int c16l) {
 #pragma unroll
         for (int cm = 0; cm < CO_M; ++cm) {
-            const size_t tile = ((size_t)((co0 >> 5) + cm) * K + kk) * nc16 + (ci0 >> 4) + c16l;
+            const int tile = ((co32 + cm) * K + kk) * nc16 + (ci0 >> 4) + c16l;            // < 2^21 tiles of 3 KB
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) A[cm][pl] = wpk[(tile * 3 + pl) * 64 + lane];
+            for (int pl = 0; pl < 3; ++pl)
+                A[cm][pl] = __builtin_bit_cast(cu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (tile * 3 + pl) * 1024, 0));
         }
     };
     // (Requesting the NEXT stage's x into registers right after the publishing barrier, so that its round trip runs under
@@ -421,9 +430,8 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         // the first weight fragments of the stage do not depend on the staging: request them before the barrier
         const int n_steps = K * n16;
         cu32x4_t A[NA][CO_M][3];
-#pragma unroll
-        for (int u = 0; u < NA - 1; ++u)
-            if (u < n_steps) load_A(A[u], ci0, u / n16, u % n16);
+        load_A(A[0], ci0, 0, 0);
+        if constexpr (NA == 3) load_A(A[1], ci0, (n_steps > 1 ? 1 : 0) / n16, (n_steps > 1 ? 1 : 0) % n16);
         __syncthreads();
         // stage [W rows][32 ci] of x. Work item = (time row, channel octet): consecutive threads take consecutive rows
         // (coalesced global reads along t), 8 loads in flight, split, one 16-byte LDS store per plane.
@@ -475,25 +483,49 @@ __global__ __launch_bounds__(64 * WCO * WT, CO_M == 2 ? 2 : 3) void k_conv_bf16x
         auto do_step = [&](const cu32x4_t (&A)[CO_M][3], int s) {
             const int kk = s / n16, c16l = s - kk * n16;
             cu32x4_t B[T_M][3];
+            // one VGPR add per plane and step: lane part fixed for the kernel (bfrag), step part scalar, column tiles as
+            // immediate offsets
+            const unsigned so = (unsigned)(kk * a.dil * XPB + c16l * 32);
+            const unsigned char* bp0 = smem + (bfrag + so);
+            const unsigned char* bp1 = smem + (bfrag + so + plane32);
+            const unsigned char* bp2 = smem + (bfrag + so + 2 * plane32);
 #pragma unroll
             for (int tm = 0; tm < T_M; ++tm) {
-                const unsigned char* bp = smem + (unsigned)((wt * (32 * T_M) + tm * 32 + li + kk * a.dil) * XPB + c16l * 32 + lk * 16);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) B[tm][pl] = *reinterpret_cast<const cu32x4_t*>(bp + pl * plane);
+                B[tm][0] = *reinterpret_cast<const cu32x4_t*>(bp0 + tm * (32 * XPB));
+                B[tm][1] = *reinterpret_cast<const cu32x4_t*>(bp1 + tm * (32 * XPB));
+                B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp2 + tm * (32 * XPB));
             }
 #pragma unroll
             for (int cm = 0; cm < CO_M; ++cm)
 #pragma unroll
                 for (int tm = 0; tm < T_M; ++tm) acc[cm][tm] = mfma6(A[cm], B[tm], acc[cm][tm]);
         };
-        for (int s0 = 0; s0 < n_steps; s0 += NA) {
-#pragma unroll
-            for (int u = 0; u < NA; ++u) {
-                const int st = s0 + u, sp = st + NA - 1;           // step st runs from ring slot u; step sp is requested
-                if (st >= n_steps) break;
-                if (sp < n_steps) load_A(A[(u + NA - 1) % NA], ci0, sp / n16, sp % n16);
-                do_step(A[u], st);
+        // Steps in pairs of straight-line code, the prefetch UNCONDITIONAL (index clamped: the last pair re-requests the
+        // last step). `s_waitcnt vmcnt` counts in issue order: behind a prefetch that sits in a conditional the compiler
+        // cannot know how many younger loads are in flight and waits for all of them — vmcnt(0) right after issuing the
+        // next step's fragments, i.e. no prefetch at all (skipping the in-loop fragment loads: 1030 -> 671 us).
+        const int last = n_steps - 1;
+        // (pinned: left to itself hipcc sinks the requests into the second half of the current step, where the previous
+        // fragments' registers come free — half a step of cover for an L2 round trip)
+        auto fetch = [&](cu32x4_t (&Ad)[CO_M][3], int sp) {
+            sp = sp < last ? sp : last;
+            __builtin_amdgcn_sched_barrier(0); load_A(Ad, ci0, sp / n16, sp % n16); __builtin_amdgcn_sched_barrier(0);
+        };
+        int st = 0;
+        if constexpr (NA == 3) {                                     // two steps of prefetch
+            for (; st + 2 < n_steps; st += 3) {
+                fetch(A[2], st + 2); do_step(A[0], st);
+                fetch(A[0], st + 3); do_step(A[1], st + 1);
+                fetch(A[1], st + 4); do_step(A[2], st + 2);
             }
+            if (st < n_steps) do_step(A[0], st);
+            if (st + 1 < n_steps) do_step(A[1], st + 1);
+        } else {
+            for (; st + 1 < n_steps; st += 2) {
+                fetch(A[1], st + 1); do_step(A[0], st);
+                fetch(A[0], st + 2); do_step(A[1], st + 1);
+            }
+            if (st < n_steps) do_step(A[0], st);
         }
         if (SEG && ((ci0 + CIS) & 127) == 0) {                    // segment boundary: total += segment sum
 #pragma unroll
@@ -685,6 +717,10 @@ static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) 
     // 128-co geometry needs 256 VGPRs for it and loses). Q3_CONV_TM4=0: the T_M = 2 geometry (A/B aid)
     static const int geo = [] { const char* e = getenv("Q3_CONV_TM4"); return e ? atoi(e) : 1; }();
     if (geo && K >= 2 && a.L >= 4096 && (a.cout == 192 || a.cout == 96)) return launch_bf16x3_v<K, 1, 4, 3, 1>(a, phases, st);
+    if (geo >= 2 && K >= 2 && a.L >= 4096 && a.cout % 128 == 0 && big_tiles >= 192) {      // experiment: 4 waves x (32 co x 128 / 256 t)
+        if (geo == 2) return launch_bf16x3_v<K, 1, 4, 4, 1>(a, phases, st);
+        if (geo == 3) return launch_bf16x3_v<K, 1, 8, 4, 1>(a, phases, st);
+    }
     // 1x1 convs with a residual (second conv of every residual unit) are bound by their epilogue traffic, not by x
     // staging: the single-co-tile 64 co x 128 t geometry with batched residual loads wins at every width
     if (K == 1 && a.resid && a.cout % 64 == 0 && a.cout != 96 && big_tiles >= 192) return launch_bf16x3_v<K, 1, 2, 2, 2>(a, phases, st);
