@@ -479,17 +479,20 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
     // The first two cached K/V rows of this group are requested NOW, before the q/k-norm + RoPE prologue: they depend
     // on nothing but `pos`, and their round trip then runs under the prologue instead of after its barrier (the new
     // position itself comes from LDS after the barrier, never from the just-written global memory).
+    // Every request below is UNCONDITIONAL (a position past the group's share, or the new position, reads row `start`
+    // instead and the result is dropped): `s_waitcnt vmcnt` counts in issue order, so behind a load that sits in a
+    // conditional hipcc waits for everything in flight — with the prefetch guarded, and the three register sets rotated
+    // by copies, every key cost its own memory round trip.
     const size_t base = cache_base + li * 4;
-    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk, kn = kk, vn = kk, k2 = kk, v2 = kk;
-    const int p_first = start + grp, p_second = start + grp + 8;
-    if (p_first < end && p_first != pos) {
-        kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p_first * HEAD_DIM);
-        vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p_first * HEAD_DIM);
-    }
-    if (p_second < end && p_second != pos) {
-        kn = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p_second * HEAD_DIM);
-        vn = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p_second * HEAD_DIM);
-    }
+    auto request = [&](int p, float4& ko, float4& vo) {
+        const int ps = (p < end && p != pos) ? p : 0;               // row 0 always exists
+        ko = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)ps * HEAD_DIM);
+        vo = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)ps * HEAD_DIM);
+    };
+    float4 kA, vA, kB, vB, kC, vC;
+    const int p0 = start + grp;
+    request(p0, kA, vA);
+    request(p0 + 8, kB, vB);
 
     // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v)
     for (int j = wave; j <= NREP; j += 4) {
@@ -525,21 +528,13 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
     float4 acc[NREP];
 #pragma unroll
     for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    // the K/V rows of the NEXT position of this group are requested before the current one is consumed: with 17
-    // positions at most (code predictor) a group's whole share is in flight at once instead of one round trip each
-    auto load_kv = [&](int p, float4& ko, float4& vo) {
-        if (p == pos) {
-            ko = *reinterpret_cast<const float4*>(&s_k[li * 4]);
-            vo = *reinterpret_cast<const float4*>(&s_v[li * 4]);
-        } else {
-            ko = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
-            vo = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
+    // three register sets in rotation, the loop unrolled by three so that no set is ever copied: the rows of position
+    // p + 16 are requested before position p is consumed
+    auto consume = [&](int p, float4 kk, float4 vv) {
+        if (p == pos) {                                            // the new position: from LDS
+            kk = *reinterpret_cast<const float4*>(&s_k[li * 4]);
+            vv = *reinterpret_cast<const float4*>(&s_v[li * 4]);
         }
-    };
-    if (p_first < end && p_first == pos) load_kv(p_first, kk, vv);          // the new position: from LDS
-    if (p_second < end && p_second == pos) load_kv(p_second, kn, vn);
-    for (int p = start + grp; p < end; p += 8) {
-        if (p + 16 < end) load_kv(p + 16, k2, v2);
 #pragma unroll
         for (int r = 0; r < NREP; ++r) {
             float s = q[r].x * kk.x + q[r].y * kk.y + q[r].z * kk.z + q[r].w * kk.w;
@@ -552,7 +547,13 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
             acc[r].z = acc[r].z * corr + pe * vv.z; acc[r].w = acc[r].w * corr + pe * vv.w;
             m[r] = mn;
         }
-        kk = kn; vv = vn; kn = k2; vn = v2;
+    };
+    for (int p = p0; p < end; p += 24) {
+        request(p + 16, kC, vC); consume(p, kA, vA);
+        if (p + 8 >= end) break;
+        request(p + 24, kA, vA); consume(p + 8, kB, vB);
+        if (p + 16 >= end) break;
+        request(p + 32, kB, vB); consume(p + 16, kC, vC);
     }
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
