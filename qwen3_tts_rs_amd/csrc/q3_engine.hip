@@ -1198,7 +1198,8 @@ static hipError_t run_linear(q3_session* s, const LinArgs& a) {
 
 // one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
 static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf& b, float* kc, float* vc, int max_seq,
-                          const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1, bool skip_qkv = false) {
+                          const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1, bool skip_qkv = false,
+                          const CpGatherArgs* fold = nullptr) {     // fold: this layer's attention does the pass's gather
     const q3_model* m = s->m;
     // B = number of activation ROWS of this step: one per sequence, or rows_per_seq consecutive positions per
     // sequence (chunked prefill, the code predictor's 2-token first pass)
@@ -1219,6 +1220,11 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
         HIPC(launch_attn_decode(t, s->stream));
         HIPC(launch_attn_merge(t, s->stream));
     } else {
+        if (fold) {
+            t.g_logits = fold->cp_logits; t.g_vocab = fold->cp_vocab; t.g_qkv_tab = fold->qkv_tab;
+            t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim; t.g_x = fold->out;
+            t.g_codes = fold->codes; t.g_frame_idx = fold->frame_idx; t.g_max_frames = fold->max_frames; t.g_code_slot = fold->pass - 1;
+        }
         HIPC(launch_attn_fused(t, s->stream));
         if (n_splits > 1) HIPC(launch_attn_merge(t, s->stream));
     }
@@ -1297,7 +1303,7 @@ static q3_status cp_run(q3_session* s) {
         // for the rows that carry the talker hidden state
         const bool qt = m->qkv0_tabs && s->qkv_tables && (tabs || !m->mtp_w.t1);
         const int QKVD = (d.nh + 2 * d.nkv) * HEAD_DIM;
-        bool skip0 = false;
+        bool skip0 = false, fold0 = false;
         auto qkv_rows0 = [&](int ldx, int ldy) -> q3_status {      // run-time layer-0 qkv of the B pass-0 rows
             LinArgs a;
             a.N = QKVD; a.K = CH; set_w(a, m->cl[0].qkv, B, QKVD, CH); a.x = s->cb.X; a.ldx = ldx; a.norm_w = m->cl[0].in_ln; a.eps = d.eps;
@@ -1321,7 +1327,11 @@ static q3_status cp_run(q3_session* s) {
             } else {
                 g.out = s->cb.X; g.ld_out = CH; g.proj_tab = p == 1 ? m->sem_proj : m->cp_proj[p - 2]; g.proj_dim = CH;
                 if (qt) { g.qkv_tab = p == 1 ? m->sem_qkv0 : m->cp_qkv0[p - 2]; g.qkv_dim = QKVD; g.qkv_out = s->cb.QKV; g.ld_qkv_out = QKVD; skip0 = true; }
-                HIPC(launch_cp_gather(g, s->stream));
+                // passes >= 2 with both tables: no launch of its own — the layer-0 attention re-derives the argmax and
+                // reads the table rows itself (14 launches less per frame; Q3_CP_NO_FOLD=1: the separate launch, A/B aid)
+                static const bool no_fold = getenv("Q3_CP_NO_FOLD") != nullptr;
+                fold0 = qt && p >= 2 && !s->legacy_attn && !no_fold && CH % 4 == 0;
+                if (!fold0) HIPC(launch_cp_gather(g, s->stream));
             }
         } else {
         if (rows == 2) {
@@ -1341,7 +1351,7 @@ static q3_status cp_run(q3_session* s) {
         }
         for (int i = 0; i < c.cp_layers; ++i)
             Q3C(lm_layer(s, d, m->cl[i], s->cb, s->ckcache + (size_t)i * s->ckv_layer_stride, s->cvcache + (size_t)i * s->ckv_layer_stride,
-                         n_pass + 1, nullptr, rows == 2 ? 0 : p, 1, rows, i == 0 && skip0));
+                         n_pass + 1, nullptr, rows == 2 ? 0 : p, 1, rows, i == 0 && skip0, (i == 0 && fold0) ? &g : nullptr));
         if (p >= 1) {
             LinArgs h;
             h.N = V; h.K = CH; set_w(h, m->cp_head[p - 1], B, V, CH); h.x = s->cb.X + (size_t)(rows - 1) * CH; h.ldx = rows * CH;

@@ -84,6 +84,14 @@ struct AttnArgs {
     // prefill only: K/V of every cached position as bf16x3 planes in 32-key tiles (launch_kv_planes), kvp_tiles tiles
     // allocated per (sequence, kv head); selects the bf16-matrix-core attention when set
     const unsigned char* kvp = nullptr; int kvp_tiles = 0;
+    // launch_attn_fused only — code-predictor layer 0 of a pass whose input is a table row (the folded k_cp_gather):
+    // every workgroup re-derives row = argmax(g_logits[b]) (2048 logits: cheaper than a launch) and takes q|k|v from
+    // g_qkv_tab[row] instead of qkv[b]; the (kv head 0, split 0) workgroup also records the code and copies the
+    // residual-stream row g_proj_tab[row] to g_x[b].
+    const float* g_logits = nullptr; int g_vocab = 0;
+    const float* g_qkv_tab = nullptr;
+    const float* g_proj_tab = nullptr; int g_proj_dim = 0; float* g_x = nullptr;
+    uint32_t* g_codes = nullptr; const int* g_frame_idx = nullptr; int g_max_frames = 0, g_code_slot = 0;
 };
 constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
 // planes of positions [0, n_pos) of every (sequence, kv head) pair, from the f32 cache launch_qknorm_rope_kv filled

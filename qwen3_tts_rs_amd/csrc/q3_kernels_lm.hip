@@ -494,10 +494,23 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
     request(p0, kA, vA);
     request(p0 + 8, kB, vB);
 
+    // folded gather (AttnArgs::g_*): this sequence's q|k|v row comes from the table row of the previous pass's argmax
+    const float* qkv_row = a.qkv + (size_t)b * a.ld_qkv;
+    if (a.g_logits) {
+        __shared__ float g_red_v[4]; __shared__ int g_red_i[4];
+        const int row = block_argmax_first(a.g_logits + (size_t)b * a.g_vocab, a.g_vocab, g_red_v, g_red_i);
+        qkv_row = a.g_qkv_tab + (size_t)row * a.ld_qkv;
+        if (kvh == 0 && split == 0) {
+            const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
+            float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_proj_dim);
+            for (int c = tid; c < a.g_proj_dim / 4; c += 256) pd[c] = ps[c];
+            if (tid == 0) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
+        }
+    }
     // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v)
     for (int j = wave; j <= NREP; j += 4) {
         const bool is_q = j < NREP;
-        const float* src = a.qkv + (size_t)b * a.ld_qkv + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM);
+        const float* src = qkv_row + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM);
         float x1 = src[lane], x2 = src[lane + 64];
         const float ss = wave_sum(x1 * x1 + x2 * x2);
         const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
         const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
         if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
         else {
-            const float* vs = a.qkv + (size_t)b * a.ld_qkv + QD + KD + kvh * HEAD_DIM;
+            const float* vs = qkv_row + QD + KD + kvh * HEAD_DIM;
             const float v1 = vs[lane], v2 = vs[lane + 64];
             s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
             if (split == pos / chunk) {
