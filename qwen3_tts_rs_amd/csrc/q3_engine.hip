@@ -1214,6 +1214,10 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
     if (!s->legacy_attn && rows_per_seq == 2 && !pos_dev && pos_static == 0) {
+        if (fold) {                                 // pass-1 gather folded: row 2b+1 = table row tok[b]
+            t.g_tok = fold->tok; t.g_qkv_tab = fold->qkv_tab; t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim;
+            t.g_x = fold->out; t.g_ldx = fold->ld_out;
+        }
         HIPC(launch_attn_first2(t, s->stream));    // the code predictor's 2-token first pass
     } else if (s->legacy_attn || rows_per_seq > 1) {     // rows of one sequence depend on each other's K/V: three launches
         HIPC(launch_qknorm_rope_kv(t, s->stream));
@@ -1222,7 +1226,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     } else {
         if (fold) {
             t.g_logits = fold->cp_logits; t.g_vocab = fold->cp_vocab; t.g_qkv_tab = fold->qkv_tab;
-            t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim; t.g_x = fold->out;
+            t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim; t.g_x = fold->out; t.g_ldx = fold->ld_out;
             t.g_codes = fold->codes; t.g_frame_idx = fold->frame_idx; t.g_max_frames = fold->max_frames; t.g_code_slot = fold->pass - 1;
         }
         HIPC(launch_attn_fused(t, s->stream));
@@ -1292,9 +1296,9 @@ static q3_status cp_run(q3_session* s) {
         // 1.7B with pre-projected tables: only the talker hidden state (pass 0) still goes through the 2048 -> 1024
         // projection at run time; every embedding row arrives already projected (14 GEMV launches less per frame)
         const bool tabs = m->mtp_w.t1 && m->proj_tabs && s->proj_tables;
-        auto project = [&](int M, int ldy) -> q3_status {
+        auto project = [&](int M, int ldy, const float* x_in = nullptr) -> q3_status {
             LinArgs a;
-            a.N = CH; a.K = H; set_w(a, m->mtp_w, M, CH, H); a.x = s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = ldy;
+            a.N = CH; a.K = H; set_w(a, m->mtp_w, M, CH, H); a.x = x_in ? x_in : s->CP_IN; a.ldx = H; a.bias = m->mtp_b; a.y = s->cb.X; a.ldy = ldy;
             a.M = M; a.epi = EPI_NONE;
             HIPC(run_linear(s, a));
             return Q3_OK;
@@ -1313,12 +1317,15 @@ static q3_status cp_run(q3_session* s) {
         };
         if (tabs) {
             if (rows == 2) {
-                g.pass = 0; g.out = s->CP_IN; g.ld_out = H;                       // B rows of talker hidden
-                HIPC(launch_cp_gather(g, s->stream));
-                Q3C(project(B, 2 * CH));                                           // -> cb.X rows 2b
+                // B rows of talker hidden: projected straight from LASTH (the copy to CP_IN was a launch of its own)
+                static const bool no_fold2 = getenv("Q3_CP_NO_FOLD") != nullptr;
+                if (no_fold2) { g.pass = 0; g.out = s->CP_IN; g.ld_out = H; HIPC(launch_cp_gather(g, s->stream)); }
+                Q3C(project(B, 2 * CH, no_fold2 ? s->CP_IN : s->LASTH));           // -> cb.X rows 2b
                 g.pass = 1; g.out = s->cb.X + CH; g.ld_out = 2 * CH; g.proj_tab = m->sem_proj; g.proj_dim = CH;   // rows 2b+1
                 if (qt) { g.qkv_tab = m->sem_qkv0; g.qkv_dim = QKVD; g.qkv_out = s->cb.QKV + QKVD; g.ld_qkv_out = 2 * QKVD; }
-                HIPC(launch_cp_gather(g, s->stream));
+                // the semantic row (table row tok[b]) is read by the 2-token attention itself
+                fold0 = qt && !s->legacy_attn && !no_fold2 && CH % 4 == 0;
+                if (!fold0) HIPC(launch_cp_gather(g, s->stream));
                 if (qt) { Q3C(qkv_rows0(2 * CH, 2 * QKVD)); skip0 = true; }
             } else if (p == 0) {
                 g.out = s->CP_IN; g.ld_out = H;

@@ -88,9 +88,10 @@ struct AttnArgs {
     // every workgroup re-derives row = argmax(g_logits[b]) (2048 logits: cheaper than a launch) and takes q|k|v from
     // g_qkv_tab[row] instead of qkv[b]; the (kv head 0, split 0) workgroup also records the code and copies the
     // residual-stream row g_proj_tab[row] to g_x[b].
-    const float* g_logits = nullptr; int g_vocab = 0;
+    // launch_attn_first2: row 2b+1 of sequence b is table row g_tok[b] (no argmax, no code to record).
+    const float* g_logits = nullptr; int g_vocab = 0; const uint32_t* g_tok = nullptr;
     const float* g_qkv_tab = nullptr;
-    const float* g_proj_tab = nullptr; int g_proj_dim = 0; float* g_x = nullptr;
+    const float* g_proj_tab = nullptr; int g_proj_dim = 0; float* g_x = nullptr; int g_ldx = 0;    // g_x + b * g_ldx = the sequence's residual row
     uint32_t* g_codes = nullptr; const int* g_frame_idx = nullptr; int g_max_frames = 0, g_code_slot = 0;
 };
 constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
         qkv_row = a.g_qkv_tab + (size_t)row * a.ld_qkv;
         if (kvh == 0 && split == 0) {
             const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
-            float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_proj_dim);
+            float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
             for (int c = tid; c < a.g_proj_dim / 4; c += 256) pd[c] = ps[c];
             if (tid == 0) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
         }
@@ -625,7 +625,8 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
     for (int j = wave; j < NREP + 2; j += 4) {
         const bool is_q = j < NREP;
         const int row = is_q ? 1 : j - NREP, pos = row;
-        const float* base = a.qkv + (size_t)(2 * b + row) * a.ld_qkv;
+        const float* base = (row == 1 && a.g_tok) ? a.g_qkv_tab + (size_t)a.g_tok[b] * a.ld_qkv        // folded pass-1 gather
+                                                  : a.qkv + (size_t)(2 * b + row) * a.ld_qkv;
         const float* src = base + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM);
         float x1 = src[lane], x2 = src[lane + 64];
         const float ss = wave_sum(x1 * x1 + x2 * x2);
@@ -645,6 +646,11 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
             float* vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM;
             kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
         }
+    }
+    if (a.g_tok && kvh == 0) {                                   // the semantic row of the residual stream
+        const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)a.g_tok[b] * a.g_proj_dim);
+        float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
+        for (int c = tid; c < a.g_proj_dim / 4; c += 256) pd[c] = ps[c];
     }
     __syncthreads();
     const float scale = 0.08838834764831845f;
