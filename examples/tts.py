@@ -20,10 +20,13 @@ def main(argv=None) -> int:
     ap.add_argument("--model-dir", default="test_data/model")
     ap.add_argument("--ref-audio", default="examples/data/clone_2.wav")
     ap.add_argument("--out-dir", default=".")
-    ap.add_argument("--max-length", type=int, default=None, help="cap on generated frames (synthetic checkpoints never emit EOS)")
+    ap.add_argument("--max-length", type=int, default=None, help="cap on generated frames (synthetic checkpoints rarely emit EOS)")
+    ap.add_argument("--seed", type=int, default=None, help="sampling seed for every call (default: time-based, as the reference example)")
     a = ap.parse_args(argv)
     out = lambda name: os.path.join(a.out_dir, name)
     cap = {} if a.max_length is None else {"max_length": a.max_length}
+    seedkw = {} if a.seed is None else {"seed": a.seed}
+    cap.update(seedkw)
 
     device = q.auto_device()
     print(f"Loading model from: {a.model_dir}")
@@ -41,7 +44,7 @@ def main(argv=None) -> int:
     print(f"Serena: {audio.duration():.2f}s -> output_serena.wav")
 
     # 3. custom generation options
-    options = q.SynthesisOptions(temperature=0.9, top_k=30, max_length=a.max_length or 512)
+    options = q.SynthesisOptions(temperature=0.9, top_k=30, max_length=a.max_length or 512, **seedkw)
     audio = model.synthesize_with_voice(tok.encode("Custom sampling parameters."), q.Speaker.Ryan, q.Language.English, options)
     audio.save(out("output_custom.wav"))
     print(f"Custom: {audio.duration():.2f}s -> output_custom.wav")

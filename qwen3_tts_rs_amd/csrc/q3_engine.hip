@@ -1483,9 +1483,11 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     if (s->max_seq > m->rope_len) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds the RoPE table (%d)", s->max_seq, m->rope_len);
     {
         static const int ns_env = [] { const char* e = getenv("Q3_ATTN_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid
-        // ~4 attention workgroups per CU over a 640-frame utterance (B = 8: 3.926 / 3.847 / 3.828 / 4.019 ms/frame at
-        // 4 / 8 / 16 / 32 splits; B = 16: 4.602 / 4.557 / 4.615 at 4 / 8 / 16)
-        int ns = ns_env > 0 ? ns_env : 1024 / (batch * c.n_kv_heads);
+        // ~2 attention workgroups per CU over a 640-frame utterance. With the three-deep unconditional K/V requests of
+        // k_attn_fused (round 2) a workgroup walks its keys without a round trip per key and fewer, longer key ranges
+        // win: B = 8: 3.908 / 3.724 / 3.651 / 3.609 / 3.635 / 3.812 ms/frame at 1 / 2 / 4 / 8 / 16 / 32 splits (before:
+        // 4.40 / 3.99 / 3.77 / 3.67 / 3.68); B = 1 stays at 16 (2.794 vs 2.800 at 8)
+        int ns = ns_env > 0 ? ns_env : (batch <= 2 ? 16 : 512 / (batch * c.n_kv_heads));
         // long contexts (a 4k-position prompt: 38 MB of f32 K/V per layer) want more than 16 workgroups per KV head to
         // stream them (B = 1 at 4.1k positions: 3.90 -> 3.55 ms/frame); short sessions keep the cheaper 16-way merge
         const int cap = ns_env > 0 ? MAX_SPLITS : (s->max_seq > 2048 ? MAX_SPLITS : 16);

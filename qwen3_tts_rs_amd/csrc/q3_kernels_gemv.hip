@@ -562,9 +562,9 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     for (int g = 0; g < MG; ++g) {
         const int m = g * 4 + j;
         act[g] = m < a.M;
-        xr[g] = a.x + (size_t)(act[g] ? m : 0) * a.ldx + kb * 8;
+        xr[g] = a.x + (size_t)(act[g] ? m : 0) * a.ldx;
     }
-    const float* __restrict__ nwp = RMS ? a.norm_w + kb * 8 : nullptr;
+    const float* __restrict__ nwp = RMS ? a.norm_w : nullptr;
 
     float pre_b = 0.0f, pre_r = 0.0f;     // epilogue operands requested up front (see k_gemv_mfma)
     if (tid < 16 * MG) {
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
-                const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
+                const int ko = (s * 128 + kb * 8) < a.K ? s * 128 + kb * 8 : 0;   // past K (K % 128 != 0): column 0, masked below — never past the row
 #pragma unroll
                 for (int g = 0; g < MG; ++g) {
                     xa[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko) : float4{0.f, 0.f, 0.f, 0.f};     // unused columns: no request
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
                 const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
                 wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
                 if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
-                const int ko = (s * 128 + kb * 8) < a.K ? s * 128 : 0;
+                const int ko = (s * 128 + kb * 8) < a.K ? s * 128 + kb * 8 : 0;   // past K (K % 128 != 0): column 0, masked below — never past the row
 #pragma unroll
                 for (int g = 0; g < MG; ++g) {
                     xa[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # round 2, GPU call K: decode-attention KV splits at B = 8 (is the merge launch worth its splits?)
+cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r2k; mkdir -p $O
-for ns in 1 2 4 8 16; do
+for ns in 1 2 4 8 16 32; do
   Q3_ATTN_SPLITS=$ns timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --also-batches "" --ttfa-reps 1 > $O/b_$ns.json 2> $O/b_$ns.err
   python - $ns <<'PY'
 import json, sys
