@@ -1487,7 +1487,7 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
         // k_attn_fused (round 2) a workgroup walks its keys without a round trip per key and fewer, longer key ranges
         // win: B = 8: 3.908 / 3.724 / 3.651 / 3.609 / 3.635 / 3.812 ms/frame at 1 / 2 / 4 / 8 / 16 / 32 splits (before:
         // 4.40 / 3.99 / 3.77 / 3.67 / 3.68); B = 1 stays at 16 (2.794 vs 2.800 at 8)
-        int ns = ns_env > 0 ? ns_env : (batch <= 2 ? 16 : 512 / (batch * c.n_kv_heads));
+        int ns = ns_env > 0 ? ns_env : (batch <= 2 ? 1024 : 512) / (batch * c.n_kv_heads);     // (B <= 2: up to the long-context cap below)
         // long contexts (a 4k-position prompt: 38 MB of f32 K/V per layer) want more than 16 workgroups per KV head to
         // stream them (B = 1 at 4.1k positions: 3.90 -> 3.55 ms/frame); short sessions keep the cheaper 16-way merge
         const int cap = ns_env > 0 ? MAX_SPLITS : (s->max_seq > 2048 ? MAX_SPLITS : 16);

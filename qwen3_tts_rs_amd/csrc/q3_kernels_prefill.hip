@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_lm_gemm(GemmArgs a) {
             }
         }
         __syncthreads();
-        if constexpr (PL) { if (k0 + 64 < a.Kpad) fetch_x(k0 + 64); }
+        if constexpr (PL) fetch_x(k0 + 64 < a.Kpad ? k0 + 64 : k0);      // unconditional: see k_lm_gemm2
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if ((k0 >> 5) + ks >= S) break;
@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void k_lm_gemm2(GemmArgs a) {
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<pu32x4_t*>(dst + pl * plane + q * 16) = xt[pl][q];
         }
         __syncthreads();
-        if (k0 + 64 < a.Kpad) fetch_x(k0 + 64);
+        fetch_x(k0 + 64 < a.Kpad ? k0 + 64 : k0);                // unconditional (past the end: this stage again): a prefetch
+                                                                 // in a uniform branch makes hipcc wait for ALL loads at the join
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if ((k0 >> 5) + ks >= S) break;
@@ -585,8 +586,21 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
                 o[e] = v;
             }
             *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
+            // (Writing the consumer's bf16x3 planes from this epilogue — SwiGLU output, residual stream times the next norm
+            // weight — instead of separate k_split_rows passes was built and measured: 45.3 vs 45.3 ms per 4105-position
+            // prefill; the 8-byte plane stores cost the epilogue what the split passes cost on their own.)
         }
     }
+}
+
+static bool lm_gemm_geo3(const GemmArgs& a) {
+    if (!a.xp || getenv("Q3_GEMM_GEO1")) return false;
+    const char* ge = getenv("Q3_GEMM_GEO");
+    const int force = ge ? atoi(ge) : 0;
+    const int nt3 = a.epi == EPI_SWIGLU ? 128 : 256;
+    const bool ok3 = a.Kpad % 128 == 0 && a.N % nt3 == 0;
+    const int nMt = (a.M + 127) / 128;
+    return ok3 && force != 2 && (force == 3 || nMt * (a.N / nt3) >= 224);
 }
 
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
@@ -597,12 +611,9 @@ hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
     // geometry 3 (256-row workgroup tiles, LDS-DMA, one barrier per stage) when it fills the chip: one workgroup per CU,
     // so its grid wants >= 256 workgroups; Q3_GEMM_GEO=2 / 3 forces a geometry (A/B aid, read per call)
     if (a.xp && !geo1) {
-        const char* ge = getenv("Q3_GEMM_GEO");
-        const int force = ge ? atoi(ge) : 0;
         const int nt3 = a.epi == EPI_SWIGLU ? 128 : 256;
-        const bool ok3 = a.Kpad % 128 == 0 && a.N % nt3 == 0;
         const int nMt = (a.M + 127) / 128;
-        if (ok3 && force != 2 && (force == 3 || nMt * (a.N / nt3) >= 224)) {
+        if (lm_gemm_geo3(a)) {
             // super-tile shape: 4 x 8 when the grid fills the chip; fewer M tiles per super-tile for small problems so
             // that every XCD still gets work (Q3_GEMM3_SUP="m,n" overrides, A/B aid)
             const int nNt = a.N / nt3, T = nMt * nNt;
@@ -976,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
             *reinterpret_cast<float4*>(&sV[skey * KVP + sc + 4 * t]) = vst[t];
         }
         __syncthreads();
-        if (tile + 1 < t_end) fetch(tile + 1);                 // lands under this tile's MFMAs
+        fetch(tile + 1 < t_end ? tile + 1 : tile);             // lands under this tile's MFMAs (unconditional: see k_lm_gemm2)
         if (tile * 32 > my_last_pos) continue;                 // wave-uniform: every key of the tile is in this wave's future
         pf32x16_t S;
 #pragma unroll
