@@ -1003,15 +1003,31 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayerW& L = m->dl[l];
         HIPC(launch_rmsnorm_c(Hd, L.in_ln, Nn, DH, T, c.dec_eps, st));
-        HIPC(conv1(Nn, L.q, nullptr, q, DH, QD, T, st));
-        HIPC(conv1(Nn, L.k, nullptr, k, DH, QD, T, st));
-        HIPC(conv1(Nn, L.v, nullptr, v, DH, QD, T, st));
+        // q | k | v (and gate | up below) as ONE launch when their packed weights sit back to back in the arena (they are
+        // packed in this order at finalize: concatenating A-operand tiles along the output channels is just adjacency) —
+        // 3 x 160 workgroups of 29 us each become one grid of 480; per output the same arithmetic
+        auto adjacent = [&](const float* w0, const float* w1, int cout, int cin) {
+            const char* p0 = (const char*)m->pk(w0); const char* p1 = (const char*)m->pk(w1);
+            return p0 && p1 && p1 == p0 + packed_conv_w_bytes(cout, cin, 1);
+        };
+        static const bool no_fuse_qkv = getenv("Q3_CODEC_NO_QKV_FUSE") != nullptr;      // A/B aid
+        if (!no_fuse_qkv && adjacent(L.q, L.k, QD, DH) && adjacent(L.k, L.v, QD, DH)) {
+            HIPC(conv1(Nn, L.q, nullptr, q, DH, 3 * QD, T, st));
+        } else {
+            HIPC(conv1(Nn, L.q, nullptr, q, DH, QD, T, st));
+            HIPC(conv1(Nn, L.k, nullptr, k, DH, QD, T, st));
+            HIPC(conv1(Nn, L.v, nullptr, v, DH, QD, T, st));
+        }
         HIPC(launch_rope_c(q, k, ws.cs, ws.sn, c.dec_heads, c.dec_head_dim, T, st));
         HIPC(launch_attn_c(q, k, v, ao, c.dec_heads, c.dec_head_dim, T, scale, st));
         HIPC(conv1(ao, L.o, nullptr, Hd, QD, DH, T, st, Hd, L.attn_scale));
         HIPC(launch_rmsnorm_c(Hd, L.post_ln, Nn, DH, T, c.dec_eps, st));
-        HIPC(conv1(Nn, L.gate, nullptr, g, DH, DI, T, st));
-        HIPC(conv1(Nn, L.up, nullptr, u, DH, DI, T, st));
+        if (!no_fuse_qkv && adjacent(L.gate, L.up, DI, DH)) {
+            HIPC(conv1(Nn, L.gate, nullptr, g, DH, 2 * DI, T, st));
+        } else {
+            HIPC(conv1(Nn, L.gate, nullptr, g, DH, DI, T, st));
+            HIPC(conv1(Nn, L.up, nullptr, u, DH, DI, T, st));
+        }
         HIPC(launch_silu_mul(g, u, g, (int64_t)DI * T, st));
         HIPC(conv1(g, L.down, nullptr, Hd, DI, DH, T, st, Hd, L.mlp_scale));
     }
