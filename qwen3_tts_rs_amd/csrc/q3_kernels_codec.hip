@@ -436,10 +436,11 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
         // stage [W rows][32 ci] of x. Work item = (time row, channel octet): consecutive threads take consecutive rows
         // (coalesced global reads along t), 8 loads in flight, split, one 16-byte LDS store per plane.
         // Work items = (64-row chunk, channel octet), dealt round-robin to the waves: wave-uniform, so no division by the
-        // runtime tile width and scalar channel-row addresses. A wave's items are requested in batches of up to NB, ALL
+        // runtime tile width and scalar channel-row addresses. A wave's items are requested in batches of NB, ALL
         // their loads unconditional (clamped addresses, zeroed by a select afterwards): a load guarded by a run-time
         // condition makes hipcc branch around it and wait for it, one memory round trip per item.
-        constexpr int NB = 3;
+        constexpr int NCHK = (T_WG + (K - 1) * 9 + 63) / 64, NBF = (NOCT * NCHK + WCO * WT - 1) / (WCO * WT);
+        constexpr int NB = NBF < 1 ? 1 : (NBF > 4 ? 4 : NBF);        // a wave's whole share in one batch up to dilation 9 (3 waves: 4 items)
         const int n_items = NOCT * ((W + 63) >> 6);
         for (int c0 = wave; c0 < n_items; c0 += NB * WCO * WT) {
             float v[NB][8];
