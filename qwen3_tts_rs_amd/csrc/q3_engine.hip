@@ -1697,6 +1697,9 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
         g.xp = XP; g.xp_plane = plane_elems;
         return launch_split_rows(g.x, g.ldx, g.norm_w, XP, plane_elems, g.M, g.K, g.Kpad, s->stream);
     };
+    // split-K workspace of the third GEMM geometry: small row counts only (that is where a GEMM's grid underfills the chip)
+    float* SKW = nullptr; size_t skw_bytes = 0;
+    if (planes && max_rows <= 1024) { skw_bytes = (size_t)8 * max_rows * (QD + 2 * KD > 2 * I / 4 ? QD + 2 * KD : 2 * I / 4) * sizeof(float); HIPC(tmp.alloc(&SKW, skw_bytes / sizeof(float))); }
     int ch = 0;
     for (int t0 = 0; t0 < S; t0 += C) {
         ch = (S - t0) < C ? (S - t0) : C;
@@ -1708,6 +1711,7 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
             HIPC(launch_row_den(X, H, DEN, rows, H, d.eps, s->stream));
             GemmArgs g; g.W = w.qkv.t1; g.x = X; g.ldx = H; g.norm_w = w.in_ln; g.den = DEN; g.y = QKV; g.ldy = QD + 2 * KD;
             g.M = rows; g.N = QD + 2 * KD; g.K = H; g.Kpad = kp(H); g.epi = EPI_NONE;
+            g.splitk_ws = SKW; g.splitk_ws_bytes = skw_bytes;
             HIPC(split(g)); HIPC(launch_lm_gemm(g, s->stream));
             AttnArgs t{};
             t.qkv = QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
@@ -1725,13 +1729,16 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
             if (kv_split) HIPC(launch_attn_merge(t, s->stream));
             GemmArgs o; o.W = w.o.t1; o.x = ATT; o.ldx = QD; o.resid = X; o.ldr = H; o.y = SUM; o.ldy = H;
             o.M = rows; o.N = H; o.K = QD; o.Kpad = kp(QD); o.epi = EPI_RESID;
+            o.splitk_ws = SKW; o.splitk_ws_bytes = skw_bytes;
             HIPC(split(o)); HIPC(launch_lm_gemm(o, s->stream));
             HIPC(launch_row_den(SUM, H, DEN, rows, H, d.eps, s->stream));
             GemmArgs gu; gu.W = w.gate.t1; gu.W2 = w.up.t1; gu.x = SUM; gu.ldx = H; gu.norm_w = w.post_ln; gu.den = DEN; gu.y = ACT; gu.ldy = I;
             gu.M = rows; gu.N = I; gu.K = H; gu.Kpad = kp(H); gu.epi = EPI_SWIGLU;
+            gu.splitk_ws = SKW; gu.splitk_ws_bytes = skw_bytes;
             HIPC(split(gu)); HIPC(launch_lm_gemm(gu, s->stream));
             GemmArgs dn; dn.W = w.down.t1; dn.x = ACT; dn.ldx = I; dn.resid = SUM; dn.ldr = H; dn.y = X; dn.ldy = H;
             dn.M = rows; dn.N = H; dn.K = I; dn.Kpad = kp(I); dn.epi = EPI_RESID;
+            dn.splitk_ws = SKW; dn.splitk_ws_bytes = skw_bytes;
             HIPC(split(dn)); HIPC(launch_lm_gemm(dn, s->stream));
         }
     }

@@ -48,6 +48,9 @@ struct GemmArgs {
     // content) by the LDS-DMA geometry and never stored.
     const uint16_t* xp = nullptr; size_t xp_plane = 0;
     int n_split = 1;                                             // set by launch_lm_gemm: N range cut into this many XCD work units per M tile
+    // third geometry: optional workspace for split-K partial sums (8 ranges x [gate, up] x M x N floats); set by the caller
+    float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;
+    int k_ranges = 1, k_split = 1, wg_per_split = 0;             // set by launch_lm_gemm
     int sup_m = 4, sup_n = 8;                                    // set by launch_lm_gemm (third geometry): M x N tiles of the super-tile one XCD runs at a time
 };
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st);

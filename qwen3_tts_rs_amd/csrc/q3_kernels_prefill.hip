@@ -384,12 +384,12 @@ __global__ __launch_bounds__(256) void k_lm_gemm2(GemmArgs a) {
 //     stage s and waited for (vmcnt(0)) after them, ONE barrier per stage instead of two;
 //   * 256 weight rows share one set of planes: per 64-k stage and CU the texture path moves 112 KB under
 //     2 x 96 MFMAs per SIMD (3072 clk) instead of 160 KB (two 128 x 128 workgroups).
-// Per accumulator the MFMA order is the second geometry's (k-step, then lo, mid, hi), so results are bit-identical.
+// Per accumulator the MFMA order is the second geometry's (k-step, then lo, mid, hi); K is summed in ranges (below).
 // ------------------------------------------------------------------------------------------------
 constexpr int G3_PLANE = 128 * 128;            // bytes per plane per buffer: 128 activation rows x 64 k x 2 B
 constexpr int G3_BUF = 3 * G3_PLANE;
 
-template <int EPI, bool RMS, int V = 2>          // schedule: 2 interleaved (below); A/B aids: 1 = fragment reads pinned one group ahead, 0 = hipcc's order
+template <int EPI, bool RMS>
 __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int RT = 4 / NW;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
         // (planes L2/MALL-warm) while it walks the N groups.
         const int nMt = (a.M + 127) / 128, nNt = a.N / (256 / NW);
         const int nMg = (nMt + a.sup_m - 1) / a.sup_m, nNg = (nNt + a.sup_n - 1) / a.sup_n, per = a.sup_m * a.sup_n;
-        const int lin = (int)blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        const int lin = (int)blockIdx.x % a.wg_per_split, xcd = lin & 7, j = lin >> 3;        // blockIdx / wg_per_split = K split (below)
         const int sup = xcd + 8 * (j / per), w = j % per;
         if (sup >= nMg * nNg) return;
         mt = (sup % nMg) * a.sup_m + w / a.sup_n; ntile = (sup / nMg) * a.sup_n + w % a.sup_n;
@@ -474,21 +474,50 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
                     acc[w][r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8_t, A[w][r][ks]),
                                                                           __builtin_bit_cast(pbf16x8_t, B[c]), acc[w][r][c], 0, 0, 0);
     };
-    auto compute = [&](const pu32x4_t (&A)[NW][RT][2], int buf) {
-        pu32x4_t Ba[4], Bb[4];                          // fragment reads run one group ahead of the MFMAs
-        auto pin = [] { if constexpr (V == 1) __builtin_amdgcn_sched_barrier(0); };
-        load_B(Ba, buf, 0); pin();
-        load_B(Bb, buf, 1); pin(); mfma_group(A, Ba, 0); pin();
-        load_B(Ba, buf, 2); pin(); mfma_group(A, Bb, 1); pin();
-        load_B(Bb, buf, 3); pin(); mfma_group(A, Ba, 2); pin();
-        load_B(Ba, buf, 4); pin(); mfma_group(A, Bb, 3); pin();
-        load_B(Bb, buf, 5); pin(); mfma_group(A, Ba, 4); pin();
-        mfma_group(A, Bb, 5);
+    // K RANGES. K is cut into a.k_ranges (8 when the stage count allows, else 1) contiguous ranges; each range is accumulated
+    // from zero and the range sums are added in ascending order — by this workgroup when it walks all of K (tot below),
+    // or, for small M, by k_gemm_splitk_reduce when the launcher spreads the ranges over a.k_split workgroups (split-K:
+    // a 509-position prompt gives the down projection 32 workgroups of 96 serial stages on 256 CUs). Either way an
+    // output is the same sum in the same order: a prompt gets the same bits whatever batch it is prefilled in.
+    const int R = a.k_ranges, spr = nst / R;                         // stages per range: even (launcher)
+    const int kz = (int)blockIdx.x / a.wg_per_split;
+    const int r_begin = kz * R / a.k_split, r_end = (kz + 1) * R / a.k_split;
+    const int st_begin = r_begin * spr, st_end = r_end * spr;
+    pf32x4_t tot[NW][RT][4];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tot[w][r][c] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto range_done = [&](int range) {
+        if (a.k_split == 1) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { tot[w][r][c] = tot[w][r][c] + acc[w][r][c]; acc[w][r][c] = pf32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        } else {                                                     // partial sums [range][w][m][n] for the reduce kernel
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int m = m0 + wc * 64 + c * 16 + mj;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        const int n = (rt0 + r) * 16 + kg * 4;
+                        if (m < a.M && n < a.N)
+                            *reinterpret_cast<pf32x4_t*>(a.splitk_ws + (((size_t)range * NW + w) * a.M + m) * a.N + n) = acc[w][r][c];
+                        acc[w][r][c] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        }
     };
 
     pu32x4_t A0[NW][RT][2], A1[NW][RT][2];
-    stage_x(0, 0); load_A(A0, 0);
-    if constexpr (V == 2) {
+    stage_x(st_begin, 0); load_A(A0, st_begin);
+    {
         // Interleaved schedule: the barrier releases all 8 waves at once, so anything issued in a block of its own (the
         // next stage's 6 LDS-DMA pieces and 8 weight-fragment loads, the next group's 4 fragment reads) is time in which
         // no wave of the CU feeds the matrix cores. Here every group of 16 MFMAs is cut into 4 chunks and each chunk is
@@ -542,28 +571,19 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
                     }
                 }
         };
-        for (int st = 0; st < nst; st += 2) {
+        int range = r_begin, range_end = st_begin + spr;
+        for (int st = st_begin; st < st_end; st += 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             step(A0, A1, 0, st + 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            step(A1, A0, 1, st + 2 < nst ? st + 2 : nst - 1);      // past the end: a spare request of the last stage, never read
+            step(A1, A0, 1, st + 2 < st_end ? st + 2 : st_end - 1);      // past the end: a spare request of the last stage, never read
+            if (st + 2 == range_end) { range_done(range); ++range; range_end += spr; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA may outlive the workgroup
-    } else
-    for (int st = 0; st < nst; st += 2) {
-        // stage st sits in buffer 0 / A0 once every wave's requests have landed; the barrier also says that every wave
-        // is done reading buffer 1 (stage st - 1), which the next requests overwrite
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        stage_x(st + 1, 1); load_A(A1, st + 1);
-        compute(A0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + 2 < nst) { stage_x(st + 2, 0); load_A(A0, st + 2); }
-        compute(A1, 1);
     }
+    if (a.k_split > 1) return;                                      // epilogue in k_gemm_splitk_reduce
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int m = m0 + wc * 64 + c * 16 + mj;
@@ -576,8 +596,8 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = acc[0][r][c][e];
-                float v2 = NW == 2 ? acc[NW - 1][r][c][e] : 0.0f;
+                float v = tot[0][r][c][e];
+                float v2 = NW == 2 ? tot[NW - 1][r][c][e] : 0.0f;
                 if constexpr (RMS) { v = v / den; if constexpr (NW == 2) v2 = v2 / den; }
                 if (a.bias) v = v + a.bias[n + e];
                 if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n + e] + v;
@@ -593,6 +613,37 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
     }
 }
 
+// split-K second pass: y[m][n] = epilogue(range sums added in ascending order) — the arithmetic of k_lm_gemm3's own epilogue
+template <int EPI, bool RMS>
+__global__ __launch_bounds__(256) void k_gemm_splitk_reduce(GemmArgs a) {
+    constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int n4 = a.N >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)a.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+    pf32x4_t t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        t[w] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < a.k_ranges; ++r)
+            t[w] = t[w] + *reinterpret_cast<const pf32x4_t*>(a.splitk_ws + (((size_t)r * NW + w) * a.M + m) * a.N + n);
+    }
+    const float den = RMS ? a.den[m] : 1.0f;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = t[0][e];
+        float v2 = NW == 2 ? t[NW - 1][e] : 0.0f;
+        if constexpr (RMS) { v = v / den; if constexpr (NW == 2) v2 = v2 / den; }
+        if (a.bias) v = v + a.bias[n + e];
+        if constexpr (EPI == EPI_RESID) v = a.resid[(size_t)m * a.ldr + n + e] + v;
+        if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
+        if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
+        o[e] = v;
+    }
+    *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 static bool lm_gemm_geo3(const GemmArgs& a) {
     if (!a.xp || getenv("Q3_GEMM_GEO1")) return false;
     const char* ge = getenv("Q3_GEMM_GEO");
@@ -600,7 +651,8 @@ static bool lm_gemm_geo3(const GemmArgs& a) {
     const int nt3 = a.epi == EPI_SWIGLU ? 128 : 256;
     const bool ok3 = a.Kpad % 128 == 0 && a.N % nt3 == 0;
     const int nMt = (a.M + 127) / 128;
-    return ok3 && force != 2 && (force == 3 || nMt * (a.N / nt3) >= 224);
+    (void)nMt;                                                   // any grid size: with split-K small grids fill the chip too (round 2:
+    return ok3 && force != 2;                                    //   forced geometry 3 beat geometry 2 at 200 / 500 / 1000 positions already)
 }
 
 hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
@@ -623,9 +675,26 @@ hipError_t launch_lm_gemm(const GemmArgs& a, hipStream_t st) {
             if (const char* se = getenv("Q3_GEMM3_SUP")) { int m_ = 0, n_ = 0; if (sscanf(se, "%d,%d", &m_, &n_) == 2 && m_ > 0 && n_ > 0) { b.sup_m = m_; b.sup_n = n_; } }
             const int nsup = ((nMt + b.sup_m - 1) / b.sup_m) * ((nNt + b.sup_n - 1) / b.sup_n);
             dim3 g3((unsigned)(8 * ((nsup + 7) / 8) * b.sup_m * b.sup_n));
-            const char* ve = getenv("Q3_GEMM3_V");
-            const int vsel = ve ? atoi(ve) : 2;            // 0 hipcc's order, 1 pinned fragment prefetch, 2 interleaved (default)
-#define Q3_GEMM3(E, R) do { if (vsel == 2) hipLaunchKernelGGL((k_lm_gemm3<E, R, 2>), g3, dim3(512), 0, st, b); else if (vsel == 1) hipLaunchKernelGGL((k_lm_gemm3<E, R, 1>), g3, dim3(512), 0, st, b); else hipLaunchKernelGGL((k_lm_gemm3<E, R, 0>), g3, dim3(512), 0, st, b); } while (0)
+            // K ranges and split-K (see the kernel): 8 ranges when the stage count is a multiple of 16; the ranges are
+            // spread over 2 / 4 / 8 workgroups while that still leaves the grid within one round of the chip and the
+            // partial sums fit the workspace (Q3_GEMM3_KSPLIT = forced split, A/B aid)
+            const int nst = a.Kpad >> 6;
+            b.k_ranges = (nst % 16 == 0) ? 8 : 1;
+            b.k_split = 1;
+            const int nw = a.epi == EPI_SWIGLU ? 2 : 1;
+            if (b.k_ranges == 8 && a.splitk_ws) {
+                const char* ke = getenv("Q3_GEMM3_KSPLIT");
+                int ks = 1;
+                if (ke) ks = atoi(ke);
+                else while (ks < 8 && T * ks * 2 <= 256) ks *= 2;
+                if (ks != 1 && ks != 2 && ks != 4 && ks != 8) ks = 1;
+                if ((size_t)8 * nw * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) ks = 1;
+                b.k_split = ks;
+            }
+            b.wg_per_split = (int)g3.x;
+            g3.x *= b.k_split;
+#define Q3_GEMM3(E, R) do { hipLaunchKernelGGL((k_lm_gemm3<E, R>), g3, dim3(512), 0, st, b); \
+                            if (b.k_split > 1) hipLaunchKernelGGL((k_gemm_splitk_reduce<E, R>), dim3((unsigned)(((size_t)a.M * (a.N / 4) + 255) / 256)), dim3(256), 0, st, b); } while (0)
             switch (a.epi) {
                 case EPI_NONE: if (rms) Q3_GEMM3(EPI_NONE, true); else Q3_GEMM3(EPI_NONE, false); return hipGetLastError();
                 case EPI_RESID: if (rms) return hipErrorInvalidValue; Q3_GEMM3(EPI_RESID, false); return hipGetLastError();
