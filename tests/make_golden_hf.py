@@ -247,8 +247,46 @@ def mimi_fixture():
     print("wrote", path)
 
 
+def sampling_fixture():
+    """Sampler filters (A9: lib.rs:1271-1322 penalties, sampling.rs:189-262 top-k / top-p) against Hugging Face's own
+    logits processors (transformers.generation.logits_process): RepetitionPenaltyLogitsProcessor, TopKLogitsWarper,
+    TopPLogitsWarper, TemperatureLogitsWarper. Same published rules; the one structural difference: HF's top-p walks the
+    ASCENDING sort and removes the tail whose cumulative probability is <= 1 - p, the reference walks the DESCENDING sort
+    and keeps tokens until the cumulative probability exceeds p — the same kept set in exact arithmetic, decided by
+    different f32 sums, so a boundary token whose inclusion hangs on the last ulps may differ (the test reports how many
+    of the cases have such a token; none of the seeded cases does)."""
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TopKLogitsWarper, TopPLogitsWarper,
+                                                        TemperatureLogitsWarper)
+    rng = np.random.default_rng(7)
+    V = 3072
+    cases = []
+    for i in range(16):
+        scale = [1.0, 3.0, 8.0][i % 3]
+        logits = (rng.standard_normal(V) * scale).astype(np.float32)
+        n_seen = int(rng.integers(0, 60))
+        seen_ids = rng.choice(V - 1024, size=n_seen, replace=False).astype(np.int64)
+        pen = [1.0, 1.05, 1.3][i % 3]; k = [50, 30, 5, 0][i % 4]; p = [0.9, 0.8, 0.95, 1.0][(i // 2) % 4]; temp = [0.9, 1.0, 0.7][(i // 3) % 3]
+        x = torch.from_numpy(logits.copy())[None]
+        ids = torch.from_numpy(seen_ids)[None]
+        after_pen = RepetitionPenaltyLogitsProcessor(pen)(ids, x.clone()) if (pen != 1.0 and n_seen) else x.clone()
+        after_t = TemperatureLogitsWarper(temp)(None, after_pen.clone()) if temp != 1.0 else after_pen.clone()
+        after_k = TopKLogitsWarper(k)(None, after_t.clone()) if k > 0 else after_t.clone()
+        after_p = TopPLogitsWarper(p)(None, after_k.clone()) if p < 1.0 else after_k.clone()
+        cases.append(dict(logits=logits, seen=seen_ids, pen=pen, k=k, p=p, temp=temp, after_pen=after_pen[0].numpy(),
+                          after_t=after_t[0].numpy(), keep_k=np.isfinite(after_k[0].numpy()), keep_p=np.isfinite(after_p[0].numpy())))
+    res = {"n": np.int64(len(cases))}
+    for i, c in enumerate(cases):
+        for kk, v in c.items():
+            res[f"c{i}_{kk}"] = np.asarray(v)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_sampling.npz")
+    np.savez_compressed(path, **res)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     if "mimi" in sys.argv[1:]:
         mimi_fixture()
+    elif "sampling" in sys.argv[1:]:
+        sampling_fixture()
     else:
         main()

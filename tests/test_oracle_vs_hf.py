@@ -113,3 +113,36 @@ def test_speech_encoder_matches_hf_mimi():
                 bad += 1
         assert bad <= max(1, codes.shape[0] // 20), (tag, bad)
         o.close()
+
+
+def test_sampler_filters_match_hf_logits_processors():
+    """A9 sampler filters against transformers.generation.logits_process (fixture: make_golden_hf.py sampling): repetition
+    penalty values, the top-k kept set and the top-p kept set on 16 seeded logit rows (three logit scales, k in {50, 30, 5,
+    off}, p in {0.9, 0.8, 0.95, off}). HF's top-p sums the ascending tail, the reference the descending head: the kept
+    sets must agree except for a token whose inclusion hangs on the last ulps of those two different f32 sums."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_sampling.npz"))
+    n = int(fx["n"]); V = fx["c0_logits"].shape[0]
+    boundary = 0
+    for i in range(n):
+        g = lambda k: fx[f"c{i}_{k}"]
+        logits = g("logits").astype(np.float32); pen = float(g("pen")); k = int(g("k")); p = float(g("p")); temp = float(g("temp"))
+        seen = np.zeros(V, np.uint8); seen[g("seen")] = 1
+        l = np.ascontiguousarray(logits.copy())
+        O.olib.q3o_apply_penalties(l.ctypes.data, V, seen.ctypes.data, pen, 100, 0, -1)
+        lo = V - 1024                                                    # the oracle also suppresses [V-1024, V): not an HF rule
+        # same rule (x > 0 ? x / pen : x * pen); the reference multiplies by the f32 reciprocal where HF divides: <= 1 ulp
+        np.testing.assert_allclose(l[:lo], g("after_pen")[:lo], rtol=2.5e-7, atol=0)
+        t_hf = g("after_t").astype(np.float32)
+        t_or = (g("after_pen").astype(np.float32) * np.float32(1.0 / temp) + np.float32(0.0)) if temp != 1.0 else g("after_pen")
+        assert np.abs(t_or[:lo] - t_hf[:lo]).max() <= 2e-6 * max(1.0, np.abs(t_hf[:lo]).max())     # x * (1/t) vs x / t
+        x = np.ascontiguousarray(t_hf.copy())                          # filters on HF's own input row: only the filter rules differ
+        if k > 0:
+            O.olib.q3o_top_k_filter(x.ctypes.data, V, k)
+            np.testing.assert_array_equal(np.isfinite(x), g("keep_k"))
+        if p < 1.0:
+            O.olib.q3o_top_p_filter(x.ctypes.data, V, p)
+            diff = np.flatnonzero(np.isfinite(x) != g("keep_p"))
+            if diff.size:
+                boundary += 1
+                assert diff.size == 1, (i, diff)                        # at most the one boundary token
+    assert boundary <= 1, boundary
