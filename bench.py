@@ -162,7 +162,7 @@ def main():
 
     # ---- roofline of the dominant kernel: the bf16-weight MFMA GEMV family (every projection of the frame) ----
     # The launch inventory is the ENGINE's: a profiled session runs a few frames and reports every distinct GEMV launch
-    # (M, N, K, epilogue, input-norm form, producer outputs, tiling) with its count per frame. Each shape is then replayed
+    # (M, N, K, epilogue, fused input norm, tiling) with its count per frame. Each shape is then replayed
     # from a hipGraph over HBM-resident weight copies and timed with HIP events on the launch stream (q3_bench_linear, mean
     # of 5 replays); achieved = Σ algorithmic weight bytes of one frame's GEMV launches ÷ Σ their launch times. The same
     # profiled frames also give the in-situ figure (event pairs around every GEMV launch of real frames, eager launches).
@@ -178,17 +178,17 @@ def main():
     sp.close()
     tot_bytes = tot_us = 0.0; launches = 0; per_shape = {}
     EPI = {0: "none", 1: "resid", 2: "silu", 3: "swiglu"}
-    for (Mr, N, K, epi, rms, produce, tiled, count) in shapes:
+    for (Mr, N, K, epi, rms, _reserved, tiled, count) in shapes:
         assert count % pf == 0, (Mr, N, K, count, pf)
         cnt = count // pf
         nb = N * K * 2 * (2 if epi == 3 else 1)
-        us = bench_linear(Mr, N, K, epi, rms, tiled=tiled, device=dev, produce=bool(produce))
-        per_shape[f"M={Mr} N={N} K={K} {EPI[epi]} norm={rms} prod={produce} tile={16 if tiled == 1 else 4}"] = \
+        us = bench_linear(Mr, N, K, epi, rms, tiled=tiled, device=dev)
+        per_shape[f"M={Mr} N={N} K={K} {EPI[epi]} norm={rms} tile={16 if tiled == 1 else 4}"] = \
             {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
         tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
     achieved = tot_bytes / tot_us / 1e3     # GB/s
     # HBM traffic per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # passes, FETCH_SIZE x2 gfx950 correction; tests/pmc_collect.sh) — PMC counters cannot be read from inside the run
+    # passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_collect.sh) — PMC counters cannot be read from inside the run
     traffic = None; pmc_path = None
     for cand in (f"r2_pmc_gemv_M{min(B, 16)}.json", f"r1_pmc_gemv_M{min(B, 16)}.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
@@ -197,7 +197,7 @@ def main():
         pmc = json.load(open(pmc_path)).get("shapes", {})
         by_dims = {(v["N"], v["K"], v["epi"]): v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc.values() if "N" in v}
         tsum = tcnt = 0.0
-        for (Mr, N, K, epi, rms, produce, tiled, count) in shapes:      # weighted by the engine's launches per frame
+        for (Mr, N, K, epi, rms, _reserved, tiled, count) in shapes:      # weighted by the engine's launches per frame
             if (N, K, epi) in by_dims:
                 tsum += by_dims[(N, K, epi)] * (count // pf); tcnt += count // pf
         if tcnt >= 0.9 * launches:

@@ -109,8 +109,11 @@ typedef struct q3_request {
      * frames [n_ref][16] (from the caller's speech encoder) and the reference transcript's token ids. With
      * both present (mode = voice clone) the talker prefill is extended by the ICL block of
      * build_icl_prompt (talker.rs:646-710, streaming overlay), repetition_penalty is floored at 1.5 and
-     * max_length capped at max(75, 6·n_text) (lib.rs:913-929), and the full-utterance decode prepends the
-     * reference frames and cuts them off again (lib.rs:1022-1041). */
+     * max_length capped at max(75, 6·n_text) (lib.rs:913-929).
+     * ref_codes ALONE (with or without the transcript) already makes the full-utterance decode of a prefilled session
+     * (q3_session_decode(b, 0, n_frames), q3_session_run) prepend the reference frames and cut their share of the samples
+     * off again, as lib.rs:1022-1041 does for any prompt that carries codes; before q3_session_prefill (no frames, the
+     * reference frames not yet on the device) the call decodes the empty range. */
     const uint32_t* ref_codes;    int32_t n_ref;
     const uint32_t* ref_text_ids; int32_t n_ref_text;
 } q3_request;
@@ -254,7 +257,8 @@ q3_status q3_session_set_profile(q3_session* s, int enable);
  * the bf16 GEMV family (the dominant kernel) */
 q3_status q3_session_profile_read(q3_session* s, double* ms, double* bytes, long* launches, int reset);
 /* the distinct GEMV launches of the frame loop since profiling was enabled (bench.py's roofline inventory): rows of 8 ints
- * {M, N, K, epilogue, input norm 0/1/2, producer outputs 0/1, tiling, count}; rows == NULL: only *n_rows */
+ * {M, N, K, epilogue, fused input RMSNorm 0/1, reserved (0), tiling, count} — exactly the arguments q3_bench_linear
+ * replays; rows == NULL: only *n_rows */
 q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap_rows, int* n_rows, int reset);
 /* µs per launch of one GEMV shape: `iters` launches over `n_copies` distinct weight buffers (HBM-resident
  * stream, not Infinity-Cache hits) replayed from one hipGraph and timed with HIP events on that stream.

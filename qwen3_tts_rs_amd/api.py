@@ -284,7 +284,7 @@ class Session:
         return ms.value, by.value, n.value
 
     def profile_shapes(self, reset: bool = True) -> List[Tuple[int, ...]]:
-        """distinct GEMV launches since set_profile(True): (M, N, K, epi, rms, produce, tiled, count)"""
+        """distinct GEMV launches since set_profile(True): (M, N, K, epi, rms 0/1, reserved 0, tiled, count)"""
         n = ctypes.c_int()
         check(lib.q3_session_profile_shapes(self._h, None, 0, ctypes.byref(n), 0))
         buf = (ctypes.c_int * (8 * max(n.value, 1)))()
@@ -710,15 +710,14 @@ def sample(logits: np.ndarray, u: np.ndarray, options: SynthesisOptions, seen: O
 
 
 def bench_linear(M: int, N: int, K: int, epi: int = 0, rms=False, tiled: int = -1, iters: int = 200,
-                 n_copies: int = 0, device: int = 0, produce: bool = False) -> float:
+                 n_copies: int = 0, device: int = 0) -> float:
     """µs per launch of one GEMV shape: mean over 5 hipGraph replays of `iters` launches cycling over HBM-resident weight
-    copies. rms: 0 / False none, 1 / True norm weight applied in the kernel, 2 pre-normed input; produce: the launch
-    also writes the producer-side RMSNorm outputs."""
+    copies. rms: fused input RMSNorm (norm weight applied in the kernel) or none."""
     nbytes = N * K * 2 * (2 if epi == 3 else 1)
     if n_copies <= 0:
         n_copies = max(2, int(600e6 // nbytes))
     us = ctypes.c_double()
-    check(lib.q3_bench_linear(device, M, N, K, epi | (16 if produce else 0), int(rms), tiled, iters, n_copies, ctypes.byref(us)))
+    check(lib.q3_bench_linear(device, M, N, K, epi, 1 if rms else 0, tiled, iters, n_copies, ctypes.byref(us)))
     return us.value
 
 

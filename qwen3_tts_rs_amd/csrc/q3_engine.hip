@@ -1006,11 +1006,16 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
         // q | k | v (and gate | up below) as ONE launch when their packed weights sit back to back in the arena (they are
         // packed in this order at finalize: concatenating A-operand tiles along the output channels is just adjacency) —
         // 3 x 160 workgroups of 29 us each become one grid of 480; per output the same arithmetic
+        // Only the bf16x3 kernel reads the packed images; its fallbacks (Q3_CONV_F32 / Q3_CONV_VALU A/B switches, shapes
+        // outside its divisibility rules) read the f32 tensor of ONE projection, so the fusion is tied to that path and to
+        // the f32 tensors being adjacent as well (a fallback would otherwise run past the end of L.q / L.gate).
         auto adjacent = [&](const float* w0, const float* w1, int cout, int cin) {
             const char* p0 = (const char*)m->pk(w0); const char* p1 = (const char*)m->pk(w1);
-            return p0 && p1 && p1 == p0 + packed_conv_w_bytes(cout, cin, 1);
+            return p0 && p1 && p1 == p0 + packed_conv_w_bytes(cout, cin, 1) && w1 == w0 + (size_t)cout * cin &&
+                   cout % 32 == 0 && cin % 16 == 0;
         };
-        static const bool no_fuse_qkv = getenv("Q3_CODEC_NO_QKV_FUSE") != nullptr;      // A/B aid
+        static const bool no_fuse_qkv = getenv("Q3_CODEC_NO_QKV_FUSE") != nullptr || getenv("Q3_CONV_F32") != nullptr ||
+                                        getenv("Q3_CONV_VALU") != nullptr;      // A/B aids
         if (!no_fuse_qkv && adjacent(L.q, L.k, QD, DH) && adjacent(L.k, L.v, QD, DH)) {
             HIPC(conv1(Nn, L.q, nullptr, q, DH, 3 * QD, T, st));
         } else {
@@ -1179,14 +1184,32 @@ struct q3_session {
     bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
     bool proj_tables = getenv("Q3_NO_PROJ_TABLES") == nullptr;   // A/B aid: set to project the gathered embedding on every pass
     bool qkv_tables = getenv("Q3_NO_QKV_TABLES") == nullptr;     // A/B aid: set to run the layer-0 qkv GEMV on every pass
+    bool cp_attn = getenv("Q3_NO_CP_ATTN") == nullptr;        // A/B aid: set to run the code predictor on the generic k_attn_fused
     bool no_chunk = getenv("Q3_NO_CHUNK") != nullptr;         // A/B aid: one position per prefill step, 16-pass code predictor
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
     std::vector<hipEvent_t> prof_pool; size_t prof_pool_next = 0;
     std::vector<ProfShape> prof_shapes;
+#ifdef Q3_TRACE
+    // development builds only (q3_kernels.h, Q3_TRACE): per-node stamp slices of the captured frame graph
+    unsigned long long* trace_buf = nullptr; int trace_node = 0, trace_cap = 0;
+    struct TraceMeta { int kind, a, b, c, d, e, f; };       // kind 0 linear (M, N, K, epi, rms, tiled) / 1 attn_cp / 2 attn_fused / 3 attn_merge (B, nh, splits, pos)
+    std::vector<TraceMeta> trace_meta;
+    unsigned long long* trace_next(int kind, int a, int b, int c, int d = 0, int e = 0, int f = 0) {
+        if (!trace_buf || trace_node >= trace_cap) return nullptr;
+        trace_meta.push_back({kind, a, b, c, d, e, f});
+        return trace_buf + (size_t)(trace_node++) * TRACE_NODE;
+    }
+#endif
     ~q3_session();
 };
 
-static hipError_t run_linear(q3_session* s, const LinArgs& a) {
+static hipError_t run_linear(q3_session* s, const LinArgs& a_in) {
+#ifdef Q3_TRACE
+    LinArgs a = a_in;
+    a.trace = s->trace_next(0, a.M, a.N, a.K, a.epi, a.norm_w ? 1 : 0, a.tiled);
+#else
+    const LinArgs& a = a_in;
+#endif
     if (!s->profile) return launch_linear(a, s->stream);
     // profiling: bracket the launch with event records (inside graph capture these become event-record
     // nodes, so the timestamps are taken on the GPU timeline without host launch latency in between)
@@ -1202,7 +1225,7 @@ static hipError_t run_linear(q3_session* s, const LinArgs& a) {
     hipError_t e2 = hipEventRecord(e1, s->stream);
     s->prof_events.push_back({e0, e1});
     s->prof_event_bytes.push_back((double)a.N * a.K * 2.0 * (a.epi == EPI_SWIGLU ? 2.0 : 1.0));
-    {   // launch inventory (q3_session_profile_shapes): M, N, K, epilogue, input-norm form, producer outputs, tiling
+    {   // launch inventory (q3_session_profile_shapes): M, N, K, epilogue, fused input norm, reserved, tiling
         ProfShape ps{a.M, a.N, a.K, a.epi, a.norm_w ? 1 : 0, 0, a.tiled, 1};
         bool found = false;
         for (auto& q : s->prof_shapes)
@@ -1245,8 +1268,21 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
             t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim; t.g_x = fold->out; t.g_ldx = fold->ld_out;
             t.g_codes = fold->codes; t.g_frame_idx = fold->frame_idx; t.g_max_frames = fold->max_frames; t.g_code_slot = fold->pass - 1;
         }
-        HIPC(launch_attn_fused(t, s->stream));
-        if (n_splits > 1) HIPC(launch_attn_merge(t, s->stream));
+        if (s->cp_attn && attn_cp_ok(t)) {      // <= 16 positions, static position: the code predictor
+#ifdef Q3_TRACE
+            t.trace = s->trace_next(1, t.B, t.nh, 1, t.pos_static, t.g_logits ? 1 : 0);
+#endif
+            HIPC(launch_attn_cp(t, s->stream));
+        } else {
+#ifdef Q3_TRACE
+            t.trace = s->trace_next(2, t.B, t.nh, n_splits, t.pos_static, t.g_logits ? 1 : 0);
+#endif
+            HIPC(launch_attn_fused(t, s->stream));
+#ifdef Q3_TRACE
+            if (n_splits > 1) t.trace = s->trace_next(3, t.B, t.nh, n_splits, t.pos_static);
+#endif
+            if (n_splits > 1) HIPC(launch_attn_merge(t, s->stream));
+        }
     }
     LinArgs o;
     o.N = d.H; o.K = QD; set_w(o, w.o, B, o.N, o.K); o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID;
@@ -1405,6 +1441,9 @@ static void fill_sample_args(q3_session* s, SampleArgs& a) {
 // one frame of generate_codes (lib.rs:580-652)
 static q3_status frame_launch(q3_session* s) {
     const q3_model* m = s->m; const q3_config& c = m->cfg;
+#ifdef Q3_TRACE
+    s->trace_node = 0; s->trace_meta.clear();        // every frame (and the capture) re-uses the same slices
+#endif
     Q3C(cp_run(s));
     FrameEmbedArgs f{};
     f.codec_emb = m->codec_emb; f.cp_embs = m->cp_embs_dev; f.tok = s->tok;
@@ -1840,14 +1879,17 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     const int chunk = s->no_chunk ? 1 : (16 / B > 0 ? 16 / B : 1);
     // The GEMM path works in 128-position tiles and its grids are sized to fill the chip in whole rounds (4096
     // positions: 256 / 512 / 1536 workgroups of 256 CUs' worth); a few positions past the last full tile would cost every
-    // GEMM another round (4105 positions: +9 ... +50 % per GEMM). Up to Q3_PREFILL_TAIL_PASSES (default 2) weight
-    // passes' worth of trailing positions therefore go through the decode-step schedule below instead (about 1 ms
-    // per pass at 4k context), which appends to the same KV cache.
-    static const int tail_passes = [] { const char* e = getenv("Q3_PREFILL_TAIL_PASSES"); return e ? atoi(e) : 2; }();
+    // GEMM another round (4105 positions, one sequence: +9 ... +50 % per GEMM). Up to Q3_PREFILL_TAIL (default 32)
+    // trailing positions of a >= 1024-position prompt therefore go through the decode-step schedule below instead (about
+    // 1 ms per 16 rows at 4k context), which appends to the same KV cache. The rule looks at the PROMPT only — never at the
+    // batch — so which kernels compute a given position does not depend on how many sequences are prefilled together
+    // (a batch pays ceil(B * r / 16) passes for it; positions below the cut always take the GEMM, whose bits are
+    // batch-invariant; the decode-step kernels pick their tiling by the row count of a pass, like any decode step).
+    static const int tail_max = [] { const char* e = getenv("Q3_PREFILL_TAIL"); return e ? atoi(e) : 32; }();
     int t_begin = 0;
     if (!s->no_chunk && !s->debug && gemm_min > 0 && S >= gemm_min && tiles_ok) {
         const int r = S % 128;
-        const int Sg = (S >= 1024 && r > 0 && (r + chunk - 1) / chunk <= tail_passes) ? S - r : S;
+        const int Sg = (S >= 1024 && r > 0 && r <= tail_max) ? S - r : S;
         Q3C(prefill_gemm(s, S, Sg, Sg == S));
         t_begin = Sg;
     }
@@ -1982,7 +2024,7 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
     if (f0 < 0 || f1 < f0 || f1 > s->seq[b].n_frames) return set_err(Q3_INVALID_ARG, "bad frame range [%d,%d) of %d", f0, f1, s->seq[b].n_frames);
     const int T = f1 - f0, spf = samples_per_frame(s->m->cfg);
     const SeqInfo& q = s->seq[b];
-    if (!q.ref_codes.empty() && f0 == 0 && f1 == q.n_frames) {
+    if (!q.ref_codes.empty() && s->prefilled && s->ref_codes_dev && f0 == 0 && f1 == q.n_frames) {
         // ICL full-utterance decode (lib.rs:1022-1041): decode [ref_frames ; generated], then cut the first
         // ref_len * samples / total_frames samples
         const int n_ref = (int)(q.ref_codes.size() / 16), total = n_ref + T;
@@ -2467,6 +2509,35 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
     return Q3_OK;
 }
 
+#ifdef Q3_TRACE
+// development builds only (not declared in include/q3tts.h): arm the per-node stamp buffer BEFORE the first
+// q3_session_generate (the captured graph keeps the slice pointers), then read the stamps of the last replayed frame.
+extern "C" q3_status q3_debug_trace_enable(q3_session* s, int max_nodes) {
+    if (!s || max_nodes < 1) return set_err(Q3_INVALID_ARG, "q3_debug_trace_enable");
+    const size_t bytes = (size_t)max_nodes * TRACE_NODE * 8;
+    HIPC(hipMalloc((void**)&s->trace_buf, bytes));
+    HIPC(hipMemset(s->trace_buf, 0, bytes));
+    s->trace_cap = max_nodes;
+    return Q3_OK;
+}
+extern "C" q3_status q3_debug_trace_read(q3_session* s, unsigned long long* stamps_host, int* meta_host, int cap_nodes, int* n_nodes) {
+    if (!s || !s->trace_buf || !n_nodes) return set_err(Q3_INVALID_ARG, "q3_debug_trace_read");
+    HIPC(hipStreamSynchronize(s->stream));
+    const int n = (int)s->trace_meta.size();
+    *n_nodes = n;
+    if (stamps_host && meta_host) {
+        if (cap_nodes < n) return set_err(Q3_INVALID_ARG, "trace buffer too small");
+        HIPC(hipMemcpy(stamps_host, s->trace_buf, (size_t)n * TRACE_NODE * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            const auto& t = s->trace_meta[i];
+            const int v[7] = {t.kind, t.a, t.b, t.c, t.d, t.e, t.f};
+            memcpy(meta_host + (size_t)i * 7, v, sizeof v);
+        }
+    }
+    return Q3_OK;
+}
+#endif
+
 extern "C" q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     const q3_config& c = s->m->cfg;
@@ -2492,7 +2563,7 @@ extern "C" q3_status q3_session_profile_read(q3_session* s, double* ms, double* 
 }
 
 // the distinct GEMV launches (and how often each ran) since profiling was enabled / last reset: rows of 8 ints
-// {M, N, K, epilogue, input norm (0 none / 1 in-kernel / 2 pre-normed), producer outputs, tiling, count}
+// {M, N, K, epilogue, fused input RMSNorm (0 / 1), reserved (0), tiling, count} — what q3_bench_linear can replay
 extern "C" q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap_rows, int* n_rows, int reset) {
     if (!s || !n_rows) return set_err(Q3_INVALID_ARG, "null argument");
     *n_rows = (int)s->prof_shapes.size();
@@ -2509,14 +2580,15 @@ extern "C" q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap
 }
 
 // ------------------------------------------------------------------------------------------------
-// micro-benchmark of one GEMV shape (kernel development aid, used by tests/bench_kernels.py):
+// micro-benchmark of one GEMV shape (kernel development aid, used by tools/bench_kernels.py):
 // `iters` back-to-back launches cycling over `n_copies` distinct weight buffers (so the stream comes
 // from HBM, not the 256 MiB Infinity Cache), captured in one hipGraph and timed with HIP events.
 // epi: LinEpi; rms: fused input RMSNorm; tiled: 1 = MFMA kernel, 0 = first-generation VALU kernel.
 // ------------------------------------------------------------------------------------------------
 extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                                      double* avg_us) {
-    if (M < 1 || M > Q3_MAX_BATCH || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us) return set_err(Q3_INVALID_ARG, "bad argument");
+    if (M < 1 || M > Q3_MAX_BATCH || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us || epi < EPI_NONE || epi > EPI_SWIGLU || rms < 0 || rms > 1)
+        return set_err(Q3_INVALID_ARG, "q3_bench_linear: bad argument (epi 0..3, rms 0/1)");
     if (tiled < 0) tiled = (M <= 16 && N < 4096 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
     HIPC(hipSetDevice(device));
     DevPool pool;

@@ -11,6 +11,34 @@ constexpr int HEAD_DIM = 128;        // talker / code-predictor head dim (kernel
 constexpr int MAX_SPLITS = 64;       // KV splits of the decode attention (16 unless the context is long, see q3_session_create)
 constexpr int PART_STRIDE = HEAD_DIM + 2;   // partial record: acc[128], m, l
 
+// ---- Q3_TRACE (development builds only: tools/trace_build.sh -> libq3tts_trace.so; never defined in the product) ----
+// Per-node timeline of the captured frame graph at 10 ns resolution: every instrumented kernel gets, per launch, its own
+// slice of a device buffer through its argument struct (a captured node keeps its kernargs, so each replay overwrites
+// the same slice), and lane 0 of every workgroup stores s_memrealtime stamps taken at fixed points: slot 0 = entry,
+// 1 = inputs landed (vmcnt(0)), 2 = main work done, 3 = results stored (issued), 4 = stores acknowledged (vmcnt(0)).
+// tools/trace_frame.py turns them into the Gantt table of one frame (launch gaps, entry skew, phase lengths).
+#ifdef Q3_TRACE
+constexpr int TRACE_SLOTS = 8, TRACE_WGS = 512, TRACE_DWGS = 16, TRACE_WAVES = 16;     // + every wave of the first TRACE_DWGS workgroups
+constexpr int TRACE_NODE = TRACE_SLOTS * (TRACE_WGS + TRACE_DWGS * TRACE_WAVES);          // u64 per node
+#define Q3_TRACE_FIELD unsigned long long* trace = nullptr;
+#if defined(__HIPCC__)
+#define Q3T_DECL unsigned long long q3t_[q3::TRACE_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define Q3T(i) do { q3t_[i] = (unsigned long long)wall_clock64(); } while (0)
+#define Q3T_W(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q3t_[i] = (unsigned long long)wall_clock64(); } while (0)
+#define Q3T_FLUSH(a, wg) do { if ((a).trace && threadIdx.x == 0 && (int)(wg) < q3::TRACE_WGS) { \
+        _Pragma("unroll") for (int q3i_ = 0; q3i_ < q3::TRACE_SLOTS; ++q3i_) (a).trace[(size_t)(wg) * q3::TRACE_SLOTS + q3i_] = q3t_[q3i_]; } \
+    if ((a).trace && (threadIdx.x & 63) == 0 && (int)(wg) < q3::TRACE_DWGS && (int)(threadIdx.x >> 6) < q3::TRACE_WAVES) { \
+        _Pragma("unroll") for (int q3i_ = 0; q3i_ < q3::TRACE_SLOTS; ++q3i_) \
+            (a).trace[(size_t)q3::TRACE_SLOTS * (q3::TRACE_WGS + (wg) * q3::TRACE_WAVES + (threadIdx.x >> 6)) + q3i_] = q3t_[q3i_]; } } while (0)
+#endif
+#else
+#define Q3_TRACE_FIELD
+#define Q3T_DECL
+#define Q3T(i) do { } while (0)
+#define Q3T_W(i) do { } while (0)
+#define Q3T_FLUSH(a, wg) do { } while (0)
+#endif
+
 // ---- bf16-weight skinny GEMM ("GEMV family"): y[m][n] = sum_k x[m][k] * W[n][k] ----
 enum LinEpi { EPI_NONE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_SWIGLU = 3 };
 struct LinArgs {
@@ -25,6 +53,7 @@ struct LinArgs {
     int epi = EPI_NONE;
     int tiled = 0;                  // 1: 16-row MFMA tiles [N/16][Kpad/32][64 lanes][8 bf16]; 2: 4-row tiles [N/4][Kpad/128][64][8]
     int Kpad = 0;                   // K rounded up to 32 (tiled == 1) or 128 (tiled == 2)
+    Q3_TRACE_FIELD
 };
 hipError_t launch_linear(const LinArgs& a, hipStream_t st);       // dispatches on a.tiled
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st);   // MFMA bf16x3 kernel (16-row tiles, tiled == 1)
@@ -96,6 +125,7 @@ struct AttnArgs {
     const float* g_qkv_tab = nullptr;
     const float* g_proj_tab = nullptr; int g_proj_dim = 0; float* g_x = nullptr; int g_ldx = 0;    // g_x + b * g_ldx = the sequence's residual row
     uint32_t* g_codes = nullptr; const int* g_frame_idx = nullptr; int g_max_frames = 0, g_code_slot = 0;
+    Q3_TRACE_FIELD
 };
 constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
 // planes of positions [0, n_pos) of every (sequence, kv head) pair, from the f32 cache launch_qknorm_rope_kv filled
@@ -110,6 +140,10 @@ hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_prefill(const AttnArgs& a, hipStream_t st);
 // fused q/k-norm + RoPE + KV append + attention (+ final normalisation when n_splits == 1)
 hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st);
+// the same for caches that never exceed 16 positions with the position known at launch (the code predictor's single-row
+// passes): one wave per (sequence, q head), one memory round trip; attn_cp_ok says whether the arguments qualify
+bool attn_cp_ok(const AttnArgs& a);
+hipError_t launch_attn_cp(const AttnArgs& a, hipStream_t st);
 
 // ---- frame glue ----
 // gather rows: out[r][0..dim) = f32(table_bf16[ids[r]][0..dim))

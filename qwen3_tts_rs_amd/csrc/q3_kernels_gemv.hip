@@ -125,6 +125,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     constexpr int G = (NW == 2 || RMS) ? 4 : 6;
     __shared__ __attribute__((aligned(16))) float red[NWAVES][NW][256];
     __shared__ float ssq[NWAVES][4][16];
+    Q3T_DECL Q3T(0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // (Rotating the wave -> K-slice map with the workgroup index, so that the 256 CUs do not all walk the shared activation
     // vector in the same order, was tried against an L2-channel hot-spot theory: no change on any shape or on the frame —
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
                 sp[i] = gemv_prep<RMS>(valid, g.xa[i], g.xb[i], RMS ? g.na[i] : g.xa[i], RMS ? g.nb[i] : g.xb[i], ss);
             }
             __builtin_amdgcn_sched_barrier(0);      // all splits done before the first wait on a weight tile
+            Q3T(1);
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 acc0 = mfma3(g.wa[i], sp[i], acc0);
@@ -250,11 +252,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     }
     return;
 #endif
+    Q3T_W(2);
     // partial tile → LDS, layout [col m][row]: lane (m, kg) owns rows kg*4 .. kg*4+3
     *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = acc0;
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = acc1;
     if constexpr (RMS) ssq[wave][kg][m] = ss;
+    Q3T(6);
     __syncthreads();
+    Q3T(5);
     if (tid < 256) {
         const int col = tid >> 4, row = tid & 15;
         if (col < a.M) {
@@ -284,12 +289,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
             }
         }
     }
+    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Third generation of the 16-row-tile kernel: x goes through a wave-private LDS staging buffer.
 //
-// Measured on MI355X (tests/bench_kernels.py with the -DQ3_ABLATE builds): in k_gemv_mfma the B-operand loads — two
+// Measured on MI355X (tools/bench_kernels.py with the -DQ3_ABLATE builds): in k_gemv_mfma the B-operand loads — two
 // 16-B x loads and two 16-B norm-weight loads per lane per k-step, against ONE weight load — take 30-45 % of the
 // kernel (removing them: qkv 7.8 -> 4.7 us, down 12.3 -> 6.6 us at M = 8) although they hit L2: every 64-lane
 // dwordx4 load costs the CU's vector-memory pipe the same ~16 clocks whether it brings 1 KiB of fresh weights or
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
     constexpr int NWAVES = 8, G = 4;
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float lds[NWAVES * ZB + NWAVES * 16];
+    Q3T_DECL Q3T(0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
     const int S = a.Kpad >> 5;                       // k-steps of 32
@@ -410,6 +417,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
         wg_load<NW>(wa0, wb0, wp, wp2, s0, s1);
         for (int sb = s0; sb < s1; sb += 2 * G) {
             xg_stage<RMS>(X0, zb, ss, a.M, lane);
+            if (sb == s0) Q3T(1);
             const bool more1 = sb + G < s1;
             if (more1) {
                 xg_load<RMS>(X1, a.x, a.ldx, a.norm_w, a.M, a.K, (sb + G) * 32, lane);
@@ -436,11 +444,14 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
             if ((lane & 31) == 0) ssq[wave * 16 + 2 * r + (lane >> 5)] = v;
         }
     }
+    Q3T_W(2);
     __syncthreads();                                  // every wave is done with its staging buffer: `red` may alias it
     float* __restrict__ red = lds;                    // [NWAVES][NW][256], layout [col m][row]
     *reinterpret_cast<f32x4_t*>(&red[(wave * NW + 0) * 256 + m * 16 + kg * 4]) = acc0;
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[(wave * NW + 1) * 256 + m * 16 + kg * 4]) = acc1;
+    Q3T(6);
     __syncthreads();
+    Q3T(5);
     if (tid < 256) {
         const int col = tid >> 4, row = tid & 15;
         if (col < a.M) {
@@ -468,13 +479,14 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
             }
         }
     }
+    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
 }
 
 template <int EPI, bool RMS>
 static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     const int tiles = (a.N + 15) / 16;
     const int S = a.Kpad >> 5;
-    // Kernel choice, from tests/bench_kernels.py on MI355X at M = 8 (profiles/r1_gemv_microbench_*.log; run-to-run noise
+    // Kernel choice, from tools/bench_kernels.py on MI355X at M = 8 (profiles/r1_gemv_microbench_*.log; run-to-run noise
     // is about +-0.5 us, so only consistent differences are encoded):
     //   * K <= 1024 (a wave's slice is one 4-step group): 8 waves, register-direct, everything requested at kernel
     //     start — code-predictor qkv 4.6, gate/up 5.4, lm_head 4.3 us (16 waves: 6.6 / 8.0 / 6.3; LDS-staged: 5.7 / 6.5 / 5.1);
@@ -549,6 +561,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ float red[8][NW][MG][4][4];
     __shared__ float ssq[8][MG][4];
+    Q3T_DECL Q3T(0);
     const int nwv = blockDim.x >> 6;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 3, kb = lane >> 2;
@@ -626,6 +639,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
                     sp[i][g] = gemv_prep<RMS>(act[g] && kok, xa[i][g], xb[i][g], RMS ? na[i] : xa[i][g], RMS ? nb[i] : xb[i][g], ss[g]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            Q3T(1);
 #pragma unroll
             for (int i = 0; i < G; ++i)
 #pragma unroll
@@ -676,6 +690,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     }
     return;
 #endif
+    Q3T_W(2);
     // sum the 16 k-blocks across lanes; lanes 0..3 (block 0) then hold D[i][j = lane] in acc[.][.][i]
 #pragma unroll
     for (int w = 0; w < NW; ++w)
@@ -693,7 +708,9 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
             if (lane < 4) ssq[wave][g][lane] = v;
         }
     }
+    Q3T(6);
     __syncthreads();
+    Q3T(5);
     if (tid < 16 * MG) {
         const int m = tid >> 2, i = tid & 3, g = m >> 2, jj = m & 3;
         const int n = blockIdx.x * 4 + i;
@@ -717,6 +734,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
             a.y[(size_t)m * a.ldy + n] = v;
         }
     }
+    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
 }
 
 template <int EPI, bool RMS>

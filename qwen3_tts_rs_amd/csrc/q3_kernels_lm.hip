@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float s_k[HEAD_DIM], s_v[HEAD_DIM];
     __shared__ float sm_m[NREP][8], sm_l[NREP][8];
     __shared__ __attribute__((aligned(16))) float sm_acc[NREP][8][HEAD_DIM];
+    Q3T_DECL Q3T(0);
     const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, grp = tid >> 5, li = tid & 31, wave = tid >> 6, lane = tid & 63;
     const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
         }
     }
     __syncthreads();
+    Q3T(1);
 
     float4 q[NREP];
 #pragma unroll
@@ -570,6 +572,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
         if (p + 16 >= end) break;
         request(p + 32, kB, vB); consume(p + 16, kC, vC);
     }
+    Q3T(2);
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
         if (li == 0) { sm_m[r][grp] = m[r]; sm_l[r][grp] = l[r]; }
@@ -599,6 +602,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
             if (d == 0) { rec[HEAD_DIM] = M; rec[HEAD_DIM + 1] = L; }
         }
     }
+    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
@@ -685,6 +689,165 @@ hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Code-predictor decode attention (code_predictor.rs:370-416 through transformer.rs:247-372): the cache of a
+// frame's code predictor never holds more than 16 positions, so the generic kernel above — split bookkeeping, eight
+// key groups merged through LDS, two barriers — pays a split-capable kernel's latency for a <= 16-key problem
+// (6.3 us per launch, 70 launches per frame). Here ONE WAVE owns one (sequence, q head): no LDS, no barrier, and
+// every global request — the token's q / k / v, norm weights, RoPE row and all cached K / V rows — is issued before
+// the first value is used, so the launch costs one memory round trip (two with the folded gather).
+//   * lane l holds head dims 2l, 2l+1 (one 8-byte load per row and lane, 512-byte rows fully coalesced); the
+//     rotate-half partner d +- 64 is lane l ^ 32.
+//   * the NK partial dot products of a lane are reduced by a TRANSPOSING butterfly: at each of the first log2(NK)
+//     steps a lane hands half of its values to its partner and keeps the other half (17 exchanges instead of 96 for 16
+//     keys); afterwards lane l holds the complete score of key (l * NK) >> 6.
+//   * softmax exactly in the reference's form, exp(s - max) / sum with the sum taken in key order (each weight is
+//     broadcast with v_readlane), then sum_p w_p * V[p] in key order.
+// Slot p of the NK key slots is the cached row p for p < pos, the new token (registers, never the just-written
+// memory) for p == pos, and masked beyond. The q-head-0 wave of each kv group appends K / V.
+// ------------------------------------------------------------------------------------------------
+// transposing butterfly of k_attn_cp: N live values per lane, exchanged with lane ^ OFF; ends with s[0] = the complete sum of
+// value `key` over all 64 lanes
+template <int NK, int N, int OFF>
+__device__ __forceinline__ void tbutterfly(float (&s)[NK], int lane, int& key) {
+    if constexpr (N > 1) {
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const float send = up ? s[i] : s[i + N / 2];
+            const float keep = up ? s[i + N / 2] : s[i];
+            s[i] = keep + __shfl_xor(send, OFF);
+        }
+        if (up) key += N / 2;
+        tbutterfly<NK, N / 2, OFF / 2>(s, lane, key);
+    } else {
+#pragma unroll
+        for (int off = OFF; off >= 1; off >>= 1) s[0] += __shfl_xor(s[0], off);
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(64) void k_attn_cp(AttnArgs a) {
+    Q3T_DECL Q3T(0);
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int nrep = a.nh / a.nkv, kvh = h / nrep;
+    const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
+    const int pos = a.pos_static;
+    const size_t cache_base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM + 2 * lane;
+    // every cached row first (they depend on nothing): slot p >= pos re-reads row 0, which always exists and is finite
+    float2 kc[NK], vc[NK];
+#pragma unroll
+    for (int p = 0; p < NK; ++p) {
+        const size_t ro = cache_base + (size_t)(p < pos ? p : 0) * HEAD_DIM;
+        kc[p] = *reinterpret_cast<const float2*>(a.kcache + ro);
+        vc[p] = *reinterpret_cast<const float2*>(a.vcache + ro);
+    }
+    const float2 qw = *reinterpret_cast<const float2*>(a.q_norm_w + 2 * lane);
+    const float2 kw = *reinterpret_cast<const float2*>(a.k_norm_w + 2 * lane);
+    const int ri = pos * 64 + ((2 * lane) & 63);
+    const float2 rc = *reinterpret_cast<const float2*>(a.rope_cos + ri), rs = *reinterpret_cast<const float2*>(a.rope_sin + ri);
+
+    const float* qkv_row = a.qkv + (size_t)b * a.ld_qkv;
+    if (a.g_logits) {            // folded gather (AttnArgs::g_*): the row is the argmax of the previous pass's logits
+        const float* lg = a.g_logits + (size_t)b * a.g_vocab;
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        auto take4 = [&](const float4& v, int j) {
+            if (v.x > bv || (v.x == bv && j < bi)) { bv = v.x; bi = j; }
+            if (v.y > bv || (v.y == bv && j + 1 < bi)) { bv = v.y; bi = j + 1; }
+            if (v.z > bv || (v.z == bv && j + 2 < bi)) { bv = v.z; bi = j + 2; }
+            if (v.w > bv || (v.w == bv && j + 3 < bi)) { bv = v.w; bi = j + 3; }
+        };
+        if (a.g_vocab == 2048) {          // the production vocabulary: all eight 16-byte requests of a lane in flight at once
+            float4 v[8];                  // (a run-time trip count kept them serial: eight round trips, 4.9 us before the first use)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(lg + lane * 4 + i * 256);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) take4(v[i], lane * 4 + i * 256);
+        } else if ((a.g_vocab & 3) == 0) {
+            for (int j = lane * 4; j < a.g_vocab; j += 256) take4(*reinterpret_cast<const float4*>(lg + j), j);
+        } else {
+            for (int j = lane; j < a.g_vocab; j += 64) { const float v = lg[j]; if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; } }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off); const int oi = __shfl_xor(bi, off);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        const int row = bi == 0x7fffffff ? 0 : bi;
+        qkv_row = a.g_qkv_tab + (size_t)row * a.ld_qkv;
+        if (h == 0) {
+            const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
+            float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
+            for (int c = lane; c < a.g_proj_dim / 4; c += 64) pd[c] = ps[c];
+            if (lane == 0) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
+        }
+    }
+    float2 q = *reinterpret_cast<const float2*>(qkv_row + h * HEAD_DIM + 2 * lane);
+    float2 k = *reinterpret_cast<const float2*>(qkv_row + QD + kvh * HEAD_DIM + 2 * lane);
+    const float2 v = *reinterpret_cast<const float2*>(qkv_row + QD + KD + kvh * HEAD_DIM + 2 * lane);
+
+    Q3T_W(1);
+    // per-head RMSNorm (x / sqrt(mean + eps) * w) and rotate-half RoPE with separately rounded products
+    const bool upper = lane >= 32;
+    auto norm_rope = [&](float2 x, const float2& w) {
+        const float den = sqrtf(wave_sum(x.x * x.x + x.y * x.y) / (float)HEAD_DIM + a.eps);
+        x.x = x.x / den * w.x; x.y = x.y / den * w.y;
+        const float px = __shfl_xor(x.x, 32), py = __shfl_xor(x.y, 32);     // the d +- 64 partner
+        float2 o;
+        if (upper) { o.x = __fadd_rn(__fmul_rn(x.x, rc.x), __fmul_rn(px, rs.x)); o.y = __fadd_rn(__fmul_rn(x.y, rc.y), __fmul_rn(py, rs.y)); }
+        else       { o.x = __fsub_rn(__fmul_rn(x.x, rc.x), __fmul_rn(px, rs.x)); o.y = __fsub_rn(__fmul_rn(x.y, rc.y), __fmul_rn(py, rs.y)); }
+        return o;
+    };
+    q = norm_rope(q, qw);
+    k = norm_rope(k, kw);
+    if (h == kvh * nrep) {
+        const size_t ro = cache_base + (size_t)pos * HEAD_DIM;
+        *reinterpret_cast<float2*>(a.kcache + ro) = k;
+        *reinterpret_cast<float2*>(a.vcache + ro) = v;
+    }
+
+    float s[NK];
+#pragma unroll
+    for (int p = 0; p < NK; ++p) {
+        const float2 kk = p == pos ? k : kc[p];
+        s[p] = q.x * kk.x + q.y * kk.y;
+    }
+    int key = 0;
+    tbutterfly<NK, NK, 32>(s, lane, key);
+    const bool valid = key <= pos;
+    const float sc = valid ? s[0] * 0.08838834764831845f : -INFINITY;
+    float M = sc;
+#pragma unroll
+    for (int off = 32; off >= 64 / NK; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
+    const float w = valid ? expf(sc - M) : 0.0f;
+    float L = 0.0f;
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < NK; ++p) {
+        const float wp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), p * (64 / NK)));
+        const float2 vv = p == pos ? v : vc[p];
+        L += wp;
+        acc.x += wp * vv.x; acc.y += wp * vv.y;
+    }
+    Q3T(2);
+    *reinterpret_cast<float2*>(a.out + (size_t)b * a.ld_out + h * HEAD_DIM + 2 * lane) = make_float2(acc.x / L, acc.y / L);
+    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// single-row passes of a cache that never exceeds 16 positions, position known at launch (the code predictor)
+bool attn_cp_ok(const AttnArgs& a) {
+    return !a.pos_dev && a.rows_per_seq <= 1 && a.n_splits == 1 && a.pos_static >= 0 && a.pos_static < 16 && a.pos_static < a.max_seq &&
+           a.nkv > 0 && a.nh % a.nkv == 0 && a.ld_qkv % 2 == 0 && a.ld_out % 2 == 0 && (!a.g_logits || (a.g_proj_dim % 4 == 0 && a.g_ldx % 4 == 0));
+}
+hipError_t launch_attn_cp(const AttnArgs& a, hipStream_t st) {
+    if (!attn_cp_ok(a)) return hipErrorInvalidValue;
+    dim3 grid(a.nh, a.B);
+    if (a.pos_static < 4) hipLaunchKernelGGL(k_attn_cp<4>, grid, dim3(64), 0, st, a);
+    else if (a.pos_static < 8) hipLaunchKernelGGL(k_attn_cp<8>, grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_attn_cp<16>, grid, dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
 // merge the split partials: out[b][h*128+d] = Σ_s A_s[d] e^{m_s-M} / Σ_s l_s e^{m_s-M}
 // A separate launch on purpose. Folding it into k_attn_fused as a "last split block to arrive merges" epilogue (release
 // fence + ticket atomic + acquire fence + agent-scope loads) was built and measured on MI355X: bit-identical output,
@@ -692,6 +855,7 @@ hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
 // L2 under every later launch, while this kernel boundary costs 1.6 us.
 template <int NS>      // capacity of the fixed unroll: 16, or 64 for long-context sessions
 __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
+    Q3T_DECL Q3T(0);
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* rec = a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE;
     // all loads first (fixed unroll, predicated): one memory round trip instead of 2*n_splits dependent ones
@@ -704,6 +868,7 @@ __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
         ls[s] = ok ? r[HEAD_DIM + 1] : 0.0f;
         as[s] = ok ? r[d] : 0.0f;
     }
+    Q3T_W(1);
     float M = -INFINITY;
 #pragma unroll
     for (int s = 0; s < NS; ++s) M = fmaxf(M, ms[s]);
@@ -714,7 +879,9 @@ __global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
         L += ls[s] * wgt;
         A += as[s] * wgt;
     }
+    Q3T(2);
     a.out[(size_t)b * a.ld_out + h * HEAD_DIM + d] = A / L;
+    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // two partials per (row, head) — the key halves of the long-prompt prefill attention, tens of thousands of records per

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(512) void k_lm_gemm3(GemmArgs a) {
     // from zero and the range sums are added in ascending order — by this workgroup when it walks all of K (tot below),
     // or, for small M, by k_gemm_splitk_reduce when the launcher spreads the ranges over a.k_split workgroups (split-K:
     // a 509-position prompt gives the down projection 32 workgroups of 96 serial stages on 256 CUs). Either way an
-    // output is the same sum in the same order: a prompt gets the same bits whatever batch it is prefilled in.
+    // output is the same sum in the same order: a position prefilled by this GEMM gets the same bits whatever batch it is
+    // prefilled in (which positions those are depends on the prompt length only: q3_session_prefill's tail rule).
     const int R = a.k_ranges, spr = nst / R;                         // stages per range: even (launcher)
     const int kz = (int)blockIdx.x / a.wg_per_split;
     const int r_begin = kz * R / a.k_split, r_end = (kz + 1) * R / a.k_split;

@@ -82,6 +82,79 @@ def sum_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def _rdv_paths(path: str, world: int, nonce: str):
+    base = f"{path}.{nonce}" if nonce else path
+    return base, [f"{base}.req.{r}" for r in range(1, world)], [f"{base}.ack.{r}" for r in range(1, world)]
+
+
+def _rdv_put(p: str, data: bytes):
+    tmp = f"{p}.tmp.{os.getpid()}"
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, p)
+
+
+def _rdv_get(p: str, n: int):
+    try:
+        with open(p, "rb") as f:
+            d = f.read()
+        return d if len(d) == n else None
+    except OSError:
+        return None
+
+
+def file_rendezvous(path: str, rank: int, world: int, make_uid, timeout_s: float = 120.0, nonce: str = "") -> bytes:
+    """File handshake that cannot return a stale id, whatever an earlier job (same path, same MASTER_PORT, a crash that
+    skipped the clean-up) left behind. Every non-root rank draws a fresh 16-byte token and posts it (`<path>.req.<rank>`);
+    rank 0 publishes `id || tokens of ranks 1..world-1` and re-publishes whenever the posted tokens change; a non-root rank
+    accepts an id file only if it carries ITS token at its slot, then acknowledges with the token (`<path>.ack.<rank>`);
+    rank 0 leaves once every acknowledgement equals the token it published for that rank. Rank 0 starts by deleting the id
+    and acknowledgement files (no valid one can exist before its first publication), so a stale `req` can only delay the
+    handshake until the live rank overwrites it. Plain files + atomic renames: works on any shared directory."""
+    import time
+    base, reqs, acks = _rdv_paths(path, world, nonce)
+    n_blob = 128 + 16 * (world - 1)
+    deadline = time.time() + timeout_s
+    if rank == 0:
+        for p in [base] + acks:
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+        uid = make_uid()
+        assert len(uid) == 128
+        published = None
+        while True:
+            toks = [_rdv_get(p, 16) for p in reqs]
+            if all(t is not None for t in toks):
+                if toks != published:
+                    _rdv_put(base, uid + b"".join(toks)); published = toks
+                if [_rdv_get(p, 16) for p in acks] == toks:
+                    return uid
+            if time.time() > deadline:
+                raise TimeoutError(f"rank 0: ranks 1..{world - 1} did not complete the rendezvous at {base} within {timeout_s}s")
+            time.sleep(0.005)
+    token = os.urandom(16)
+    _rdv_put(reqs[rank - 1], token)
+    while True:
+        blob = _rdv_get(base, n_blob)
+        if blob is not None and blob[128 + 16 * (rank - 1):128 + 16 * rank] == token:
+            _rdv_put(acks[rank - 1], token)
+            return blob[:128]
+        if time.time() > deadline:
+            raise TimeoutError(f"rank {rank}: no RCCL id for this run at {base} after {timeout_s}s")
+        time.sleep(0.005)
+
+
+def rendezvous_cleanup(path: str, world: int, nonce: str = ""):
+    base, reqs, acks = _rdv_paths(path, world, nonce)
+    for p in [base] + reqs + acks:
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
+
+
 class NativeComm:
     """RCCL communicator through the C ABI (q3_dp_*, q3_dp.cpp) — what a host without torch.distributed (the reference's
     Rust host) uses for the one weight broadcast. Rendezvous: rank 0 creates the 128-byte id and the host ships it to
@@ -105,30 +178,16 @@ class NativeComm:
 
     @classmethod
     def from_file(cls, path: str, rank: int, world: int, device: int, timeout_s: float = 120.0, nonce: str = "") -> "NativeComm":
-        """Rendezvous through a file: rank 0 publishes the RCCL id, the others read it. The file name carries a job nonce
-        (pass the same `nonce` on every rank: the launcher's job id / master port; default: MASTER_PORT or TORCHELASTIC_RUN_ID
-        from the environment) so that an id left behind by an earlier job, or read before rank 0 has rewritten it, can
-        never be mistaken for this job's — a mismatched id makes ncclCommInitRank hang until its timeout."""
-        import time
-        nonce = nonce or os.environ.get("TORCHELASTIC_RUN_ID", "") + os.environ.get("MASTER_PORT", "")
-        path = f"{path}.{nonce}" if nonce else path
+        """Rendezvous through a shared path (every rank of the job calls this): `file_rendezvous` below hands every rank
+        the 128-byte RCCL id rank 0 created FOR THIS RUN — never one left behind by an earlier job, which would make
+        ncclCommInitRank hang until its timeout — then the communicator is built, one all-gather proves that every rank
+        is past the rendezvous, and rank 0 removes the files. `nonce` is only a namespace (several jobs sharing a directory)."""
+        uid = file_rendezvous(path, rank, world, cls.unique_id, timeout_s, nonce)
+        comm = cls(rank, world, uid, device)
+        comm.allgather([float(rank)])
         if rank == 0:
-            if os.path.exists(path):
-                os.unlink(path)          # never leave a stale id visible while the new one is being written
-            uid = cls.unique_id()
-            with open(path + ".tmp", "wb") as f:
-                f.write(uid)
-            os.replace(path + ".tmp", path)
-        else:
-            t0 = time.time()
-            started = t0 - 5.0           # an id older than this rank's start (minus clock slack) belongs to an earlier job
-            while not (os.path.exists(path) and os.path.getsize(path) == 128 and (nonce or os.path.getmtime(path) >= started)):
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s}s")
-                time.sleep(0.01)
-            with open(path, "rb") as f:
-                uid = f.read()
-        return cls(rank, world, uid, device)
+            rendezvous_cleanup(path, world, nonce)
+        return comm
 
     def broadcast_weights(self, model, root: int = 0):
         from . import _lib

@@ -93,7 +93,10 @@ def synth_tensor(cfg: Q3Config, seed: int, name: str, n: int, stored: int) -> Tu
         return _fill(seed, name, F32, 0.02, 1.0, n), F32
     # conv / linear weights: fan_in from the shape
     fan = _decoder_fan_in(cfg, name, n)
-    boost = 0.25 if name == "decoder.decoder.6.conv.weight" else 1.0
+    # The stack above the final conv has no normalisation, so its input arrives with RMS ~ 80 on seeded weights; the final
+    # 96 -> 1 conv is scaled (2^-9 / sqrt(fan)) so that the PRE-CLAMP waveform has a speech-like RMS of 0.15-0.2 and the
+    # clamp(-1, 1) almost never engages — otherwise the PCM tolerance of the parity tests would be checked on +-1 samples only.
+    boost = 2.0 ** -9 if name == "decoder.decoder.6.conv.weight" else 1.0
     return _fill(seed, name, F32, boost / np.sqrt(fan), 0.0, n), F32
 
 

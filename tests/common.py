@@ -54,6 +54,18 @@ def top2_margin(logits):
     return float(s[-1] - s[-2])
 
 
+def pcm_rms(got, ref, min_unsat=0.9):
+    """RMS error of a PCM buffer against the oracle's, for the north-star tolerance (1e-3). Asserts first that the reference
+    waveform is real signal — at least `min_unsat` of its samples strictly inside the clamp(-1, 1) of decoder_12hz.rs:496-504 and
+    a non-trivial level — so that agreement cannot come from both sides sitting at +-1."""
+    got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    unsat = float((np.abs(ref) < 0.999).mean())
+    level = float(np.sqrt(np.mean(ref ** 2)))
+    assert unsat >= min_unsat and level >= 0.02, f"reference PCM is saturated or silent (unsaturated {unsat:.3f}, rms {level:.3f})"
+    return float(np.sqrt(np.mean((got - ref) ** 2)))
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

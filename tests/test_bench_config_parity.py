@@ -13,7 +13,7 @@ import pytest
 import qwen3_tts_rs_amd as q
 from qwen3_tts_rs_amd import synth
 import oracle as O
-from common import oracle_model, synthetic_prompt, top2_margin
+from common import oracle_model, synthetic_prompt, top2_margin, pcm_rms
 from make_golden_bench import bench_utt, tap_indices, pcm_decimate_idx, N_FRAMES
 
 pytestmark = pytest.mark.gpu
@@ -197,16 +197,16 @@ def test_full_size_vocoder_long(gm17, T):
     else:
         ref = fx["pcm_decimated"]; got = pcm[pcm_decimate_idx(pcm.size)]
     rms = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)))
-    unsat = np.abs(ref) < 0.999           # synthetic weights drive most samples into the clamp: look at the rest on their own
+    unsat = np.abs(ref) < 0.999           # the clamp must not be what makes the PCM agree (synth.py scales the final conv for that)
     rms_unsat = float(np.sqrt(np.mean((got[unsat].astype(np.float64) - ref[unsat]) ** 2))) if unsat.any() else 0.0
     _dump(f"bench_vocoder_T{T}.json", {"tap_rel_err": errs, "pcm_rms_err": rms, "pcm_rms_err_unsaturated": rms_unsat,
                                        "unsaturated_fraction": float(unsat.mean())})
     for nme, e in errs.items():
         assert e <= 2e-4, (nme, e)
-    # north-star tolerance: PCM within 1e-3 RMS. (With the synthetic weights ~97 % of the samples sit in the clamp; on the
-    # unsaturated rest the error is the blk3 tap's relative error times the pre-clamp amplitude, recorded above.)
-    assert rms <= 1e-3, (rms, rms_unsat)
-    assert rms_unsat <= 2e-4 * 60.0, rms_unsat
+    # north-star tolerance: PCM within 1e-3 RMS, over ALL samples, of a waveform whose RMS is speech-like (0.19) and that
+    # practically never touches the clamp — so the tolerance is exercised on real values, not on +-1 against +-1
+    assert float(unsat.mean()) >= 0.9 and 0.05 <= float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) <= 0.5
+    assert rms <= 1e-3 and rms_unsat <= 1e-3, (rms, rms_unsat)
 
 
 def test_streaming_chunks_1_7b(gm17):
@@ -222,10 +222,11 @@ def test_streaming_chunks_1_7b(gm17):
     # the vocoder on the oracle's frames, chunk by chunk (independent of any near-tie in the frame loop)
     for k, name in enumerate(("chunk0", "chunk1")):
         got = gm17.decode_codes(ref_codes[10 * k:10 * k + 10]).samples
-        assert float(np.sqrt(np.mean((got - fx[name]) ** 2))) <= 1e-3
+        assert float((np.abs(fx[name]) < 0.999).mean()) >= 0.9             # tolerance checked on unsaturated samples
+        assert pcm_rms(got, fx[name]) <= 1e-3
     if (codes == ref_codes[:20]).all():
         for k, name in enumerate(("chunk0", "chunk1")):
-            assert float(np.sqrt(np.mean((chunks[k].samples - fx[name]) ** 2))) <= 1e-3
+            assert pcm_rms(chunks[k].samples, fx[name]) <= 1e-3
     else:
         ok, rep = _adjudicate("1.7b", u, q.SynthesisOptions(max_length=20, eos_token_id=None, seed=42), codes, "1_7b_stream")
         assert ok, rep

@@ -56,3 +56,46 @@ def test_shard_edge_cases():
     assert dp.shard_indices(3, 3, 4) == []
     assert dp.shard_indices(5, 1, 4) == [1]
     assert sum(len(dp.shard_indices(64, r, 8)) for r in range(8)) == 64
+
+
+def test_file_rendezvous_ignores_stale_files(tmp_path):
+    """NativeComm.from_file's handshake (a stale RCCL id under the same file name — same MASTER_PORT, crashed job —
+    must never be taken for this run's): plant a complete set of files from a 'previous job', then run three ranks in
+    threads with rank 0 starting LAST; every rank must come out with the id rank 0 made for THIS run."""
+    import threading, time
+    path = str(tmp_path / "rccl_id")
+    world = 3
+    stale = bytes([0xEE]) * 128
+    stale_tok = [bytes([r]) * 16 for r in range(1, world)]
+    with open(path, "wb") as f:
+        f.write(stale + b"".join(stale_tok))
+    for r in range(1, world):
+        for kind in ("req", "ack"):
+            with open(f"{path}.{kind}.{r}", "wb") as f:
+                f.write(stale_tok[r - 1])
+    fresh = bytes(range(128))
+    out, errs = {}, []
+
+    def run(rank, delay):
+        try:
+            time.sleep(delay)
+            out[rank] = dp.file_rendezvous(path, rank, world, lambda: fresh, timeout_s=20.0)
+        except Exception as e:          # noqa: BLE001
+            errs.append((rank, repr(e)))
+    ts = [threading.Thread(target=run, args=(1, 0.0)), threading.Thread(target=run, args=(2, 0.15)), threading.Thread(target=run, args=(0, 0.3))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert not errs, errs
+    assert out == {0: fresh, 1: fresh, 2: fresh}
+    dp.rendezvous_cleanup(path, world)
+    assert not [p for p in os.listdir(tmp_path) if p.startswith("rccl_id")]
+
+
+def test_file_rendezvous_times_out_without_root(tmp_path):
+    import pytest
+    with open(str(tmp_path / "id"), "wb") as f:          # a stale id alone must not satisfy a non-root rank
+        f.write(bytes(128 + 16))
+    with pytest.raises(TimeoutError):
+        dp.file_rendezvous(str(tmp_path / "id"), 1, 2, lambda: bytes(128), timeout_s=0.3)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Development build with -DQ3_TRACE (q3_kernels.h): qwen3_tts_rs_amd/libq3tts_trace.so, objects under build/trace/.
+# Select it with Q3TTS_LIB=qwen3_tts_rs_amd/libq3tts_trace.so (tools/trace_frame.py does).
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"; SRC="$ROOT/qwen3_tts_rs_amd/csrc"; B="$ROOT/build/trace"; mkdir -p "$B"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQ3_TRACE -Wno-unused-function -Wno-unused-variable -Wno-unused-value"
+pids=()
+for f in q3_kernels_lm q3_kernels_gemv q3_kernels_codec q3_kernels_prefill q3_engine q3_speaker q3_mimi; do
+  $HIPCC $FLAGS -c "$SRC/$f.hip" -o "$B/$f.o" & pids+=($!)
+done
+$HIPCC -O2 -std=c++17 -fPIC -c "$SRC/q3_io.cpp" -o "$B/q3_io.o" & pids+=($!)
+$HIPCC -O2 -std=c++17 -fPIC -c "$SRC/q3_dp.cpp" -o "$B/q3_dp.o" & pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$ROOT/qwen3_tts_rs_amd/libq3tts_trace.so" "$B"/*.o -ldl
+echo "built $ROOT/qwen3_tts_rs_amd/libq3tts_trace.so"
