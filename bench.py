@@ -183,7 +183,7 @@ def main():
         cnt = count // pf
         nb = N * K * 2 * (2 if epi == 3 else 1)
         us = bench_linear(Mr, N, K, epi, rms, tiled=tiled, device=dev)
-        per_shape[f"M={Mr} N={N} K={K} {EPI[epi]} norm={rms} tile={16 if tiled == 1 else 4}"] = \
+        per_shape[f"M={Mr} N={N} K={K} {EPI[epi]} norm={rms} tile={ {1: '16', 2: '4', 3: '16 split-K2'}.get(tiled, tiled) }"] = \
             {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
         tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
     achieved = tot_bytes / tot_us / 1e3     # GB/s

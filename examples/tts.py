@@ -5,7 +5,8 @@ cloning (x-vector and ICL) and streaming.
 
     python examples/tts.py --model-dir path/to/model [--ref-audio examples/data/clone_2.wav] [--out-dir .]
 
-The Rust twin of this file is shim/examples/tts.rs (same call sequence over the same C ABI)."""
+The Rust side of the same call sequence is the reference's own examples/tts.rs built against the shim crate
+(shim/Cargo.toml points its [[example]] into a sibling checkout of the reference — no copy is kept here)."""
 import argparse
 import os
 import sys

@@ -262,8 +262,9 @@ q3_status q3_session_profile_read(q3_session* s, double* ms, double* bytes, long
 q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap_rows, int* n_rows, int reset);
 /* µs per launch of one GEMV shape: `iters` launches over `n_copies` distinct weight buffers (HBM-resident
  * stream, not Infinity-Cache hits) replayed from one hipGraph and timed with HIP events on that stream.
- * tiled: 1 = 16-row tiles, 2 = 4-row tiles, 0 = first-generation row-major kernel, -1 = the engine's choice.
- * Used by bench.py for the roofline of the dominant kernel and by tests/bench_kernels.py. */
+ * tiled (the inventory's tiling column): 1 = 16-row tiles, 2 = 4-row tiles, 3 = 16-row tiles with the K range split over
+ * two workgroups (order-independent atomic reduction), 0 = first-generation row-major kernel, -1 = the engine's
+ * choice among the unsplit kernels. Used by bench.py for the roofline of the dominant kernel and by tools/bench_kernels.py. */
 q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                           double* avg_us);
 /* raw stream handle (hipStream_t) the session launches on */
@@ -300,6 +301,9 @@ q3_status q3_wav_read(const char* path, float* out_host, int64_t cap, int64_t* n
 q3_status q3_codes_write_bin(const char* path, const uint32_t* codes_host, int n_frames, int n_groups);
 q3_status q3_codes_read_bin(const char* path, uint32_t* codes_host, int cap_frames, int n_groups, int* n_frames);
 q3_status q3_audio_write_bin(const char* path, const float* samples_host, int64_t n);
+/* the same dump read back — how `--compare` loads the other side's audio (generate_audio.rs:880-886); out_host == NULL or
+ * cap == 0: only *n_samples */
+q3_status q3_audio_read_bin(const char* path, float* out_host, int64_t cap, int64_t* n_samples);
 /* audio::resample / resample_to_24k (audio/resample.rs:17-176): windowed-sinc low-pass with rubato's parameters
  * (sinc_len 128, cutoff 0.95, BlackmanHarris2), output i at input time i * sr_in / sr_out; out_host = NULL queries
  * *n_out = round(n * sr_out / sr_in). Host arithmetic (once per reference clip). */

@@ -115,6 +115,7 @@ SYMBOLS = {
     "q3_codes_write_bin": (c_int, [c_char_p, c_void_p, c_int, c_int]),
     "q3_codes_read_bin": (c_int, [c_char_p, c_void_p, c_int, c_int, P(c_int)]),
     "q3_audio_write_bin": (c_int, [c_char_p, c_void_p, ctypes.c_int64]),
+    "q3_audio_read_bin": (c_int, [c_char_p, c_void_p, ctypes.c_int64, P(ctypes.c_int64)]),
     "q3_resample": (c_int, [c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32, c_void_p, ctypes.c_int64, P(ctypes.c_int64)]),
     "q3_dp_unique_id": (c_int, [c_void_p]),
     "q3_dp_init": (c_int, [c_int, c_int, c_void_p, c_int, P(c_void_p)]),

@@ -664,6 +664,16 @@ def save_audio_binary(path: str, samples: np.ndarray):
     check(lib.q3_audio_write_bin(str(path).encode(), a.ctypes.data_as(ctypes.c_void_p), a.size))
 
 
+def load_audio_binary(path: str) -> np.ndarray:
+    """the reader of save_audio_binary's format (generate_audio.rs:880-886): f32 LE samples."""
+    n = ctypes.c_int64()
+    check(lib.q3_audio_read_bin(str(path).encode(), None, 0, ctypes.byref(n)))
+    out = np.empty(n.value, dtype=np.float32)
+    if n.value:
+        check(lib.q3_audio_read_bin(str(path).encode(), out.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n)))
+    return out
+
+
 def codes_to_tensor(codes: np.ndarray) -> np.ndarray:
     """codes_to_tensor (lib.rs:1417-1431): [n][16] u32 → [1][16][n] i64."""
     c = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, 16)

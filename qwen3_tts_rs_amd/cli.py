@@ -3,6 +3,11 @@
 (PCM16, audio/io.rs:143-165) and the dump files the reference writes (codes_seed{S}_frames{N}.bin i64 LE,
 audio_seed{S}_frames{N}.bin f32 LE, metadata_seed{S}_frames{N}.json; generate_audio.rs:724-813).
 
+`--compare --reference-dir DIR` is the reference's own pin hook (generate_audio.rs:69-75, 549-553, 816-931): EOS is
+switched off so that both engines run exactly --frames frames, and this run's codes / PCM are compared with the
+codes_seed{S}_frames{N}.bin / audio_seed{S}_frames{N}.bin dumps found in DIR — produced by the reference binary (or its
+Python upstream) for the same text, seed and sampling flags. tests/PIN_WITH_REFERENCE.md has the exact commands.
+
 Differences, all explicit: `--synthetic {tiny,0.6b,1.7b}` runs without a checkpoint (seeded random weights — there is
 no network here); `--token-ids` / `--instruct-ids` bypass the tokenizer; `--ref-audio` runs the speaker encoder (and, with
 `--ref-text`, the speech encoder for ICL) of a Base checkpoint on the GPU — `--xvector-npy` / `--ref-codes-bin` inject
@@ -28,9 +33,13 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--repetition-penalty", type=float, default=1.05)
     ap.add_argument("-m", "--model-dir", default="test_data/model")
     ap.add_argument("-o", "--output-dir", default="test_data/rust_audio")
+    ap.add_argument("-c", "--compare", action="store_true", help="compare with reference dumps (if they exist); runs exactly --frames frames (no EOS)")
+    ap.add_argument("--reference-dir", default="test_data/reference_audio", help="directory holding the reference's codes_/audio_ dumps")
+    ap.add_argument("--compare-strict", action="store_true", help="with --compare: exit 1 unless all codes are identical and the PCM is within 1e-3 RMS")
     ap.add_argument("--tokenizer-dir", default=None)
     ap.add_argument("--speaker", default="ryan")
     ap.add_argument("--language", default="english")
+    ap.add_argument("--custom-voice", action="store_true", help="accepted for compatibility: the model size always comes from config.json here")
     ap.add_argument("--instruct", default=None, help="voice description (VoiceDesign models)")
     ap.add_argument("--ref-audio", default=None)
     ap.add_argument("--ref-text", default=None)
@@ -57,6 +66,68 @@ def parse_device(s: str) -> int:
         if s.startswith(p):
             return int(s[len(p):])
     raise ValueError(f"Unsupported device '{s}': this build runs on MI355X only (auto | hip | hip:N)")
+
+
+def compare_with_reference(reference_dir: str, seed: int, num_frames: int, codes: np.ndarray, audio: np.ndarray, out=print) -> dict:
+    """compare_with_reference (generate_audio.rs:816-931): this run's codes / PCM against the dumps
+    codes_seed{seed}_frames{num_frames}.bin (i64 LE, frame-major) and audio_seed{seed}_frames{num_frames}.bin (f32 LE) in
+    `reference_dir`. Prints the reference's report lines (first five differing indices, max / mean / RMSE, MATCH / CLOSE /
+    DIFFERENT at 1e-5 / 1e-3 of max difference) plus what a parity pin needs: the first differing (frame, group) and the
+    north-star verdict (all codec ids identical, PCM within 1e-3 RMS). Returns the numbers."""
+    from qwen3_tts_rs_amd import api
+    rep = {"codes_found": False, "audio_found": False, "codes_match": None, "first_diff": None, "n_diff": None,
+           "max_diff": None, "mean_diff": None, "rmse": None, "status": None, "pinned": None}
+    mine = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, 16)
+    cp = os.path.join(reference_dir, f"codes_seed{seed}_frames{num_frames}.bin")
+    if os.path.exists(cp):
+        ref = api.load_codes_binary(cp)
+        rep["codes_found"] = True
+        a, b = ref.reshape(-1).astype(np.int64), mine.reshape(-1).astype(np.int64)
+        match = a.size == b.size and bool((a == b).all())
+        rep["codes_match"] = match
+        if match:
+            out(f"Codes: MATCH (all {a.size} values identical)")
+            rep["n_diff"] = 0
+        else:
+            out("Codes: MISMATCH"); out(f"  Reference: {a.size} values"); out(f"  This run:  {b.size} values")
+            n = min(a.size, b.size)
+            bad = np.nonzero(a[:n] != b[:n])[0]
+            for i in bad[:5]:
+                out(f"  Index {int(i)} (frame {int(i) // 16}, group {int(i) % 16}): Reference={int(a[i])}, This run={int(b[i])}")
+            if bad.size > 5:
+                out(f"  ... and {bad.size - 5} more differences")
+            out(f"  Total differences: {bad.size}")
+            rep["n_diff"] = int(bad.size)
+            if bad.size:
+                rep["first_diff"] = (int(bad[0]) // 16, int(bad[0]) % 16)
+                out(f"  First divergence: frame {rep['first_diff'][0]}, group {rep['first_diff'][1]} "
+                    f"(group 0 = talker sample, 1..15 = code-predictor argmax; every later frame depends on it)")
+    else:
+        out(f"Codes: reference not found at {cp!r}")
+    ap = os.path.join(reference_dir, f"audio_seed{seed}_frames{num_frames}.bin")
+    if os.path.exists(ap):
+        ref = api.load_audio_binary(ap)
+        rep["audio_found"] = True
+        mine_a = np.ascontiguousarray(audio, dtype=np.float32).reshape(-1)
+        n = min(ref.size, mine_a.size)
+        if n > 0:
+            d = np.abs(ref[:n].astype(np.float64) - mine_a[:n].astype(np.float64))
+            rep["max_diff"], rep["mean_diff"], rep["rmse"] = float(d.max()), float(d.mean()), float(np.sqrt(np.mean(d * d)))
+            rep["status"] = "MATCH" if rep["max_diff"] < 1e-5 else "CLOSE" if rep["max_diff"] < 1e-3 else "DIFFERENT"
+            out(f"\nAudio comparison ({n} samples):"); out(f"  Reference samples: {ref.size}"); out(f"  This run samples:  {mine_a.size}")
+            out(f"  Max difference: {rep['max_diff']:.6f}"); out(f"  Mean difference: {rep['mean_diff']:.6f}"); out(f"  RMSE: {rep['rmse']:.6f}")
+            out(f"  Status: {rep['status']} (max diff " + ("< 1e-5)" if rep["status"] == "MATCH" else "< 1e-3)" if rep["status"] == "CLOSE" else ">= 1e-3)"))
+    else:
+        out(f"Audio: reference not found at {ap!r}")
+    mp = os.path.join(reference_dir, f"metadata_seed{seed}_frames{num_frames}.json")
+    if os.path.exists(mp):
+        with open(mp) as f:
+            out(f"\nReference metadata: {json.load(f)}")
+    if rep["codes_found"] and rep["audio_found"] and rep["rmse"] is not None:
+        same_len = rep["codes_match"] is True
+        rep["pinned"] = bool(same_len and rep["rmse"] <= 1e-3)
+        out(f"\nParity (north star: codec ids bit-exact, PCM within 1e-3 RMS): {'PINNED' if rep['pinned'] else 'NOT pinned'}")
+    return rep
 
 
 def max_frames_from_args(a) -> int:
@@ -112,7 +183,7 @@ def main(argv=None) -> int:
     ids = [int(x) for x in a.token_ids.split(",")] if a.token_ids else tok.encode(a.text)
     opts = q.SynthesisOptions(max_length=frames, temperature=a.temperature, top_k=a.top_k, top_p=a.top_p,
                               repetition_penalty=a.repetition_penalty, seed=a.seed)
-    if a.no_eos:
+    if a.no_eos or a.compare:          # --compare: don't stop early when comparing with the reference (generate_audio.rs:549-553)
         opts.eos_token_id = None
     utt = q.Utterance(ids, speaker, language, seed=a.seed)
     if a.instruct or a.instruct_ids:
@@ -171,6 +242,11 @@ def main(argv=None) -> int:
     if timing is not None:
         print(f"Stages: prefill {timing.prefill_ms:.1f} ms, generation {timing.generation_ms:.1f} ms ({timing.generation_frames} frames), decode {timing.decode_ms:.1f} ms")
     model.close()
+    if a.compare:
+        print("\n=== Comparing with reference ===")
+        rep = compare_with_reference(a.reference_dir, a.seed, n, codes, samples)
+        if a.compare_strict and not rep["pinned"]:
+            return 1
     return 0
 
 

@@ -6,7 +6,7 @@ OUT="$HERE/../libq3tts.so"
 BUILD="$HERE/../../build"
 mkdir -p "$BUILD"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=14 -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value"
 pids=()
 for f in q3_kernels_lm q3_kernels_gemv q3_kernels_codec q3_kernels_prefill q3_engine q3_speaker q3_mimi; do
   if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/q3_kernels.h" -nt "$BUILD/$f.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/$f.o" ]; then

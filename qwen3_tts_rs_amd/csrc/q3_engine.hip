@@ -1184,6 +1184,7 @@ struct q3_session {
     bool legacy_attn = getenv("Q3_LEGACY_ATTN") != nullptr;   // A/B aid: three-kernel attention path
     bool proj_tables = getenv("Q3_NO_PROJ_TABLES") == nullptr;   // A/B aid: set to project the gathered embedding on every pass
     bool qkv_tables = getenv("Q3_NO_QKV_TABLES") == nullptr;     // A/B aid: set to run the layer-0 qkv GEMV on every pass
+    bool ksplit = getenv("Q3_NO_KSPLIT") == nullptr;          // A/B aid: set to keep o-proj / down-proj on the unsplit kernels
     bool cp_attn = getenv("Q3_NO_CP_ATTN") == nullptr;        // A/B aid: set to run the code predictor on the generic k_attn_fused
     bool no_chunk = getenv("Q3_NO_CHUNK") != nullptr;         // A/B aid: one position per prefill step, 16-pass code predictor
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_event_bytes;
@@ -1226,7 +1227,7 @@ static hipError_t run_linear(q3_session* s, const LinArgs& a_in) {
     s->prof_events.push_back({e0, e1});
     s->prof_event_bytes.push_back((double)a.N * a.K * 2.0 * (a.epi == EPI_SWIGLU ? 2.0 : 1.0));
     {   // launch inventory (q3_session_profile_shapes): M, N, K, epilogue, fused input norm, reserved, tiling
-        ProfShape ps{a.M, a.N, a.K, a.epi, a.norm_w ? 1 : 0, 0, a.tiled, 1};
+        ProfShape ps{a.M, a.N, a.K, a.epi, a.norm_w ? 1 : 0, 0, a.ksplit == 2 ? 3 : a.tiled, 1};
         bool found = false;
         for (auto& q : s->prof_shapes)
             if (q.M == ps.M && q.N == ps.N && q.K == ps.K && q.epi == ps.epi && q.rms == ps.rms && q.produce == ps.produce && q.tiled == ps.tiled) { q.count += 1; found = true; break; }
@@ -1252,13 +1253,22 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
-    if (!s->legacy_attn && rows_per_seq == 2 && !pos_dev && pos_static == 0) {
+    // Split-K projections (LinArgs::ksplit, k_gemv_sk2): o-proj and down-proj with N <= 2048 and K >= 2048 at 3 .. 16 rows
+    // run as two K halves that meet in the output through order-independent atomic adds. The output buffer must hold zeros:
+    // SUM is cleared by this layer's attention launch (its last reader was the previous down-proj), X by the gate/up
+    // launch (its last reader is this layer's o-proj, as the residual).
+    const bool first2 = !s->legacy_attn && rows_per_seq == 2 && !pos_dev && pos_static == 0;
+    const bool attn3 = !first2 && (s->legacy_attn || rows_per_seq > 1);
+    const bool sk_rows = s->ksplit && B >= 3 && B <= 16 && d.H <= 2048 && d.H % 4 == 0;
+    const bool o_sk = sk_rows && !first2 && !attn3 && w.o.t1 && QD >= 2048 && up32(QD) / 32 >= 16;
+    const bool dn_sk = sk_rows && w.down.t1 && w.gate.t1 && d.I >= 2048 && up32(d.I) / 32 >= 16;
+    if (first2) {
         if (fold) {                                 // pass-1 gather folded: row 2b+1 = table row tok[b]
             t.g_tok = fold->tok; t.g_qkv_tab = fold->qkv_tab; t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim;
             t.g_x = fold->out; t.g_ldx = fold->ld_out;
         }
         HIPC(launch_attn_first2(t, s->stream));    // the code predictor's 2-token first pass
-    } else if (s->legacy_attn || rows_per_seq > 1) {     // rows of one sequence depend on each other's K/V: three launches
+    } else if (attn3) {     // rows of one sequence depend on each other's K/V: three launches
         HIPC(launch_qknorm_rope_kv(t, s->stream));
         HIPC(launch_attn_decode(t, s->stream));
         HIPC(launch_attn_merge(t, s->stream));
@@ -1268,6 +1278,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
             t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim; t.g_x = fold->out; t.g_ldx = fold->ld_out;
             t.g_codes = fold->codes; t.g_frame_idx = fold->frame_idx; t.g_max_frames = fold->max_frames; t.g_code_slot = fold->pass - 1;
         }
+        if (o_sk) { t.zero = b.SUM; t.zero_n = B * d.H; }
         if (s->cp_attn && attn_cp_ok(t)) {      // <= 16 positions, static position: the code predictor
 #ifdef Q3_TRACE
             t.trace = s->trace_next(1, t.B, t.nh, 1, t.pos_static, t.g_logits ? 1 : 0);
@@ -1284,15 +1295,19 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
             if (n_splits > 1) HIPC(launch_attn_merge(t, s->stream));
         }
     }
+    auto force16 = [&](LinArgs& l, const TW& tw) { l.tiled = 1; l.W = tw.t1; l.Kpad = kpad_for(1, l.K); l.ksplit = 2; };
     LinArgs o;
     o.N = d.H; o.K = QD; set_w(o, w.o, B, o.N, o.K); o.x = b.ATT; o.ldx = QD; o.resid = b.X; o.ldr = d.H; o.y = b.SUM; o.ldy = d.H; o.M = B; o.epi = EPI_RESID;
+    if (o_sk) force16(o, w.o);
     HIPC(run_linear(s, o));
     LinArgs g;
     g.N = d.I; g.K = d.H; set_w2(g, w.gate, w.up, B, g.N, g.K); g.x = b.SUM; g.ldx = d.H; g.norm_w = w.post_ln; g.eps = d.eps;
     g.y = b.ACT; g.ldy = d.I; g.M = B; g.epi = EPI_SWIGLU;
+    if (dn_sk) { g.zero = b.X; g.zero_n = B * d.H; }
     HIPC(run_linear(s, g));
     LinArgs dn;
     dn.N = d.H; dn.K = d.I; set_w(dn, w.down, B, dn.N, dn.K); dn.x = b.ACT; dn.ldx = d.I; dn.resid = b.SUM; dn.ldr = d.H; dn.y = b.X; dn.ldy = d.H; dn.M = B; dn.epi = EPI_RESID;
+    if (dn_sk) force16(dn, w.down);
     HIPC(run_linear(s, dn));
     return Q3_OK;
 }
@@ -2583,20 +2598,24 @@ extern "C" q3_status q3_session_profile_shapes(q3_session* s, int* rows, int cap
 // micro-benchmark of one GEMV shape (kernel development aid, used by tools/bench_kernels.py):
 // `iters` back-to-back launches cycling over `n_copies` distinct weight buffers (so the stream comes
 // from HBM, not the 256 MiB Infinity Cache), captured in one hipGraph and timed with HIP events.
-// epi: LinEpi; rms: fused input RMSNorm; tiled: 1 = MFMA kernel, 0 = first-generation VALU kernel.
+// epi: LinEpi; rms: fused input RMSNorm; tiled: 1 = 16-row MFMA tiles, 2 = 4-row tiles, 3 = 16-row tiles with split-K in two,
+// 0 = first-generation VALU kernel, < 0 = the engine's choice for an unsplit launch.
 // ------------------------------------------------------------------------------------------------
 extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int tiled, int iters, int n_copies,
                                      double* avg_us) {
     if (M < 1 || M > Q3_MAX_BATCH || N < 16 || K < 32 || iters < 1 || n_copies < 1 || !avg_us || epi < EPI_NONE || epi > EPI_SWIGLU || rms < 0 || rms > 1)
         return set_err(Q3_INVALID_ARG, "q3_bench_linear: bad argument (epi 0..3, rms 0/1)");
     if (tiled < 0) tiled = (M <= 16 && N < 4096 && !short_k_wide(N, K) && (M <= 2 || (N <= 1024 && M <= 8))) ? 2 : 1;    // the engine's choice (pick_mode)
+    const bool sk2 = tiled == 3;          // 3 = 16-row tiles, split-K in two (LinArgs::ksplit): y alternates between two buffers,
+    if (sk2) tiled = 1;                   // each launch clearing the other one as its side job, as the frame loop's neighbours do
     HIPC(hipSetDevice(device));
     DevPool pool;
     const size_t welems = tiled == 2 ? tiled_elems(2, N, K) : tiled_elems(1, N, K);
     const int nmat = epi == EPI_SWIGLU ? 2 : 1;
     uint16_t* w; float *x, *y, *nw, *res;
     HIPC(pool.alloc(&w, welems * nmat * n_copies));
-    HIPC(pool.alloc(&x, (size_t)Q3_MAX_BATCH * K)); HIPC(pool.alloc(&y, (size_t)Q3_MAX_BATCH * N)); HIPC(pool.alloc(&nw, (size_t)K)); HIPC(pool.alloc(&res, (size_t)Q3_MAX_BATCH * N));
+    HIPC(pool.alloc(&x, (size_t)Q3_MAX_BATCH * K)); HIPC(pool.alloc(&y, (size_t)2 * Q3_MAX_BATCH * N)); HIPC(pool.alloc(&nw, (size_t)K)); HIPC(pool.alloc(&res, (size_t)Q3_MAX_BATCH * N));
+    HIPC(hipMemset(y, 0, (size_t)2 * Q3_MAX_BATCH * N * 4));
     {   // random-ish bf16 weights / f32 activations (never zeros: DVFS, guide §5.4 rule 25)
         std::vector<uint16_t> hw(welems);
         q3_synth_fill(1, "bench.w", Q3_DTYPE_BF16, 0.02f, 0.0f, (int64_t)welems, hw.data());
@@ -2614,6 +2633,7 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
         a.N = N; a.K = K; a.Kpad = tiled == 2 ? up128(K) : up32(K); a.tiled = tiled; a.x = x; a.ldx = K; a.y = y; a.ldy = N; a.M = M; a.epi = epi;
         if (rms) { a.norm_w = nw; a.eps = 1e-6f; }
         if (epi == EPI_RESID) { a.resid = res; a.ldr = N; }
+        if (sk2) { a.ksplit = 2; a.y = y + (size_t)(i & 1) * Q3_MAX_BATCH * N; a.zero = y + (size_t)((i + 1) & 1) * Q3_MAX_BATCH * N; a.zero_n = M * N; }
         return launch_linear(a, st);
     };
     for (int i = 0; i < 4; ++i) HIPC(one(i));

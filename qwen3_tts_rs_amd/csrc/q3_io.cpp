@@ -723,3 +723,23 @@ extern "C" q3_status q3_audio_write_bin(const char* path, const float* samples, 
     if (fclose(f) != 0 || bad) return q3i_set_err(Q3_IO, "Failed to write %s", path);
     return Q3_OK;
 }
+
+// reader of the same dump (the reference CLI reads its Python counterpart this way: generate_audio.rs:880-886); out == NULL
+// or cap == 0: only *n_samples. A file whose size is not a multiple of 4 is rejected.
+extern "C" q3_status q3_audio_read_bin(const char* path, float* out, int64_t cap, int64_t* n_samples) {
+    if (!path || !n_samples || cap < 0) return q3i_set_err(Q3_INVALID_ARG, "q3_audio_read_bin: bad argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return q3i_set_err(Q3_IO, "Failed to open %s", path);
+    fseek(f, 0, SEEK_END);
+    const long bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (bytes < 0 || bytes % 4 != 0) { fclose(f); return q3i_set_err(Q3_IO, "%s: size %ld is not a whole number of f32 samples", path, bytes); }
+    const int64_t n = bytes / 4;
+    *n_samples = n;
+    if (out && cap > 0) {
+        if (cap < n) { fclose(f); return q3i_set_err(Q3_INVALID_ARG, "q3_audio_read_bin: buffer holds %lld of %lld samples", (long long)cap, (long long)n); }
+        if (n && fread(out, 4, (size_t)n, f) != (size_t)n) { fclose(f); return q3i_set_err(Q3_IO, "Failed to read %s", path); }
+    }
+    fclose(f);
+    return Q3_OK;
+}

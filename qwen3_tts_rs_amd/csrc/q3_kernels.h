@@ -25,6 +25,8 @@ constexpr int TRACE_NODE = TRACE_SLOTS * (TRACE_WGS + TRACE_DWGS * TRACE_WAVES);
 #define Q3T_DECL unsigned long long q3t_[q3::TRACE_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define Q3T(i) do { q3t_[i] = (unsigned long long)wall_clock64(); } while (0)
 #define Q3T_W(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q3t_[i] = (unsigned long long)wall_clock64(); } while (0)
+// stamp taken once the kernel argument `val` has arrived in its SGPR (slot 7: the kernarg round trip of a node)
+#define Q3T_K(i, val) do { asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(val) : "memory"); q3t_[i] = (unsigned long long)wall_clock64(); } while (0)
 #define Q3T_FLUSH(a, wg) do { if ((a).trace && threadIdx.x == 0 && (int)(wg) < q3::TRACE_WGS) { \
         _Pragma("unroll") for (int q3i_ = 0; q3i_ < q3::TRACE_SLOTS; ++q3i_) (a).trace[(size_t)(wg) * q3::TRACE_SLOTS + q3i_] = q3t_[q3i_]; } \
     if ((a).trace && (threadIdx.x & 63) == 0 && (int)(wg) < q3::TRACE_DWGS && (int)(threadIdx.x >> 6) < q3::TRACE_WAVES) { \
@@ -36,6 +38,7 @@ constexpr int TRACE_NODE = TRACE_SLOTS * (TRACE_WGS + TRACE_DWGS * TRACE_WAVES);
 #define Q3T_DECL
 #define Q3T(i) do { } while (0)
 #define Q3T_W(i) do { } while (0)
+#define Q3T_K(i, val) do { } while (0)
 #define Q3T_FLUSH(a, wg) do { } while (0)
 #endif
 
@@ -53,6 +56,14 @@ struct LinArgs {
     int epi = EPI_NONE;
     int tiled = 0;                  // 1: 16-row MFMA tiles [N/16][Kpad/32][64 lanes][8 bf16]; 2: 4-row tiles [N/4][Kpad/128][64][8]
     int Kpad = 0;                   // K rounded up to 32 (tiled == 1) or 128 (tiled == 2)
+    // Split-K in two (k_gemv_sk2: tiled == 1, no fused norm, epilogue none / resid): the K halves of a 16-row tile run as
+    // two workgroups that ADD their results into y with f32 atomics. y MUST hold zeros when the launch starts; with exactly
+    // two addends onto zero the sum does not depend on their order (f32 addition is commutative: 0 + a + b == 0 + b + a bit
+    // for bit), so the result is deterministic. The half that owns k = 0 carries bias and residual.
+    int ksplit = 1;
+    // side job of any GEMV launch: store zeros to zero[0 .. zero_n) (zero_n % 4 == 0) — how the target of the NEXT
+    // split-K launch is cleared without a launch of its own (the buffer must be dead for this launch's consumers)
+    float* zero = nullptr; int zero_n = 0;
     Q3_TRACE_FIELD
 };
 hipError_t launch_linear(const LinArgs& a, hipStream_t st);       // dispatches on a.tiled
@@ -125,6 +136,9 @@ struct AttnArgs {
     const float* g_qkv_tab = nullptr;
     const float* g_proj_tab = nullptr; int g_proj_dim = 0; float* g_x = nullptr; int g_ldx = 0;    // g_x + b * g_ldx = the sequence's residual row
     uint32_t* g_codes = nullptr; const int* g_frame_idx = nullptr; int g_max_frames = 0, g_code_slot = 0;
+    // side job (launch_attn_fused / launch_attn_cp): store zeros to zero[0 .. zero_n) — clears the target of the split-K
+    // o-projection that follows (LinArgs::ksplit)
+    float* zero = nullptr; int zero_n = 0;
     Q3_TRACE_FIELD
 };
 constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
@@ -239,5 +253,15 @@ hipError_t launch_silu_mul(const float* g, const float* u, float* y, int64_t n, 
 hipError_t launch_rvq_embed(const uint32_t* frames, int n_frames, const float* first_cb, const float* const* rest_cbs,
                             float* first_out, float* rest_out, int cb_dim, int cb_size, hipStream_t st);
 hipError_t launch_norm_codebook(const float* esum, const float* usage, float* out, int rows, int dim, hipStream_t st);
+
+#if defined(__HIPCC__)
+// zero side job (LinArgs::zero / AttnArgs::zero): workgroup `wg` of `nwg` clears its share with 16-byte stores
+__device__ __forceinline__ void zero_job(float* z, int n, int wg, int nwg, int tid, int nthreads) {
+    if (!z) return;
+    const int per = (((n + nwg - 1) / nwg) + 3) & ~3;
+    const int beg = wg * per, end = (beg + per) < n ? (beg + per) : n;
+    for (int i = beg + tid * 4; i < end; i += nthreads * 4) *reinterpret_cast<float4*>(z + i) = float4{0.f, 0.f, 0.f, 0.f};
+}
+#endif
 
 }  // namespace q3

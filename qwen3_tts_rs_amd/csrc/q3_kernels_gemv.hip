@@ -24,6 +24,15 @@
 
 namespace q3 {
 
+// Kernel-argument preload (hipcc -mllvm -amdgpu-kernarg-preload-count=14, build.sh): the first 14 dwords of a kernel's
+// explicit arguments arrive in SGPRs with the wave instead of through an s_load — whose round trip the frame's timeline
+// prices at 0.31 us per node, in front of every address a kernel computes (tools/trace_frame.py, `karg` column). A struct
+// argument is not preloadable, so the GEMV kernels take the fields their first loads depend on as leading scalars
+// (exactly 14 dwords) and the rest as the struct; Q3_LIN_APPLY overwrites the struct copy's fields with the scalars.
+#define Q3_LIN_PRE const uint16_t* pW, const uint16_t* pW2, const float* px, const float* pnw, int pM, int pN, int pK, int pKpad, int pldx, int pepi
+#define Q3_LIN_APPLY(a, a_in) LinArgs a = a_in; a.W = pW; a.W2 = pW2; a.x = px; a.norm_w = pnw; a.M = pM; a.N = pN; a.K = pK; a.Kpad = pKpad; a.ldx = pldx; a.epi = pepi
+#define Q3_LIN_PASS(a) (a).W, (a).W2, (a).x, (a).norm_w, (a).M, (a).N, (a).K, (a).Kpad, (a).ldx, (a).epi, (a)
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -120,12 +129,13 @@ __device__ __forceinline__ Split3 gemv_prep(bool valid, const float4& x0, const 
 // otherwise idle) and exchanged with a DPP row rotate: one x (and one norm-weight) instruction per k-step instead of two.
 // Lanes m >= 8 end up holding column m - 8 with its halves swapped — columns nobody reads.
 template <int EPI, bool RMS, int NWAVES, bool HALF>
-__global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
+__global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a_in) {
+    Q3_LIN_APPLY(a, a_in);
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int G = (NW == 2 || RMS) ? 4 : 6;
     __shared__ __attribute__((aligned(16))) float red[NWAVES][NW][256];
     __shared__ float ssq[NWAVES][4][16];
-    Q3T_DECL Q3T(0);
+    Q3T_DECL Q3T(0); Q3T_K(7, a.Kpad);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // (Rotating the wave -> K-slice map with the workgroup index, so that the 256 CUs do not all walk the shared activation
     // vector in the same order, was tried against an L2-channel hot-spot theory: no change on any shape or on the frame —
@@ -253,6 +263,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
     return;
 #endif
     Q3T_W(2);
+    // side job AFTER the last load was issued: vmcnt retires in issue order, so a store issued ahead of the x loads would sit
+    // in front of every wait for them (code-predictor gate/up: B operand ready 0.7 us later with the store first)
+    zero_job(a.zero, a.zero_n, blockIdx.x, gridDim.x, tid, NWAVES * 64);
     // partial tile → LDS, layout [col m][row]: lane (m, kg) owns rows kg*4 .. kg*4+3
     *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = acc0;
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = acc1;
@@ -290,6 +303,113 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(LinArgs a) {
         }
     }
     Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-K in two for the narrow, long-K projections (o-proj, down-proj: N <= 2048, K >= 2048, epilogue none / +residual).
+//
+// What the per-node timeline of the frame shows for them (tools/trace_frame.py, profiles/r3_trace_frame_b8.txt): every
+// workgroup of a GEMV reads ALL of x — M*K*4 bytes, 64-196 KB here, 4-6x its share of the weights — and the 32 CUs of an
+// XCD pull those same bytes out of one L2 at the same moment: the B operand is ready 2.3-2.9 us after kernel entry
+// (0.8 us for a kernel that reads little), and with N = 1024 the 4-row tiles that fill the chip pay a 16-block
+// cross-lane reduction on top. Here a 16-row tile's K range is cut in two; grid (tiles, 2): a workgroup reads half of x,
+// twice as many workgroups stream weights, and x traffic through the L2s halves (CP shapes: quarters, 4-row -> 16-row).
+// The two halves meet in y through f32 atomic adds onto ZEROS (LinArgs::ksplit): two addends commute bit for bit, so the
+// result does not depend on arrival order — no ticket, no fence, no second pass. The k = 0 half adds bias + residual.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int G, bool HALF>
+__global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
+    Q3_LIN_APPLY(a, a_in);
+    constexpr int NWAVES = 8;
+    __shared__ __attribute__((aligned(16))) float red[NWAVES][256];
+    Q3T_DECL Q3T(0); Q3T_K(7, a.Kpad);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int half = blockIdx.y;
+    const int S = a.Kpad >> 5;                       // k-steps of 32
+    const int h0 = (half * S) / 2, h1 = ((half + 1) * S) / 2, Sh = h1 - h0;
+    const int s0 = h0 + (wave * Sh) / NWAVES, s1 = h0 + ((wave + 1) * Sh) / NWAVES;
+    const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + (size_t)blockIdx.x * S * 64 + lane;
+    const int xrow = HALF ? (m & 7) : m, xhalf = HALF ? (m >> 3) * 4 : 0;
+    const bool act = HALF ? xrow < a.M : m < a.M;
+    const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
+
+    float pre = 0.0f;                                // bias + residual of the k = 0 half, requested up front
+    {
+        const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
+        if (half == 0 && tid < 256 && col < a.M && n < a.N) {
+            if (a.bias) pre = a.bias[n];
+            if constexpr (EPI == EPI_RESID) pre = a.resid[(size_t)col * a.ldr + n] + pre;
+        }
+    }
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f};
+    float ss = 0.0f;
+    struct Grp { u32x4_t wa[G]; float4 xa[G], xb[G]; };
+    Grp g;
+    for (int sb = s0; sb < s1; sb += G) {
+        // x first (L2), weights second (HBM): VMEM returns are counted in issue order (see k_gemv_mfma)
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+            const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;
+            g.xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!HALF) g.xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+            g.wa[i] = Q3_WLOAD(wp + (size_t)s * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Split3 sp[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = sb + i;
+            const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;
+            if constexpr (HALF) g.xb[i] = ror8(g.xa[i]);
+            sp[i] = gemv_prep<false>(valid, g.xa[i], g.xb[i], g.xa[i], g.xb[i], ss);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Q3T(1);
+#pragma unroll
+        for (int i = 0; i < G; ++i) acc0 = mfma3(g.wa[i], sp[i], acc0);
+    }
+    Q3T_W(2);
+    zero_job(a.zero, a.zero_n, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, NWAVES * 64);
+    *reinterpret_cast<f32x4_t*>(&red[wave][m * 16 + kg * 4]) = acc0;
+    Q3T(6);
+    __syncthreads();
+    Q3T(5);
+    if (tid < 256) {
+        const int col = tid >> 4, row = tid & 15, n = blockIdx.x * 16 + row;
+        if (col < a.M && n < a.N) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) v += red[w][tid];
+            if (half == 0) v = pre + v;
+            unsafeAtomicAdd(&a.y[(size_t)col * a.ldy + n], v);
+        }
+    }
+    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+static hipError_t launch_gemv_sk2(const LinArgs& a, hipStream_t st) {
+    if (a.norm_w || (a.epi != EPI_NONE && a.epi != EPI_RESID) || a.tiled != 1 || a.M > 16) return hipErrorInvalidValue;
+    const int tiles = (a.N + 15) / 16, S = a.Kpad >> 5;
+    if (S < 16) return hipErrorInvalidValue;
+    const dim3 grid(tiles, 2), blk(512);
+    const bool g6 = ((S / 2) % 48) == 0;             // a wave's slice is a multiple of 6 k-steps (K = 3072, 6144): no ragged group
+    const bool half = a.M <= 8;
+#define Q3_SK2(E, GG, H) hipLaunchKernelGGL((k_gemv_sk2<E, GG, H>), grid, blk, 0, st, Q3_LIN_PASS(a))
+    if (a.epi == EPI_RESID) {
+        if (g6) { if (half) Q3_SK2(EPI_RESID, 6, true); else Q3_SK2(EPI_RESID, 6, false); }
+        else    { if (half) Q3_SK2(EPI_RESID, 4, true); else Q3_SK2(EPI_RESID, 4, false); }
+    } else {
+        if (g6) { if (half) Q3_SK2(EPI_NONE, 6, true); else Q3_SK2(EPI_NONE, 6, false); }
+        else    { if (half) Q3_SK2(EPI_NONE, 4, true); else Q3_SK2(EPI_NONE, 4, false); }
+    }
+#undef Q3_SK2
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,7 +499,8 @@ __device__ __forceinline__ void g_compute(const u32x4_t (&wa)[4], const u32x4_t 
 }
 
 template <int EPI, bool RMS>
-__global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
+__global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
+    Q3_LIN_APPLY(a, a_in);
     constexpr int NWAVES = 8, G = 4;
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float lds[NWAVES * ZB + NWAVES * 16];
@@ -445,6 +566,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(LinArgs a) {
         }
     }
     Q3T_W(2);
+    zero_job(a.zero, a.zero_n, blockIdx.x, gridDim.x, tid, NWAVES * 64);
     __syncthreads();                                  // every wave is done with its staging buffer: `red` may alias it
     float* __restrict__ red = lds;                    // [NWAVES][NW][256], layout [col m][row]
     *reinterpret_cast<f32x4_t*>(&red[(wave * NW + 0) * 256 + m * 16 + kg * 4]) = acc0;
@@ -505,7 +627,7 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     const bool lds_pick = !no_lds && ((tiles < 256 && S > 32 && S <= 64) || (a.M > 8 && S >= 96));
     if (big8 && a.M <= 8) big = false;
     if (lds_ok && (force == 1 || (force == 0 && lds_pick))) {
-        hipLaunchKernelGGL((k_gemv_lds<EPI, RMS>), dim3(tiles), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((k_gemv_lds<EPI, RMS>), dim3(tiles), dim3(512), 0, st, Q3_LIN_PASS(a));
         return hipGetLastError();
     }
     if (force == 8) big = false; else if (force == 16) big = true;
@@ -516,16 +638,16 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     static const bool no_half = getenv("Q3_GEMV_NO_HALF") != nullptr;
     const bool half = a.M <= 8 && !no_half;
     if (four) {
-        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, true>), dim3(tiles), dim3(4 * 64), 0, st, a);
-        else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, false>), dim3(tiles), dim3(4 * 64), 0, st, a);
+        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, true>), dim3(tiles), dim3(4 * 64), 0, st, Q3_LIN_PASS(a));
+        else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, false>), dim3(tiles), dim3(4 * 64), 0, st, Q3_LIN_PASS(a));
         return hipGetLastError();
     }
     if (big) {
-        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16, true>), dim3(tiles), dim3(16 * 64), 0, st, a);
-        else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16, false>), dim3(tiles), dim3(16 * 64), 0, st, a);
+        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16, true>), dim3(tiles), dim3(16 * 64), 0, st, Q3_LIN_PASS(a));
+        else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16, false>), dim3(tiles), dim3(16 * 64), 0, st, Q3_LIN_PASS(a));
     } else {
-        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, true>), dim3(tiles), dim3(8 * 64), 0, st, a);
-        else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, false>), dim3(tiles), dim3(8 * 64), 0, st, a);
+        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, true>), dim3(tiles), dim3(8 * 64), 0, st, Q3_LIN_PASS(a));
+        else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, false>), dim3(tiles), dim3(8 * 64), 0, st, Q3_LIN_PASS(a));
     }
     return hipGetLastError();
 }
@@ -556,8 +678,31 @@ __device__ __forceinline__ float sum_over_blocks(float v) {   // lanes 4b+j, all
     return v;
 }
 
+// transposing butterfly over the 16 k-blocks of the 4x4x4 MFMA (lane = 4b + j; exchanges with lane ^ 32, 16, 8, 4): N live values
+// are halved per step while N > 1, the remaining steps reduce the single survivor plainly
+template <int V, int N, int OFF>
+__device__ __forceinline__ void tsum_blocks(float (&v)[V], int lane, int& idx) {
+    if constexpr (OFF >= 4) {
+        if constexpr (N > 1) {
+            const bool up = (lane & OFF) != 0;
+#pragma unroll
+            for (int i = 0; i < N / 2; ++i) {
+                const float send = up ? v[i] : v[i + N / 2];
+                const float keep = up ? v[i + N / 2] : v[i];
+                v[i] = keep + __shfl_xor(send, OFF);
+            }
+            if (up) idx += N / 2;
+            tsum_blocks<V, N / 2, OFF / 2>(v, lane, idx);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF);
+            tsum_blocks<V, 1, OFF / 2>(v, lane, idx);
+        }
+    }
+}
+
 template <int EPI, bool RMS, int MG, int G = 2>
-__global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
+__global__ __launch_bounds__(512) void k_gemv_mfma4(Q3_LIN_PRE, LinArgs a_in) {
+    Q3_LIN_APPLY(a, a_in);
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ float red[8][NW][MG][4][4];
     __shared__ float ssq[8][MG][4];
@@ -691,16 +836,28 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(LinArgs a) {
     return;
 #endif
     Q3T_W(2);
-    // sum the 16 k-blocks across lanes; lanes 0..3 (block 0) then hold D[i][j = lane] in acc[.][.][i]
+    zero_job(a.zero, a.zero_n, blockIdx.x, gridDim.x, tid, blockDim.x);
+    // Sum the 16 k-blocks (lanes 4b + j, all b) of the V = 4 * NW * MG values a lane holds. A plain butterfly costs 4 exchanges
+    // per value (32 at M = 8: 1 us of the launch in the frame's timeline); the TRANSPOSING butterfly hands half of the values
+    // to the partner at every step and keeps the other half — V/2 + V/4 + ... exchanges, 8 at M = 8 — and leaves value `idx`
+    // complete in the lanes whose block bits spell idx (replicated over the bits that were reduced plainly).
+    constexpr int V = 4 * NW * MG;
+    float vals[V];
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
         for (int g = 0; g < MG; ++g)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = sum_over_blocks(acc[w][g][i]);
-                if (lane < 4) red[wave][w][g][i][lane] = v;
-            }
+            for (int i = 0; i < 4; ++i) vals[(w * MG + g) * 4 + i] = acc[w][g][i];
+    int idx = 0;
+    tsum_blocks<V, V, 32>(vals, lane, idx);
+    // canonical writer of (idx, j): the lane whose plainly-reduced block bits are zero
+    constexpr int PLAIN_MASK = V >= 16 ? 0 : V == 8 ? 4 : V == 4 ? 12 : 28;
+    constexpr int R = V > 16 ? V / 16 : 1;          // survivors per lane (V = 32: two neighbouring values)
+    if ((lane & PLAIN_MASK) == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) (&red[wave][0][0][0][0])[(idx + r) * 4 + j] = vals[r];
+    }
     if constexpr (RMS) {
 #pragma unroll
         for (int g = 0; g < MG; ++g) {
@@ -747,16 +904,17 @@ static hipError_t launch_gemv4_t(const LinArgs& a, hipStream_t st) {
     // group is ragged (a ragged group still pays its split + MFMAs on a zero operand)
     const bool g3 = (S % nwv == 0) && ((S / nwv) % 3 == 0) && !RMS && EPI != EPI_SWIGLU;
     if (mg <= 1) {
-        if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1, 3>), dim3(tiles), dim3(nwv * 64), 0, st, a);
-        else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+        if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1, 3>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_LIN_PASS(a));
+        else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_LIN_PASS(a));
     } else if (mg == 2) {
-        if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2, 3>), dim3(tiles), dim3(nwv * 64), 0, st, a);
-        else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2>), dim3(tiles), dim3(nwv * 64), 0, st, a);
-    } else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 4>), dim3(tiles), dim3(nwv * 64), 0, st, a);
+        if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2, 3>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_LIN_PASS(a));
+        else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_LIN_PASS(a));
+    } else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 4>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_LIN_PASS(a));
     return hipGetLastError();
 }
 
 hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st) {
+    if (a.ksplit != 1) return hipErrorInvalidValue;
     if (a.Kpad % 128 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
         return hipErrorInvalidValue;
     const bool rms = a.norm_w != nullptr;
@@ -782,7 +940,8 @@ hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st) {
 constexpr int WS = 36;                      // staging pitch in floats (32 k + 4 pad)
 
 template <int EPI, bool RMS, int MT>
-__global__ __launch_bounds__(512) void k_gemv_wide(LinArgs a) {
+__global__ __launch_bounds__(512) void k_gemv_wide(Q3_LIN_PRE, LinArgs a_in) {
+    Q3_LIN_APPLY(a, a_in);
     constexpr int NWAVES = 8, G = 4, NX = 2 * MT;           // NX x-load instructions per k-step (8 rows each)
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int ZW = 16 * MT * WS;                        // staging floats per wave
@@ -919,9 +1078,9 @@ __global__ __launch_bounds__(512) void k_gemv_wide(LinArgs a) {
 template <int EPI, bool RMS>
 static hipError_t launch_gemv_wide_t(const LinArgs& a, hipStream_t st) {
     const int tiles = (a.N + 15) / 16, mt = (a.M + 15) / 16;
-    if (mt <= 2) hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 2>), dim3(tiles), dim3(512), 0, st, a);
-    else if (mt == 3) hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 3>), dim3(tiles), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 4>), dim3(tiles), dim3(512), 0, st, a);
+    if (mt <= 2) hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 2>), dim3(tiles), dim3(512), 0, st, Q3_LIN_PASS(a));
+    else if (mt == 3) hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 3>), dim3(tiles), dim3(512), 0, st, Q3_LIN_PASS(a));
+    else hipLaunchKernelGGL((k_gemv_wide<EPI, RMS, 4>), dim3(tiles), dim3(512), 0, st, Q3_LIN_PASS(a));
     return hipGetLastError();
 }
 static hipError_t launch_gemv_wide(const LinArgs& a, hipStream_t st) {
@@ -937,7 +1096,9 @@ static hipError_t launch_gemv_wide(const LinArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st) {
-    if (a.M > 16) return launch_gemv_wide(a, st);
+    if (a.M > 16) return a.ksplit > 1 ? hipErrorInvalidValue : launch_gemv_wide(a, st);
+    if (a.ksplit == 2) return launch_gemv_sk2(a, st);
+    if (a.ksplit != 1) return hipErrorInvalidValue;
     if (a.Kpad % 32 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)
         return hipErrorInvalidValue;
     const bool rms = a.norm_w != nullptr;

@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
             }
         }
     }
+    zero_job(a.zero, a.zero_n, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z, tid, 256);
     __syncthreads();
     Q3T(1);
 
@@ -726,9 +727,17 @@ __device__ __forceinline__ void tbutterfly(float (&s)[NK], int lane, int& key) {
     }
 }
 
+// Leading scalars = the 14 dwords every first request depends on, preloaded into SGPRs with the wave (see Q3_LIN_PRE in
+// q3_kernels_gemv.hip): K cache, q|k|v rows, this position's RoPE rows, the norm weights, V cache as a 32-bit float offset
+// from the K cache, and pos | max_seq << 8 | nh << 16 | nkv << 24.
 template <int NK>
-__global__ __launch_bounds__(64) void k_attn_cp(AttnArgs a) {
-    Q3T_DECL Q3T(0);
+__global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* p_qkv, const float* p_rc, const float* p_rs,
+                                                const float* p_qw, const float* p_kw, int p_vdelta, int p_pk, AttnArgs a_in) {
+    AttnArgs a = a_in;
+    a.pos_static = p_pk & 255; a.max_seq = (p_pk >> 8) & 255; a.nh = (p_pk >> 16) & 255; a.nkv = (p_pk >> 24) & 255;
+    a.kcache = const_cast<float*>(p_kc); a.vcache = const_cast<float*>(p_kc) + p_vdelta; a.qkv = p_qkv; a.q_norm_w = p_qw; a.k_norm_w = p_kw;
+    a.ld_qkv = (a.nh + 2 * a.nkv) * HEAD_DIM;
+    Q3T_DECL Q3T(0); Q3T_K(7, a.max_seq);
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int nrep = a.nh / a.nkv, kvh = h / nrep;
     const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
@@ -744,8 +753,8 @@ __global__ __launch_bounds__(64) void k_attn_cp(AttnArgs a) {
     }
     const float2 qw = *reinterpret_cast<const float2*>(a.q_norm_w + 2 * lane);
     const float2 kw = *reinterpret_cast<const float2*>(a.k_norm_w + 2 * lane);
-    const int ri = pos * 64 + ((2 * lane) & 63);
-    const float2 rc = *reinterpret_cast<const float2*>(a.rope_cos + ri), rs = *reinterpret_cast<const float2*>(a.rope_sin + ri);
+    const int ri = (2 * lane) & 63;                  // p_rc / p_rs point at this position's rows of the RoPE tables
+    const float2 rc = *reinterpret_cast<const float2*>(p_rc + ri), rs = *reinterpret_cast<const float2*>(p_rs + ri);
 
     const float* qkv_row = a.qkv + (size_t)b * a.ld_qkv;
     if (a.g_logits) {            // folded gather (AttnArgs::g_*): the row is the argmax of the previous pass's logits
@@ -787,6 +796,8 @@ __global__ __launch_bounds__(64) void k_attn_cp(AttnArgs a) {
     const float2 v = *reinterpret_cast<const float2*>(qkv_row + QD + KD + kvh * HEAD_DIM + 2 * lane);
 
     Q3T_W(1);
+    // side job behind the last load (vmcnt retires in issue order: a store ahead of the loads would sit in front of every wait for them)
+    zero_job(a.zero, a.zero_n, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, lane, 64);
     // per-head RMSNorm (x / sqrt(mean + eps) * w) and rotate-half RoPE with separately rounded products
     const bool upper = lane >= 32;
     auto norm_rope = [&](float2 x, const float2& w) {
@@ -836,15 +847,19 @@ __global__ __launch_bounds__(64) void k_attn_cp(AttnArgs a) {
 
 // single-row passes of a cache that never exceeds 16 positions, position known at launch (the code predictor)
 bool attn_cp_ok(const AttnArgs& a) {
+    const ptrdiff_t vd = a.vcache - a.kcache;
     return !a.pos_dev && a.rows_per_seq <= 1 && a.n_splits == 1 && a.pos_static >= 0 && a.pos_static < 16 && a.pos_static < a.max_seq &&
-           a.nkv > 0 && a.nh % a.nkv == 0 && a.ld_qkv % 2 == 0 && a.ld_out % 2 == 0 && (!a.g_logits || (a.g_proj_dim % 4 == 0 && a.g_ldx % 4 == 0));
+           a.max_seq < 256 && a.nkv > 0 && a.nh < 256 && a.nh % a.nkv == 0 && a.ld_qkv == (a.nh + 2 * a.nkv) * HEAD_DIM && a.ld_out % 2 == 0 &&
+           vd > -(ptrdiff_t)0x7fffffff && vd < (ptrdiff_t)0x7fffffff && (!a.g_logits || (a.g_proj_dim % 4 == 0 && a.g_ldx % 4 == 0));
 }
 hipError_t launch_attn_cp(const AttnArgs& a, hipStream_t st) {
     if (!attn_cp_ok(a)) return hipErrorInvalidValue;
     dim3 grid(a.nh, a.B);
-    if (a.pos_static < 4) hipLaunchKernelGGL(k_attn_cp<4>, grid, dim3(64), 0, st, a);
-    else if (a.pos_static < 8) hipLaunchKernelGGL(k_attn_cp<8>, grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(k_attn_cp<16>, grid, dim3(64), 0, st, a);
+    const float* rc = a.rope_cos + (size_t)a.pos_static * 64; const float* rs = a.rope_sin + (size_t)a.pos_static * 64;
+    const int vdelta = (int)(a.vcache - a.kcache), pk = a.pos_static | (a.max_seq << 8) | (a.nh << 16) | (a.nkv << 24);
+#define Q3_ACP(NK) hipLaunchKernelGGL(k_attn_cp<NK>, grid, dim3(64), 0, st, (const float*)a.kcache, a.qkv, rc, rs, a.q_norm_w, a.k_norm_w, vdelta, pk, a)
+    if (a.pos_static < 4) Q3_ACP(4); else if (a.pos_static < 8) Q3_ACP(8); else Q3_ACP(16);
+#undef Q3_ACP
     return hipGetLastError();
 }
 

@@ -14,6 +14,13 @@ pub mod ffi {
     pub struct Q3Request { pub mode: i32, pub text_ids: *const u32, pub n_text: i32, pub instruct_ids: *const u32, pub n_instruct: i32,
         pub speaker_id: u32, pub language_id: u32, pub xvector: *const f32, pub opts: Q3Options,
         pub ref_codes: *const u32, pub n_ref: i32, pub ref_text_ids: *const u32, pub n_ref_text: i32 }
+    /// q3_config (include/q3tts.h): 16 + 2 + 11 + 6 + 2 = 37 four-byte fields, same order
+    #[repr(C)] #[derive(Clone, Copy)]
+    pub struct Q3Config { pub text_vocab: i32, pub text_dim: i32, pub hidden: i32, pub inter: i32, pub n_layers: i32, pub n_heads: i32, pub n_kv_heads: i32,
+        pub head_dim: i32, pub codec_vocab: i32, pub cp_hidden: i32, pub cp_inter: i32, pub cp_layers: i32, pub cp_heads: i32, pub cp_kv_heads: i32,
+        pub cp_vocab: i32, pub n_groups: i32, pub rms_eps: f32, pub rope_theta: f32, pub dec_cb_dim: i32, pub dec_q_dim: i32, pub dec_latent: i32,
+        pub dec_hidden: i32, pub dec_layers: i32, pub dec_heads: i32, pub dec_head_dim: i32, pub dec_inter: i32, pub dec_cb_size: i32, pub dec_dim: i32,
+        pub dec_up_ratios: [i32; 2], pub dec_up_rates: [i32; 4], pub dec_eps: f32, pub dec_theta: f32 }
     #[repr(C)] #[derive(Default, Clone, Copy)]
     pub struct Q3Timing { pub prefill_ms: f64, pub generation_ms: f64, pub decode_ms: f64, pub generation_frames: i32 }
     #[repr(C)] #[derive(Clone, Copy, Default)]
@@ -28,6 +35,13 @@ pub mod ffi {
         pub fn q3_device_count() -> i32;
         pub fn q3_model_load(model_dir: *const c_char, device: i32, out: *mut *mut c_void, model_type: *mut i32) -> i32;
         pub fn q3_model_free(m: *mut c_void);
+        pub fn q3_model_create(cfg: *const Q3Config, device: i32, out: *mut *mut c_void) -> i32;
+        pub fn q3_config_default(variant: i32, out: *mut Q3Config) -> i32;
+        pub fn q3_model_n_tensors(m: *const c_void) -> i32;
+        pub fn q3_model_tensor_info(m: *const c_void, i: i32, name: *mut *const c_char, n: *mut i64, stored_dtype: *mut i32) -> i32;
+        pub fn q3_model_set_tensor(m: *mut c_void, name: *const c_char, dtype: i32, data: *const c_void, n: i64) -> i32;
+        pub fn q3_model_finalize(m: *mut c_void) -> i32;
+        pub fn q3_codes_to_tensor(frames: *const u32, n_frames: i32, out: *mut i64);
         pub fn q3_session_create(m: *mut c_void, reqs: *const Q3Request, batch: i32, out: *mut *mut c_void) -> i32;
         pub fn q3_session_prefill(s: *mut c_void) -> i32;
         pub fn q3_session_generate(s: *mut c_void, n_frames: i32, use_graph: i32) -> i32;
@@ -89,6 +103,17 @@ impl Language {
                      Self::French => 2061, Self::Russian => 2069, Self::Portuguese => 2071, Self::Spanish => 2054, Self::Italian => 2070 }
     }
 }
+/// talker.rs:73-88: case-insensitive names and the two-letter codes
+impl std::str::FromStr for Language {
+    type Err = anyhow::Error;
+    fn from_str(s: &str) -> std::result::Result<Self, Self::Err> {
+        const NAMES: [(&str, &str, Language); 10] = [("english", "en", Language::English), ("chinese", "zh", Language::Chinese),
+            ("japanese", "ja", Language::Japanese), ("korean", "ko", Language::Korean), ("german", "de", Language::German), ("french", "fr", Language::French),
+            ("russian", "ru", Language::Russian), ("portuguese", "pt", Language::Portuguese), ("spanish", "es", Language::Spanish), ("italian", "it", Language::Italian)];
+        let l = s.to_lowercase();
+        NAMES.iter().find(|(n, c, _)| l == *n || l == *c).map(|t| t.2).ok_or_else(|| anyhow!("Unknown language: {}", s))
+    }
+}
 /// talker.rs:111-157
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
 pub enum Speaker { Serena, Vivian, UncleFu, Ryan, Aiden, OnoAnna, Sohee, Eric, Dylan }
@@ -97,6 +122,44 @@ impl Speaker {
         match self { Self::Serena => 3066, Self::Vivian => 3065, Self::UncleFu => 3010, Self::Ryan => 3061, Self::Aiden => 2861,
                      Self::OnoAnna => 2873, Self::Sohee => 2864, Self::Eric => 2875, Self::Dylan => 2878 }
     }
+}
+
+/// talker.rs:127-143: case-insensitive names, with and without the underscore
+impl std::str::FromStr for Speaker {
+    type Err = anyhow::Error;
+    fn from_str(s: &str) -> std::result::Result<Self, Self::Err> {
+        const NAMES: [(&str, Speaker); 11] = [("ryan", Speaker::Ryan), ("serena", Speaker::Serena), ("vivian", Speaker::Vivian), ("aiden", Speaker::Aiden),
+            ("uncle_fu", Speaker::UncleFu), ("unclefu", Speaker::UncleFu), ("ono_anna", Speaker::OnoAnna), ("onoanna", Speaker::OnoAnna),
+            ("sohee", Speaker::Sohee), ("eric", Speaker::Eric), ("dylan", Speaker::Dylan)];
+        let l = s.to_lowercase();
+        NAMES.iter().find(|(n, _)| l == *n).map(|t| t.1).ok_or_else(|| anyhow!("Unknown speaker: {}", s))
+    }
+}
+impl Speaker {
+    /// talker.rs:160-171: the language a preset voice was recorded in
+    pub fn native_language(self) -> Language {
+        match self { Self::Ryan | Self::Aiden => Language::English, Self::OnoAnna => Language::Japanese, Self::Sohee => Language::Korean,
+                     Self::Serena | Self::Vivian | Self::UncleFu | Self::Eric | Self::Dylan => Language::Chinese }
+    }
+}
+
+/// A host tensor as `from_weights` takes it: the reference hands candle `Tensor`s (lib.rs:267-275); without candle the
+/// caller passes the checkpoint's bytes as they are stored (bf16 or f32, little-endian) with the element count.
+pub struct HostTensor<'a> { pub bf16: bool, pub data: &'a [u8] }
+impl HostTensor<'_> { fn elems(&self) -> i64 { (self.data.len() / if self.bf16 { 2 } else { 4 }) as i64 } }
+
+/// `[1, 16, T]` i64, `data[q * T + f]` — what `codes_to_tensor` (lib.rs:1417-1431) builds as a candle tensor
+#[derive(Clone, Debug, PartialEq, Eq)]
+pub struct CodesTensor { pub data: Vec<i64>, pub shape: [usize; 3] }
+
+/// lib.rs:1417-1431: frames of 16 codebook values -> `[1, 16, T]`; a frame with another length is an error
+pub fn codes_to_tensor(codes: &[Vec<u32>]) -> Result<CodesTensor> {
+    let t = codes.len();
+    if let Some(bad) = codes.iter().find(|f| f.len() != 16) { bail!("codes_to_tensor: frame with {} values (expected 16)", bad.len()) }
+    let flat: Vec<u32> = codes.iter().flatten().copied().collect();
+    let mut data = vec![0i64; 16 * t];
+    if t > 0 { unsafe { q3_codes_to_tensor(flat.as_ptr(), t as i32, data.as_mut_ptr()) } }
+    Ok(CodesTensor { data, shape: [1, 16, t] })
 }
 
 /// lib.rs:1786-1836 (same fields, same defaults)
@@ -174,11 +237,17 @@ impl Qwen3TTS {
     /// lib.rs:183-261: config.json + model.safetensors + speech_tokenizer/model.safetensors (q3_model_load), tokenizer.json,
     /// the speaker encoder of Base checkpoints (lib.rs:233-249) and the speech encoder (lib.rs:251-258)
     pub fn from_pretrained(model_dir: &str, device: Device) -> Result<Self> {
+        Self::from_pretrained_with_tokenizer(model_dir, None, device)
+    }
+    fn from_pretrained_no_tokenizer(model_dir: &str, device: Device, tokenizer: tokenizers::Tokenizer) -> Result<Self> {
         let (mut h, mut mt) = (std::ptr::null_mut(), -1i32);
         check(unsafe { q3_model_load(cstr(model_dir).as_ptr(), device.0, &mut h, &mut mt) })?;
-        let tokenizer = tokenizers::Tokenizer::from_file(Path::new(model_dir).join("tokenizer.json")).map_err(|e| anyhow!("Failed to load tokenizer: {e}"))?;
-        let mut me = Self { model: h, spk: std::ptr::null_mut(), speech: std::ptr::null_mut(), spk_dim: 0, tokenizer,
-                            model_type: match mt { 0 => Some(ModelType::Base), 1 => Some(ModelType::CustomVoice), 2 => Some(ModelType::VoiceDesign), _ => None }, device };
+        Ok(Self { model: h, spk: std::ptr::null_mut(), speech: std::ptr::null_mut(), spk_dim: 0, tokenizer,
+                  model_type: match mt { 0 => Some(ModelType::Base), 1 => Some(ModelType::CustomVoice), 2 => Some(ModelType::VoiceDesign), _ => None }, device })
+    }
+    /// the speaker encoder of Base checkpoints (lib.rs:233-249) and the speech encoder (lib.rs:251-258)
+    fn attach_encoders(&mut self, model_dir: &str) -> Result<()> {
+        let me = self; let device = me.device;
         let main = cstr(&format!("{model_dir}/model.safetensors"));
         let mut probe = 0i32;
         if unsafe { q3_safetensors_info(main.as_ptr(), cstr("speaker_encoder.fc.weight").as_ptr(), &mut probe, std::ptr::null_mut(), 0, std::ptr::null_mut()) } == 0 {
@@ -198,6 +267,43 @@ impl Qwen3TTS {
                 me.speech = std::ptr::null_mut();
             }
         }
+        Ok(())
+    }
+    /// lib.rs:192-261: as `from_pretrained`, the tokenizer taken from `tokenizer_id` — a directory holding tokenizer.json or
+    /// the file itself; `None` = the model directory. (The reference also accepts a Hugging Face model id and downloads
+    /// it; this build has no hub client — SURVEY.md §2 marks it out of scope — so an id that is not a path is an error.)
+    pub fn from_pretrained_with_tokenizer(model_dir: &str, tokenizer_id: Option<&str>, device: Device) -> Result<Self> {
+        let tok_path = match tokenizer_id {
+            None => Path::new(model_dir).join("tokenizer.json"),
+            Some(id) if Path::new(id).is_dir() => Path::new(id).join("tokenizer.json"),
+            Some(id) if Path::new(id).is_file() => Path::new(id).to_path_buf(),
+            Some(id) => bail!("tokenizer '{id}' is neither a directory nor a file (hub ids are not supported by this build)"),
+        };
+        let tokenizer = tokenizers::Tokenizer::from_file(&tok_path).map_err(|e| anyhow!("Failed to load tokenizer: {e}"))?;
+        let mut me = Self::from_pretrained_no_tokenizer(model_dir, device, tokenizer)?;
+        me.attach_encoders(model_dir)?;
+        Ok(me)
+    }
+    /// lib.rs:267-275: pre-loaded weight maps (talker + code predictor, decoder) instead of a directory. Model size by
+    /// weight inspection as lib.rs:371-381 does it (the talker's hidden width), no speaker / speech encoder attached.
+    pub fn from_weights(model_weights: &std::collections::HashMap<String, HostTensor>, decoder_weights: &std::collections::HashMap<String, HostTensor>,
+                        text_tokenizer: tokenizers::Tokenizer, device: Device) -> Result<Self> {
+        let hidden = model_weights.get("talker.model.norm.weight").map(|t| t.elems()).ok_or_else(|| anyhow!("from_weights: talker.model.norm.weight missing"))?;
+        let mut cfg = std::mem::MaybeUninit::<Q3Config>::uninit();
+        check(unsafe { q3_config_default(if hidden >= 2048 { 1 } else { 0 }, cfg.as_mut_ptr()) })?;
+        let mut h = std::ptr::null_mut();
+        check(unsafe { q3_model_create(cfg.as_ptr(), device.0, &mut h) })?;
+        let me = Self { model: h, spk: std::ptr::null_mut(), speech: std::ptr::null_mut(), spk_dim: 0, tokenizer: text_tokenizer, model_type: None, device };
+        for i in 0..unsafe { q3_model_n_tensors(h) } {
+            let (mut name, mut n, mut dt) = (std::ptr::null(), 0i64, 0i32);
+            check(unsafe { q3_model_tensor_info(h, i, &mut name, &mut n, &mut dt) })?;
+            let key = unsafe { CStr::from_ptr(name) }.to_string_lossy().into_owned();
+            let t = model_weights.get(&key).or_else(|| decoder_weights.get(key.strip_prefix("decoder.").map(|_| key.as_str()).unwrap_or(&key)))
+                .ok_or_else(|| anyhow!("from_weights: tensor {key} missing"))?;
+            if t.elems() != n { bail!("from_weights: {key} has {} elements, expected {n}", t.elems()) }
+            check(unsafe { q3_model_set_tensor(h, name, if t.bf16 { 1 } else { 0 }, t.data.as_ptr() as *const c_void, n) })?;
+        }
+        check(unsafe { q3_model_finalize(h) })?;
         Ok(me)
     }
     pub fn model_type(&self) -> Option<ModelType> { self.model_type }
@@ -292,6 +398,8 @@ impl Qwen3TTS {
         Ok((AudioBuffer::new(pcm, 24000), flat[..nf as usize * 16].chunks(16).map(|c| c.to_vec()).collect()))
     }
     /// lib.rs:881-890
+    /// lib.rs:873-875
+    pub fn codes_to_tensor(&self, codes: &[Vec<u32>]) -> Result<CodesTensor> { codes_to_tensor(codes) }
     pub fn decode_codes(&self, codes: &[Vec<u32>]) -> Result<AudioBuffer> {
         let flat: Vec<u32> = codes.iter().flat_map(|f| f.iter().copied()).collect();
         let mut pcm = vec![0f32; codes.len() * SAMPLES_PER_FRAME];
@@ -334,7 +442,17 @@ impl StreamingSession<'_> {
     }
     pub fn is_done(&self) -> bool { self.done }                             // lib.rs:1766-1769
 }
-impl Iterator for StreamingSession<'_> {                                    // lib.rs:1772-1782
+/// lib.rs:1772-1782, error contract included: a failing `next_chunk` is yielded as `Some(Err(e))` and the session STAYS
+/// pollable — `done` is only set by the engine's own end-of-stream flag, so the next call retries the chunk (the C ABI
+/// leaves the session's frame state untouched when it returns an error: include/q3tts.h, q3_session_next_chunk);
+/// `None` comes only after the flush of the last partial chunk.
+impl Iterator for StreamingSession<'_> {
     type Item = Result<AudioBuffer>;
-    fn next(&mut self) -> Option<Self::Item> { self.next_chunk().transpose() }
+    fn next(&mut self) -> Option<Self::Item> {
+        match self.next_chunk() {
+            Ok(Some(audio)) => Some(Ok(audio)),
+            Ok(None) => None,
+            Err(e) => Some(Err(e)),
+        }
+    }
 }

@@ -138,3 +138,58 @@ def _check_bench_line(d):
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and len(c["sample"]) > 10
+
+
+def _dumps(tmp_path, codes, pcm, seed=7):
+    n = codes.shape[0]
+    api.save_codes_binary(str(tmp_path / f"codes_seed{seed}_frames{n}.bin"), codes)
+    api.save_audio_binary(str(tmp_path / f"audio_seed{seed}_frames{n}.bin"), pcm)
+    with open(tmp_path / f"metadata_seed{seed}_frames{n}.json", "w") as f:
+        json.dump({"seed": seed, "num_frames": n}, f)
+
+
+def test_compare_with_reference_match_and_mismatch(tmp_path):
+    """The pin hook (generate_audio.rs:816-931) on synthetic dumps: identical codes + PCM within 1e-3 RMS pin, a single flipped
+    code is located by (frame, group), PCM verdicts follow the reference's MATCH / CLOSE / DIFFERENT thresholds."""
+    rng = np.random.default_rng(0)
+    codes = rng.integers(0, 2048, size=(12, 16)).astype(np.uint32)
+    pcm = (0.2 * rng.standard_normal(12 * 1920)).astype(np.float32)
+    _dumps(tmp_path, codes, pcm)
+    assert api.load_audio_binary(str(tmp_path / "audio_seed7_frames12.bin")).tobytes() == pcm.tobytes()
+    lines = []
+    rep = cli.compare_with_reference(str(tmp_path), 7, 12, codes, pcm + np.float32(2e-6), out=lines.append)
+    assert rep["codes_match"] and rep["n_diff"] == 0 and rep["status"] == "MATCH" and rep["pinned"] is True
+    assert any("Codes: MATCH (all 192 values identical)" in l for l in lines) and any("PINNED" in l for l in lines)
+    # one flipped code-predictor decision in frame 5, group 9
+    bad = codes.copy(); bad[5, 9] ^= 1
+    lines = []
+    rep = cli.compare_with_reference(str(tmp_path), 7, 12, bad, pcm + np.float32(5e-4), out=lines.append)
+    assert rep["codes_match"] is False and rep["n_diff"] == 1 and rep["first_diff"] == (5, 9)
+    assert rep["status"] == "CLOSE" and rep["pinned"] is False and 4e-4 < rep["rmse"] < 6e-4
+    assert any("Index 89 (frame 5, group 9)" in l for l in lines) and any("NOT pinned" in l for l in lines)
+    # different lengths / large PCM error
+    rep = cli.compare_with_reference(str(tmp_path), 7, 12, codes[:11], pcm[:11 * 1920] * 0.5, out=lambda *_: None)
+    assert rep["codes_match"] is False and rep["status"] == "DIFFERENT" and rep["pinned"] is False
+
+
+def test_compare_with_reference_missing_files(tmp_path):
+    lines = []
+    rep = cli.compare_with_reference(str(tmp_path), 1, 4, np.zeros((4, 16), np.uint32), np.zeros(4 * 1920, np.float32), out=lines.append)
+    assert rep["codes_found"] is False and rep["audio_found"] is False and rep["pinned"] is None
+    assert sum("reference not found" in l for l in lines) == 2
+    a = cli.build_parser().parse_args(["--compare", "--reference-dir", "x", "--custom-voice"])
+    assert a.compare and a.reference_dir == "x" and a.custom_voice and not a.compare_strict
+    assert cli.build_parser().parse_args([]).reference_dir == "test_data/reference_audio"     # generate_audio.rs:73-75
+
+
+@pytest.mark.gpu
+def test_cli_compare_round_trip(tmp_path):
+    """--compare end to end: a first run writes the dumps (EOS off, fixed length), a second run with the same flags compares
+    against them and pins; a run with another seed is reported as diverging and --compare-strict turns that into exit 1."""
+    base = ["--synthetic", "tiny", "--text", "pin me down", "--frames", "9", "--temperature", "0.9", "--output-dir"]
+    assert cli.main(base + [str(tmp_path / "ref"), "--seed", "5", "--compare", "--reference-dir", str(tmp_path / "none")]) == 0
+    assert os.path.exists(tmp_path / "ref" / "codes_seed5_frames9.bin")          # --compare ran all 9 frames (no EOS)
+    assert cli.main(base + [str(tmp_path / "a"), "--seed", "5", "--compare", "--compare-strict", "--reference-dir", str(tmp_path / "ref")]) == 0
+    os.rename(tmp_path / "ref" / "codes_seed5_frames9.bin", tmp_path / "ref" / "codes_seed6_frames9.bin")
+    os.rename(tmp_path / "ref" / "audio_seed5_frames9.bin", tmp_path / "ref" / "audio_seed6_frames9.bin")
+    assert cli.main(base + [str(tmp_path / "b"), "--seed", "6", "--compare", "--compare-strict", "--reference-dir", str(tmp_path / "ref")]) == 1

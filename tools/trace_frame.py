@@ -59,7 +59,7 @@ for i in range(N):
     out = np.nanmax(rel[:, 4])
     r = {"i": i, "name": name(meta[i]), "wgs": int(ok.sum()), "gap": (t0 - prev_out) * 0.01 if prev_out is not None else np.nan,
          "skew": float(rel[:, 0].max()), "tot": float(out)}
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 7):
         col = rel[:, k]
         r[f"s{k}m"] = float(np.nanmedian(col)) if np.isfinite(col).any() else np.nan
         r[f"s{k}x"] = float(np.nanmax(col)) if np.isfinite(col).any() else np.nan
@@ -91,13 +91,13 @@ agg = {}
 for r in rows:
     if r: agg.setdefault(r["name"], []).append(r)
 print("\n# mean per kernel shape (count = nodes per frame)")
-print(f"{'kernel':44} {'cnt':>4} {'WGs':>4} {'gap':>6} {'skew':>5} | {'in med/max':>11} {'loop med/max':>12} {'st med/max':>11} {'ack med/max':>11} | {'total':>6} {'sum us':>7}"
+print(f"{'kernel':44} {'cnt':>4} {'WGs':>4} {'gap':>6} {'skew':>5} | {'karg':>5} {'in med/max':>11} {'loop med/max':>12} {'st med/max':>11} {'ack med/max':>11} | {'total':>6} {'sum us':>7}"
       f" | waves: {'entry max':>9} {'loop min/med/max':>17} {'part max':>8} {'barrier':>7} {'tail':>5}")
 tot_all = 0.0
 for nme, rs in sorted(agg.items(), key=lambda kv: -sum(r["tot"] for r in kv[1])):
     f = lambda k: float(np.nanmean([r[k] for r in rs]))
     ssum = sum(r["tot"] for r in rs); tot_all += ssum
-    print(f"{nme:44} {len(rs):4d} {rs[0]['wgs']:4d} {f('gap'):6.2f} {f('skew'):5.2f} | {f('s1m'):5.2f}/{f('s1x'):5.2f} {f('s2m'):6.2f}/{f('s2x'):5.2f} "
+    print(f"{nme:44} {len(rs):4d} {rs[0]['wgs']:4d} {f('gap'):6.2f} {f('skew'):5.2f} | {f('s7m'):5.2f} {f('s1m'):5.2f}/{f('s1x'):5.2f} {f('s2m'):6.2f}/{f('s2x'):5.2f} "
           f"{f('s3m'):5.2f}/{f('s3x'):5.2f} {f('s4m'):5.2f}/{f('s4x'):5.2f} | {f('tot'):6.2f} {ssum:7.1f}", end="")
     rd = [r for r in rs if "w2" in r]
     if rd:
