@@ -28,6 +28,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def rocprof_in_situ(avg_bytes_per_launch):
+    """GEMV-family launches inside the captured frame graph, from the committed rocprofv3 --kernel-trace --stats table of this
+    same command (profiles/r3_rocprof_kernel_stats_bench_b8.txt: `kernel calls avg_us ms_per_run` rows): calls-weighted mean
+    duration of the k_gemv_* symbols, priced with this run's algorithmic bytes per launch."""
+    for name in ("r3_rocprof_kernel_stats_bench_b8.txt", "r2_rocprof_kernel_stats_bench_b8_final.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        calls = us = 0.0
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 4 and "k_gemv" in f[0]:
+                try:
+                    calls += float(f[-3]); us += float(f[-3]) * float(f[-2])
+                except ValueError:
+                    pass
+        if calls:
+            avg = us / calls
+            return {"source": f"profiles/{name}", "launches": int(calls), "avg_launch_us": avg, "gbps": avg_bytes_per_launch / avg / 1e3,
+                    "frac": avg_bytes_per_launch / avg / 1e3 / 8000.0}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +71,7 @@ def main():
     ap.add_argument("--cpu-frames-single", type=int, default=3, help="frames of the single-thread CPU-baseline sample (~10 s)")
     ap.add_argument("--profile-frames", type=int, default=6)
     ap.add_argument("--ttfa-reps", type=int, default=5)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE.json side configurations (greedy, x-vector, 4k-token VoiceDesign, 0.6B single utterance)")
     args = ap.parse_args()
 
     import numpy as np
@@ -148,7 +172,26 @@ def main():
     frames_rank = sum(t.generation_frames for t in timings)
     frames_total = dp.sum_over_ranks(float(frames_rank), device=f"cuda:{dev}" if world > 1 else None)
 
+    # what the collective library actually saw (so that a SCALE record can be checked from the JSON alone)
+    rccl = {"world": 1, "backend": None, "ranks_seen": [[0, dev]]}
+    if world > 1:
+        import torch.distributed as dist
+        mine = torch.tensor([rank, dev], dtype=torch.int64, device=f"cuda:{dev}" if not same_gpu else "cpu")
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        rccl = {"world": dist.get_world_size(), "backend": dist.get_backend(), "ranks_seen": [[int(t[0]), int(t[1])] for t in seen],
+                "same_gpu_test_mode": same_gpu}
+
+    def finish():
+        # every rank leaves through the same door: ranks != 0 wait here until rank 0 has printed its line (its roofline /
+        # latency extras take tens of seconds; the collective timeout is minutes), then the group is torn down
+        if world > 1:
+            import torch.distributed as dist
+            dp.barrier()
+            dist.destroy_process_group()
+
     if rank != 0:
+        finish()
         return
 
     ms_per_step = elapsed / args.steps * 1000.0
@@ -182,10 +225,16 @@ def main():
         assert count % pf == 0, (Mr, N, K, count, pf)
         cnt = count // pf
         nb = N * K * 2 * (2 if epi == 3 else 1)
-        us = bench_linear(Mr, N, K, epi, rms, tiled=tiled, device=dev)
+        try:
+            us = bench_linear(Mr, N, K, epi, rms, tiled=tiled, device=dev)
+        except Exception as e:          # a shape the replay harness refuses (tiny test configurations): leave it out of the sum
+            per_shape[f"M={Mr} N={N} K={K} {EPI[epi]} norm={rms} tile={tiled}"] = {"error": str(e), "launches_per_frame": cnt}
+            continue
         per_shape[f"M={Mr} N={N} K={K} {EPI[epi]} norm={rms} tile={ {1: '16', 2: '4', 3: '16 split-K2'}.get(tiled, tiled) }"] = \
             {"us": us, "gbps": nb / us / 1e3, "launches_per_frame": cnt}
         tot_bytes += nb * cnt; tot_us += us * cnt; launches += cnt
+    if not launches:
+        tot_bytes, tot_us, launches = 1.0, 1.0, 1
     achieved = tot_bytes / tot_us / 1e3     # GB/s
     # HBM traffic per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_collect.sh) — PMC counters cannot be read from inside the run
@@ -211,9 +260,12 @@ def main():
                           "weight copies, HIP events on the launch stream, mean of 5 replays x 200 launches",
                 "launches_per_frame": launches, "avg_launch_us": tot_us / launches, "avg_bytes_per_launch": tot_bytes / launches,
                 "gemv_us_per_frame": tot_us, "per_shape": per_shape,
-                "in_situ": {"what": "HIP event pairs around every GEMV launch of real frames (eager launches, profiling session)",
+                "in_situ": {"what": "HIP event pairs around every GEMV launch of real frames (EAGER launches in a profiling session): inflated by the "
+                                    "event records and the host launch path — a lower bound on the in-graph rate, not the figure to trust; the in-graph "
+                                    "in-situ figure is rocprof_in_situ below",
                             "launches_per_frame": insitu_n / pf, "avg_launch_us": insitu_ms * 1e3 / max(insitu_n, 1),
                             "gbps": insitu_bytes / max(insitu_ms, 1e-9) / 1e6, "frac": insitu_bytes / max(insitu_ms, 1e-9) / 1e6 / 8000.0},
+                "rocprof_in_situ": rocprof_in_situ(tot_bytes / launches),
                 "frame_weight_bytes": wbytes, "frame_kv_bytes": kvbytes,
                 "frame_model_gbps": (wbytes + kvbytes) / (stage["generation_ms"] / 1000.0 / args.frames) / 1e9}
 
@@ -252,6 +304,40 @@ def main():
                              "stage_ms": {"prefill_ms": tw.prefill_ms, "generation_ms": tw.generation_ms, "decode_ms": tw.decode_ms}}
         except Exception as e:
             wide[str(bb)] = {"error": str(e)}
+
+    # ---- BASELINE.json's other configurations, same step definition, one warm + one timed step each (N = 1 only) ----
+    others = {}
+    if world == 1 and not args.no_other_configs and args.workload == "customvoice" and args.sampling == "default":
+        def timed(mdl, uu, oo, reps=1):
+            sw = mdl.session(uu, oo); sw.run_timing_only(use_graph=use_graph); sw.close()           # warm (graph capture, session-shape cache)
+            best = None
+            for _ in range(reps):
+                sw = mdl.session(uu, oo); ta = time.perf_counter(); tt = sw.run_timing_only(use_graph=use_graph); wall = time.perf_counter() - ta; sw.close()
+                if best is None or wall < best[0]:
+                    best = (wall, tt)
+            wall, tt = best
+            return {"frames_per_s": tt.generation_frames / wall, "rtf_per_utterance": wall / (args.frames * 0.08), "ms_per_frame": tt.generation_ms / args.frames,
+                    "stage_ms": {"prefill_ms": tt.prefill_ms, "generation_ms": tt.generation_ms, "decode_ms": tt.decode_ms}, "utterances": len(uu)}
+        def guarded(name, fn):
+            try:
+                others[name] = fn()
+            except Exception as e:      # side configurations must never kill the headline line
+                others[name] = {"error": str(e)}
+        saved = args.workload
+        guarded(f"{args.model}_greedy_b{B}", lambda: timed(model, utts, q.SynthesisOptions(max_length=args.frames, eos_token_id=None, seed=42, temperature=0.0)))
+        args.workload = "xvector"
+        guarded(f"{args.model}_xvector_b{B}", lambda: timed(model, [make_utt(i) for i in range(B)], opts))
+        args.workload = "voicedesign4k"
+        guarded(f"{args.model}_voicedesign4k_b1", lambda: timed(model, [make_utt(0)], opts))
+        args.workload = saved
+        if args.model == "1.7b":
+            def small():
+                m06 = q.Qwen3TTS.from_synthetic(q.qwen3_tts_0_6b(), device=dev, seed=synth.DEFAULT_SEED)
+                try:
+                    return timed(m06, [q.Utterance(synthetic_prompt(args.prompt_tokens, 0), q.Speaker.Ryan, q.Language.English, seed=42)], opts)
+                finally:
+                    m06.close()
+            guarded("0.6b_customvoice_b1", small)
 
     # ---- CPU baseline: the oracle (port of the candle-CPU F32 path) on this host, bounded sample ----
     cpu = None
@@ -307,14 +393,17 @@ def main():
                                f"{args.prompt_tokens}-token prompts, {args.workload} prefill, {args.frames} frames each "
                                f"(eos off), {args.sampling} sampling, non-streaming prefill+generate+decode",
                    "utterances_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"dp{world}",
-                   "weights": "bf16", "activations_kv": "f32", "hip_graph": use_graph, "prefill": args.workload, "sampling": args.sampling,
+                   "weights": "bf16", "activations_kv": "f32",
+                   "kv": "f32, in place (2x the bytes of the reference GPU path's bf16 cache, kv_cache.rs:234-310: the parity contract is the CPU F32 path)",
+                   "hip_graph": use_graph, "prefill": args.workload, "sampling": args.sampling,
                    "pcm_copy_out": False},     # PCM stays in HBM inside the timed step (39 MB / step D2H at B = 8 would add < 0.5 %)
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,
                                                         "gbps": (bcast_bytes / bcast_s / 1e9) if bcast_s > 0 else None},
-        "roofline": roofline, "cpu_baseline": cpu, "other_batches": wide,
+        "roofline": roofline, "cpu_baseline": cpu, "other_batches": wide, "other_configs": others, "rccl": rccl,
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    finish()
 
 
 if __name__ == "__main__":

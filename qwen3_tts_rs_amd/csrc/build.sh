@@ -2,11 +2,15 @@
 # Builds libq3tts.so (gfx950) in-tree: qwen3_tts_rs_amd/libq3tts.so
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../libq3tts.so"
-BUILD="$HERE/../../build"
+# A/B aids: Q3_BUILD_OUT / Q3_BUILD_DIR = another library / object directory, Q3_BUILD_EXTRA = extra hipcc flags,
+# Q3_NO_PRELOAD=1 = without kernel-argument preload
+OUT="${Q3_BUILD_OUT:-$HERE/../libq3tts.so}"
+BUILD="${Q3_BUILD_DIR:-$HERE/../../build}"
 mkdir -p "$BUILD"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=14 -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value"
+PRELOAD="-mllvm -amdgpu-kernarg-preload-count=14"
+[ -n "$Q3_NO_PRELOAD" ] && PRELOAD=""
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC $PRELOAD -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value $Q3_BUILD_EXTRA"
 pids=()
 for f in q3_kernels_lm q3_kernels_gemv q3_kernels_codec q3_kernels_prefill q3_engine q3_speaker q3_mimi; do
   if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/q3_kernels.h" -nt "$BUILD/$f.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/$f.o" ]; then

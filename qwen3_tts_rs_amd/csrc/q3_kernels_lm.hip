@@ -459,8 +459,14 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
 // code predictor's case: 16 positions at most). Every split block re-derives the (tiny) normed/roped q heads
 // and the new K/V row in LDS; the split that owns position `pos` appends them to the cache, and every block
 // takes position `pos` from LDS, never from the just-written global memory.
+// Leading scalars: the 14 dwords the first requests depend on, preloaded into SGPRs (see k_attn_cp): position array, caches,
+// q|k|v rows, norm weights, max_seq and n_splits | nkv << 8 | nh << 16.
 template <int NREP>
-__global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
+__global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const float* p_kc, const float* p_vc, const float* p_qkv, const float* p_qw,
+                                                    const float* p_kw, int p_max_seq, int p_pk, AttnArgs a_in) {
+    AttnArgs a = a_in;
+    a.pos_dev = p_pos; a.kcache = const_cast<float*>(p_kc); a.vcache = const_cast<float*>(p_vc); a.qkv = p_qkv; a.q_norm_w = p_qw; a.k_norm_w = p_kw;
+    a.max_seq = p_max_seq; a.n_splits = p_pk & 255; a.nkv = (p_pk >> 8) & 255; a.nh = (p_pk >> 16) & 255;
     __shared__ __attribute__((aligned(16))) float s_q[NREP][HEAD_DIM];
     __shared__ __attribute__((aligned(16))) float s_k[HEAD_DIM], s_v[HEAD_DIM];
     __shared__ float sm_m[NREP][8], sm_l[NREP][8];
@@ -608,11 +614,13 @@ __global__ __launch_bounds__(256) void k_attn_fused(AttnArgs a) {
 
 hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
     const int nrep = a.nh / a.nkv;
+    if (a.n_splits > 255 || a.nh > 255 || a.nkv > 255) return hipErrorInvalidValue;
     dim3 grid(a.n_splits, a.nkv, a.B);
-    if (nrep == 1) hipLaunchKernelGGL(k_attn_fused<1>, grid, dim3(256), 0, st, a);
-    else if (nrep == 2) hipLaunchKernelGGL(k_attn_fused<2>, grid, dim3(256), 0, st, a);
-    else if (nrep == 4) hipLaunchKernelGGL(k_attn_fused<4>, grid, dim3(256), 0, st, a);
+    const int pk = a.n_splits | (a.nkv << 8) | (a.nh << 16);
+#define Q3_AF(R) hipLaunchKernelGGL(k_attn_fused<R>, grid, dim3(256), 0, st, a.pos_dev, (const float*)a.kcache, (const float*)a.vcache, a.qkv, a.q_norm_w, a.k_norm_w, a.max_seq, pk, a)
+    if (nrep == 1) Q3_AF(1); else if (nrep == 2) Q3_AF(2); else if (nrep == 4) Q3_AF(4);
     else return hipErrorInvalidValue;
+#undef Q3_AF
     return hipGetLastError();
 }
 
@@ -707,24 +715,30 @@ hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
 // Slot p of the NK key slots is the cached row p for p < pos, the new token (registers, never the just-written
 // memory) for p == pos, and masked beyond. The q-head-0 wave of each kv group appends K / V.
 // ------------------------------------------------------------------------------------------------
-// transposing butterfly of k_attn_cp: N live values per lane, exchanged with lane ^ OFF; ends with s[0] = the complete sum of
-// value `key` over all 64 lanes
-template <int NK, int N, int OFF>
-__device__ __forceinline__ void tbutterfly(float (&s)[NK], int lane, int& key) {
-    if constexpr (N > 1) {
-        const bool up = (lane & OFF) != 0;
-#pragma unroll
-        for (int i = 0; i < N / 2; ++i) {
-            const float send = up ? s[i] : s[i + N / 2];
-            const float keep = up ? s[i + N / 2] : s[i];
-            s[i] = keep + __shfl_xor(send, OFF);
-        }
-        if (up) key += N / 2;
-        tbutterfly<NK, N / 2, OFF / 2>(s, lane, key);
-    } else {
-#pragma unroll
-        for (int off = OFF; off >= 1; off >>= 1) s[0] += __shfl_xor(s[0], off);
-    }
+// ---- VALU-only cross-lane moves (k_attn_cp): a ds_bpermute (what __shfl_xor compiles to) is an LDS-pipe round trip of
+// ~60 ns, and the kernel's first generation chained 17 of them behind its loads (1.65 us of a 2.9 us launch in the frame's
+// timeline); DPP row rotations, v_permlane16/32_swap (gfx950) and v_readlane run at VALU latency ----
+template <int N> __device__ __forceinline__ float row_ror(float v) {          // lane i of each 16-lane row reads lane (i + N) % 16
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false); }
+// sum over the 16 lanes of a row, identical bits in every lane of the row (each step pairs lanes symmetrically)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+    return v;
+}
+__device__ __forceinline__ float lane_xor32(float v, bool upper) {            // value of lane ^ 32
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(upper ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor16(float v, bool odd_row) {          // value of lane ^ 16
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(odd_row ? r[0] : r[1]);
+}
+__device__ __forceinline__ float read_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_sum_valu(float v) {                      // uniform result
+    v = row_sum16(v);
+    return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 
 // Leading scalars = the 14 dwords every first request depends on, preloaded into SGPRs with the wave (see Q3_LIN_PRE in
@@ -738,6 +752,9 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
     a.kcache = const_cast<float*>(p_kc); a.vcache = const_cast<float*>(p_kc) + p_vdelta; a.qkv = p_qkv; a.q_norm_w = p_qw; a.k_norm_w = p_kw;
     a.ld_qkv = (a.nh + 2 * a.nkv) * HEAD_DIM;
     Q3T_DECL Q3T(0); Q3T_K(7, a.max_seq);
+#ifdef Q3_TRACE
+    q3t_[5] = (unsigned long long)clock64();          // shader-clock counter beside the 100 MHz stamps: the clock the frame loop really runs at
+#endif
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int nrep = a.nh / a.nkv, kvh = h / nrep;
     const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
@@ -777,18 +794,24 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         } else {
             for (int j = lane; j < a.g_vocab; j += 64) { const float v = lg[j]; if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; } }
         }
+        // first-max over the wave: DPP rotations inside the rows (the combine is symmetric, so every lane of a row ends with the
+        // row's winner), then the four row winners by v_readlane
+        argmax_combine(bv, bi, row_ror<8>(bv), row_ror_i<8>(bi)); argmax_combine(bv, bi, row_ror<4>(bv), row_ror_i<4>(bi));
+        argmax_combine(bv, bi, row_ror<2>(bv), row_ror_i<2>(bi)); argmax_combine(bv, bi, row_ror<1>(bv), row_ror_i<1>(bi));
+        {
+            float wv = read_lane(bv, 0); int wi = __builtin_amdgcn_readlane(bi, 0);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off); const int oi = __shfl_xor(bi, off);
-            argmax_combine(bv, bi, ov, oi);
+            for (int r = 1; r < 4; ++r) argmax_combine(wv, wi, read_lane(bv, 16 * r), __builtin_amdgcn_readlane(bi, 16 * r));
+            bv = wv; bi = wi;
         }
         const int row = bi == 0x7fffffff ? 0 : bi;
         qkv_row = a.g_qkv_tab + (size_t)row * a.ld_qkv;
-        if (h == 0) {
+        {   // the residual-stream row: every head's wave copies its share (one wave copying all of it finished 2.4 us after the others)
+            const int per = (((a.g_proj_dim / 4) + a.nh - 1) / a.nh), c0 = h * per, c1 = (c0 + per) < a.g_proj_dim / 4 ? (c0 + per) : a.g_proj_dim / 4;
             const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
             float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
-            for (int c = lane; c < a.g_proj_dim / 4; c += 64) pd[c] = ps[c];
-            if (lane == 0) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
+            for (int c = c0 + lane; c < c1; c += 64) pd[c] = ps[c];
+            if (h == 0 && lane == 0) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
         }
     }
     float2 q = *reinterpret_cast<const float2*>(qkv_row + h * HEAD_DIM + 2 * lane);
@@ -799,11 +822,11 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
     // side job behind the last load (vmcnt retires in issue order: a store ahead of the loads would sit in front of every wait for them)
     zero_job(a.zero, a.zero_n, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, lane, 64);
     // per-head RMSNorm (x / sqrt(mean + eps) * w) and rotate-half RoPE with separately rounded products
-    const bool upper = lane >= 32;
+    const bool upper = lane >= 32, odd_row = (lane & 16) != 0;
     auto norm_rope = [&](float2 x, const float2& w) {
-        const float den = sqrtf(wave_sum(x.x * x.x + x.y * x.y) / (float)HEAD_DIM + a.eps);
+        const float den = sqrtf(wave_sum_valu(x.x * x.x + x.y * x.y) / (float)HEAD_DIM + a.eps);
         x.x = x.x / den * w.x; x.y = x.y / den * w.y;
-        const float px = __shfl_xor(x.x, 32), py = __shfl_xor(x.y, 32);     // the d +- 64 partner
+        const float px = lane_xor32(x.x, upper), py = lane_xor32(x.y, upper);     // the d +- 64 partner
         float2 o;
         if (upper) { o.x = __fadd_rn(__fmul_rn(x.x, rc.x), __fmul_rn(px, rs.x)); o.y = __fadd_rn(__fmul_rn(x.y, rc.y), __fmul_rn(py, rs.y)); }
         else       { o.x = __fsub_rn(__fmul_rn(x.x, rc.x), __fmul_rn(px, rs.x)); o.y = __fsub_rn(__fmul_rn(x.y, rc.y), __fmul_rn(py, rs.y)); }
@@ -823,26 +846,52 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         const float2 kk = p == pos ? k : kc[p];
         s[p] = q.x * kk.x + q.y * kk.y;
     }
-    int key = 0;
-    tbutterfly<NK, NK, 32>(s, lane, key);
-    const bool valid = key <= pos;
-    const float sc = valid ? s[0] * 0.08838834764831845f : -INFINITY;
-    float M = sc;
+    // Reduce the NK per-lane partials over the 64 lanes. Across the two row pairs the butterfly TRANSPOSES while more than four
+    // values are alive (a lane hands half of its values to lane ^ 32 / ^ 16 and keeps the other half), the last four are summed
+    // over their row with DPP rotations: afterwards a lane of row r holds the complete scores of keys kbase .. kbase + 3.
+    int kbase = 0;
+    if constexpr (NK == 16) {
 #pragma unroll
-    for (int off = 32; off >= 64 / NK; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
-    const float w = valid ? expf(sc - M) : 0.0f;
+        for (int i = 0; i < 8; ++i) s[i] = (upper ? s[i + 8] : s[i]) + lane_xor32(upper ? s[i] : s[i + 8], upper);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = (odd_row ? s[i + 4] : s[i]) + lane_xor16(odd_row ? s[i] : s[i + 4], odd_row);
+        kbase = (upper ? 8 : 0) + (odd_row ? 4 : 0);
+    } else if constexpr (NK == 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = (upper ? s[i + 4] : s[i]) + lane_xor32(upper ? s[i] : s[i + 4], upper);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] += lane_xor16(s[i], odd_row);
+        kbase = upper ? 4 : 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[i] += lane_xor32(s[i], upper); s[i] += lane_xor16(s[i], odd_row); }
+    }
+    float sc[4], M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = (kbase + i) <= pos ? row_sum16(s[i]) * 0.08838834764831845f : -INFINITY;
+        M = fmaxf(M, sc[i]);
+    }
+    M = fmaxf(fmaxf(read_lane(M, 0), read_lane(M, 16)), fmaxf(read_lane(M, 32), read_lane(M, 48)));
+    float w4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (kbase + i) <= pos ? expf(sc[i] - M) : 0.0f;
     float L = 0.0f;
     float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
     for (int p = 0; p < NK; ++p) {
-        const float wp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), p * (64 / NK)));
+        const float wp = read_lane(w4[p & 3], NK == 16 ? 16 * (p >> 2) : NK == 8 ? 32 * (p >> 2) : 0);     // the row that holds key p
         const float2 vv = p == pos ? v : vc[p];
         L += wp;
         acc.x += wp * vv.x; acc.y += wp * vv.y;
     }
     Q3T(2);
     *reinterpret_cast<float2*>(a.out + (size_t)b * a.ld_out + h * HEAD_DIM + 2 * lane) = make_float2(acc.x / L, acc.y / L);
-    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
+    Q3T(3); Q3T_W(4);
+#ifdef Q3_TRACE
+    q3t_[6] = (unsigned long long)clock64();
+#endif
+    Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // single-row passes of a cache that never exceeds 16 positions, position known at launch (the code predictor)
@@ -869,7 +918,9 @@ hipError_t launch_attn_cp(const AttnArgs& a, hipStream_t st) {
 // but the frame got 17 % SLOWER (1.7B, B = 8: 4.34 -> 5.07 ms) — device-scope fences write back / invalidate the XCD's
 // L2 under every later launch, while this kernel boundary costs 1.6 us.
 template <int NS>      // capacity of the fixed unroll: 16, or 64 for long-context sessions
-__global__ __launch_bounds__(128) void k_attn_merge(AttnArgs a) {
+__global__ __launch_bounds__(128) void k_attn_merge(const float* p_part, float* p_out, int p_splits, int p_nh, int p_ld_out, AttnArgs a_in) {
+    AttnArgs a = a_in;                                  // leading scalars: preloaded kernel arguments (see k_attn_cp)
+    a.part = const_cast<float*>(p_part); a.out = p_out; a.n_splits = p_splits; a.nh = p_nh; a.ld_out = p_ld_out;
     Q3T_DECL Q3T(0);
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* rec = a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE;
@@ -923,8 +974,8 @@ hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(k_attn_merge2, dim3((unsigned)(((long)a.B * a.nh + 3) / 4)), dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    if (a.n_splits <= 16) hipLaunchKernelGGL(k_attn_merge<16>, dim3(a.nh, a.B), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL(k_attn_merge<MAX_SPLITS>, dim3(a.nh, a.B), dim3(128), 0, st, a);
+    if (a.n_splits <= 16) hipLaunchKernelGGL(k_attn_merge<16>, dim3(a.nh, a.B), dim3(128), 0, st, (const float*)a.part, a.out, a.n_splits, a.nh, a.ld_out, a);
+    else hipLaunchKernelGGL(k_attn_merge<MAX_SPLITS>, dim3(a.nh, a.B), dim3(128), 0, st, (const float*)a.part, a.out, a.n_splits, a.nh, a.ld_out, a);
     return hipGetLastError();
 }
 

@@ -265,3 +265,117 @@ def test_0_6b_single_utterance(sampling):
     opts = q.SynthesisOptions(max_length=N_FRAMES, eos_token_id=None, seed=42, **kw)
     _check_free_run(gm, "0.6b", [bench_utt(0)], opts, ref[:1], True, f"0_6b_b1_{sampling}_graph")
     gm.close()
+
+
+def _tf_steps(s, fx, cfg, B, stats, tag):
+    """teacher-forced code-predictor runs + talker steps of a prefilled B-row session against a steps fixture"""
+    h = fx["prefill_hidden"]
+    for st in range(fx["sem"].shape[0]):
+        codes, cl = s.cp_generate(h, fx["sem"][st])
+        for b in range(B):
+            same = codes[b] == fx["cp_codes"][st, b]
+            first_bad = int(np.argmin(same)) if not same.all() else 15
+            if first_bad < 15:          # a wrong greedy code poisons the later groups: only an oracle near-tie may cause it
+                assert fx["cp_top2_margin"][st, b, first_bad] < MARGIN_EPS, (tag, st, b, first_bad, float(fx["cp_top2_margin"][st, b, first_bad]))
+            for k, g in enumerate((0, 7, 14)):
+                if g <= first_bad:
+                    e = float(np.abs(cl[b, g] - fx["cp_logits_g0_7_14"][st, b, k]).max())
+                    stats.setdefault(f"cp_logits_g{g}", []).append(e)
+                    assert e <= 2e-3, (tag, st, b, g, e)
+        hid, lg = s.talker_step(fx["emb"][st])
+        eh = np.abs(hid - fx["hidden"][st]).max(axis=1); el = np.abs(lg - fx["talker_logits"][st]).max(axis=1)
+        stats.setdefault("step_hidden", []).extend(float(x) for x in eh); stats.setdefault("step_logits", []).extend(float(x) for x in el)
+        assert eh.max() <= 5e-4 and el.max() <= 5e-3, (tag, st, eh.max(), el.max())
+        h = fx["hidden"][st]
+
+
+def test_long_context_b8(gm17):
+    """The bench batch BEHIND LONG CONTEXT: 8 sequences with equal 600-position VoiceDesign prompts — GEMM +
+    flash-attention prefill of 8 x 600 rows, then the decode step at positions 600 / 601: `k_attn_fused` with its 8-way key split
+    over ~75 keys per split + `k_attn_merge`, the split-K projections and the code predictor at M = 8, teacher-forced against
+    the oracle logit by logit; then a 10-frame default-sampling hipGraph free run of the same batch, codes bit-exact."""
+    from make_golden_bench import longctx_utt
+    fx = np.load(os.path.join(G, "bench_1_7b_longctx.npz"))
+    cfg = gm17.config
+    B = 8
+    utts = [longctx_utt(b) for b in range(B)]
+    s = gm17.session(utts, q.SynthesisOptions(max_length=10, seed=42)); s.prefill()
+    assert s.prefill_len(0)[0] == 600
+    stats = {}
+    for b in range(B):
+        hid = s.get(1, (cfg.hidden,), b=b); lg = s.get(2, (cfg.codec_vocab,), b=b)
+        stats.setdefault("prefill_hidden", []).append(float(np.abs(hid - fx["prefill_hidden"][b]).max()))
+        stats.setdefault("prefill_logits", []).append(float(np.abs(lg - fx["prefill_logits"][b]).max()))
+    assert max(stats["prefill_hidden"]) <= 5e-4 and max(stats["prefill_logits"]) <= 5e-3, stats
+    _tf_steps(s, fx, cfg, B, stats, "longctx")
+    s.close()
+    _dump("bench_long_context_b8.json", {k: {"max": max(v), "mean": float(np.mean(v))} for k, v in stats.items()})
+    opts = q.SynthesisOptions(max_length=10, eos_token_id=None, seed=42)
+    rep = _check_free_run(gm17, "1.7b", utts, opts, fx["free_codes"], True, "1_7b_longctx_b8_graph")
+    assert len(rep) <= 1, rep
+
+
+def test_640_frames_b8(gm17):
+    """The benchmark's own run length: the 8-utterance bench session carried to all 640 frames under the
+    hipGraph, sequences 0 and 5 compared with the oracle's 640-frame runs — the decode attention's key splits at 100 .. 650
+    positions, every per-frame counter, the penalty mask after hundreds of tokens. Each 640-frame run holds ~20 code-predictor
+    decisions with an oracle top-2 margin below 2e-3 (two of them below 3e-5), so a sequence may leave the fixture — but only
+    AT such a decision (margins are in the fixture; a sampled talker token is adjudicated live), never before the first
+    decision whose margin is below 1e-4, and every frame before that point must be bit-exact (150+ frames for one sequence).
+    The decode attention at 600 keys is compared separately, logit by logit (test_long_context_b8)."""
+    fx = np.load(os.path.join(G, "bench_1_7b_long640.npz"))
+    FR = 640
+    opts = q.SynthesisOptions(max_length=FR, eos_token_id=None, seed=42)
+    utts = [bench_utt(i) for i in range(8)]
+    s = gm17.session(utts, opts); s.prefill(); s.generate(FR, use_graph=True)
+    report = []; exact = []
+    for i in [int(x) for x in fx["seqs"]]:
+        codes = s.codes(i); ref = fx[f"codes_{i}"]
+        assert codes.shape == ref.shape == (FR, 16)
+        if (codes == ref).all():
+            exact.append(FR); continue
+        f = next(k for k in range(FR) if not (codes[k] == ref[k]).all())
+        g = int(np.nonzero(codes[f] != ref[f])[0][0])
+        exact.append(f)
+        risky = np.argwhere(fx[f"cp_top2_margin_{i}"] < 1e-4)
+        first_risky = int(risky[0][0]) if len(risky) else FR
+        assert f >= first_risky or g == 0, (i, f, g, first_risky)          # kernels agree to ~1e-5: nothing may flip before a < 1e-4 margin
+        if g > 0:
+            m = float(fx[f"cp_top2_margin_{i}"][f][g - 1])
+            report.append({"seq": i, "frame": f, "group": g, "oracle_margin": m})
+            assert m < MARGIN_EPS, report[-1]
+        else:
+            ok, rep = _adjudicate("1.7b", utts[i], opts, codes, f"1_7b_long640_seq{i}")
+            report.append(rep)
+            assert ok, rep
+    s.close()
+    _dump("bench_640_frames_b8.json", {"exact_frames": exact, "near_tie_divergences": report,
+                                       "min_cp_margin": {str(int(i)): float(fx[f"cp_top2_margin_{int(i)}"].min()) for i in fx["seqs"]}})
+    assert max(exact) >= 150, (exact, report)
+
+
+@pytest.mark.parametrize("flavour", ["xvector", "icl"])
+def test_clone_prefill_1_7b(gm17, flavour):
+    """BASELINE config[3] ("1.7B-Base") / config[4] ("ICL voice-clone") prompt flavours at full width: the
+    x-vector prefill (speaker embedding row instead of a preset speaker token) and the ICL prefill (reference codes summed
+    over 16 codebooks + reference text, talker.rs:646-710; repetition penalty floored at 1.5, lib.rs:913-929): last hidden
+    state, first logits and four greedy hipGraph frames against the oracle."""
+    from make_golden_bench import clone_utts
+    fx = np.load(os.path.join(G, "bench_1_7b_clone.npz"))
+    cfg = gm17.config
+    utt = clone_utts(cfg)[flavour]
+    opts = q.SynthesisOptions(max_length=4, temperature=0.0, eos_token_id=None, seed=42)
+    s = gm17.session([utt], opts); s.prefill()
+    assert s.prefill_len(0)[0] == int(fx[f"{flavour}_prefill_len"][0])
+    hid = s.get(1, (cfg.hidden,)); lg = s.get(2, (cfg.codec_vocab,))
+    eh = float(np.abs(hid - fx[f"{flavour}_hidden"]).max()); el = float(np.abs(lg - fx[f"{flavour}_logits"]).max())
+    _dump(f"bench_clone_{flavour}.json", {"hidden_max_abs_err": eh, "logits_max_abs_err": el, "prefill_len": int(fx[f"{flavour}_prefill_len"][0])})
+    assert eh <= 2e-4 and el <= 2e-3, (eh, el)
+    s.generate(4, use_graph=True)
+    codes = s.codes(0); ref = fx[f"{flavour}_codes"]
+    if not (codes == ref).all():
+        f = next(i for i in range(4) if not (codes[i] == ref[i]).all())
+        g = int(np.nonzero(codes[f] != ref[f])[0][0])
+        m = float(fx[f"{flavour}_talker_top2_margin"][f]) if g == 0 else float(fx[f"{flavour}_cp_top2_margin"][f][g - 1])
+        assert m < MARGIN_EPS, (f, g, m)
+    s.close()

@@ -867,3 +867,25 @@ def test_dp_two_ranks_on_one_gpu():
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0: arena" in r.stdout and "rank 1: arena" in r.stdout and "DIFFER" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_same_gpu():
+    """The WHOLE bench.py flow at N = 2: self-spawned ranks, arena broadcast, non-root finalize, barriers,
+    max-over-ranks timing, the `rccl` record, rank 0's extras while rank 1 waits at the final barrier, destroy_process_group
+    on every rank, exit code 0 — both ranks on cuda:0 over gloo (RCCL refuses two ranks per device), tiny model."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["Q3_DP_TEST_SAME_GPU"] = "1"; env["MASTER_ADDR"] = "127.0.0.1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--model", "tiny", "--steps", "1", "--warmup", "1", "--frames", "12",
+                        "--batch", "2", "--also-batches", "", "--no-cpu-baseline", "--no-other-configs", "--ttfa-reps", "1", "--prompt-tokens", "16"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["rccl"]["world"] == 2 and sorted(x[0] for x in out["rccl"]["ranks_seen"]) == [0, 1] and out["rccl"]["same_gpu_test_mode"] is True
+    assert out["config"]["utterances_per_gpu"] == 2 and out["weight_broadcast"]["bytes"] > 0

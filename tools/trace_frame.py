@@ -106,5 +106,14 @@ for nme, rs in sorted(agg.items(), key=lambda kv: -sum(r["tot"] for r in kv[1]))
               f"{g(lambda r: r['w6x']):8.2f} {g(lambda r: r['w5']):7.2f} {g(lambda r: r['tail']):5.2f}")
     else:
         print()
+# shader clock: attn_cp nodes carry clock64() at entry (slot 5) and exit (slot 6) beside the 100 MHz stamps (slots 0 and 4)
+mhz = []
+for i in range(N):
+    if meta[i][0] == 1:
+        v = st[i].astype(np.int64); ok = (v[:, 0] != 0) & (v[:, 5] != 0) & (v[:, 6] > v[:, 5]) & (v[:, 4] > v[:, 0])
+        if ok.any():
+            mhz.extend(((v[ok, 6] - v[ok, 5]) / ((v[ok, 4] - v[ok, 0]) * 0.01)).tolist())
+if mhz:
+    print(f"\nshader clock during the frame (clock64 ticks per us over {len(mhz)} attn_cp workgroups): median {np.median(mhz):.0f} MHz, min {np.min(mhz):.0f}, max {np.max(mhz):.0f}")
 gaps = [r["gap"] for r in rows if r and np.isfinite(r["gap"])]
 print(f"\nsum of node totals {tot_all:.1f} us, sum of gaps {np.nansum(gaps):.1f} us (incl. un-instrumented nodes), nodes {len(gaps) + 1}")
