@@ -339,6 +339,34 @@ def main():
                     m06.close()
             guarded("0.6b_customvoice_b1", small)
 
+    # ---- utterances that END AT DIFFERENT FRAMES (what EOS does to a real batch): 4 x B requests with lengths drawn from
+    # 100 .. frames go through B rows, (a) continuously — a row that ends is refilled at the 32-frame poll (q3_session_replace)
+    # — and (b) as lockstep sessions of B, each running until its longest row is done. Useful frames / wall of the generation
+    # loop (prefills of the swapped-in requests included; no vocoder on either side). ----
+    eos_mix = None
+    if world == 1 and not args.no_other_configs and args.workload == "customvoice":
+        try:
+            rng = np.random.default_rng(2026)
+            n_req = 4 * B
+            lens = [int(x) for x in rng.integers(min(100, args.frames), args.frames + 1, size=n_req)]
+            mix = []
+            for i, L in enumerate(lens):
+                u = make_utt(i); u.max_length = L
+                mix.append(u)
+            model.synthesize_continuous(mix[:B + 2], opts, slots=B, decode=False, use_graph=use_graph)       # warm (graph, side-session shapes)
+            _, _, fr_c, wall_c = model.synthesize_continuous(mix, opts, slots=B, decode=False, use_graph=use_graph)
+            wall_l = 0.0; fr_l = 0
+            for k in range(0, n_req, B):
+                sl = model.session(mix[k:k + B], opts)
+                ta = time.perf_counter(); sl.prefill(); sl.generate(args.frames, use_graph=use_graph); wall_l += time.perf_counter() - ta
+                fr_l += sum(sl.frames(b)[0] for b in range(len(mix[k:k + B]))); sl.close()
+            eos_mix = {"requests": n_req, "rows": B, "lengths": f"uniform {min(100, args.frames)}..{args.frames} frames (seed 2026), mean {float(np.mean(lens)):.0f}",
+                       "continuous_frames_per_s": fr_c / wall_c, "lockstep_frames_per_s": fr_l / wall_l, "frames": fr_c,
+                       "what": "generation loop only (prefill of swapped-in requests included, no vocoder); lockstep = sessions of `rows` requests "
+                               "each running until its longest row ends"}
+        except Exception as e:
+            eos_mix = {"error": str(e)}
+
     # ---- CPU baseline: the oracle (port of the candle-CPU F32 path) on this host, bounded sample ----
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -400,7 +428,7 @@ def main():
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,
                                                         "gbps": (bcast_bytes / bcast_s / 1e9) if bcast_s > 0 else None},
-        "roofline": roofline, "cpu_baseline": cpu, "other_batches": wide, "other_configs": others, "rccl": rccl,
+        "roofline": roofline, "cpu_baseline": cpu, "other_batches": wide, "other_configs": others, "eos_mix": eos_mix, "rccl": rccl,
     }
     print(json.dumps(out), flush=True)
     finish()

@@ -190,6 +190,19 @@ q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_host, const s
  * up to chunk_frames frames, decodes them as an independent utterance; *done=1 with
  * *n_samples=0 when finished. */
 q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_t cap, size_t* n_samples, int* done);
+/* The same for sequence b of a session with several sequences (one StreamingSession per row, lib.rs:1484-1541): the rows
+ * advance in lockstep, so the first row asked generates the chunk's frames for all of them and the others only run their
+ * vocoder. An error leaves the row's position untouched: the call can be repeated (lib.rs:1775-1781). */
+q3_status q3_session_next_chunk_row(q3_session* s, int b, float* pcm_host, size_t cap, size_t* n_samples, int* done);
+/* Continuous batching: replace row b of a PREFILLED session — normally one whose sequence has ended (q3_session_frames:
+ * done; fetch its codes / PCM first) — by a new request, which then starts at its frame 0 while the other rows go on. The
+ * reference keeps all per-utterance state per call (KV caches, SamplingContext, penalty mask, trailing text:
+ * lib.rs:743-756; StreamingSession lib.rs:1484-1541); here it is row b's slice of the session's device state, refilled
+ * from a one-row prefill of `req`. The request must share the session's sampling options (seed and max_length may differ;
+ * max_length <= the session's largest), fit the row (text rows <= max(1024, the longest of the original batch); prompt +
+ * max_length within the row's KV extent) and carry no reference codes. Each row of a session stops at its own
+ * opts.max_length; q3_session_generate returns early once every row is done. Other rows are bit-for-bit unaffected. */
+q3_status q3_session_replace(q3_session* s, int b, const q3_request* req);
 /* Chunk decode mode of q3_session_next_chunk. 0 (default) = each chunk decoded as an independent utterance, exactly
  * as the reference does (lib.rs:1755-1758: audible seams, every chunk restarts from zero padding). 1 = continuous:
  * the vocoder's front runs over all frames so far and its convolutional stack over the chunk plus 12 frames of left

@@ -147,6 +147,7 @@ class Utterance:
     ref_codes: Optional[np.ndarray] = None           # ICL voice clone: reference codec frames [n_ref][16]
     ref_text_ids: Optional[Sequence[int]] = None     # ICL voice clone: reference transcript token ids
     seed: Optional[int] = None                       # overrides options.seed for this sequence
+    max_length: Optional[int] = None                 # overrides options.max_length for this sequence (rows of a session end at their own limit)
 
     def mode(self) -> int:
         if self.instruct_ids is not None:
@@ -167,38 +168,59 @@ class Session:
         self._ref_frames = [0 if u.ref_codes is None else int(np.asarray(u.ref_codes).reshape(-1, 16).shape[0]) for u in utts]
         reqs = (CRequest * self.B)()
         for i, u in enumerate(utts):
-            r = reqs[i]
-            r.mode = u.mode()
-            t = np.ascontiguousarray(u.text_ids, dtype=np.uint32); self._keep.append(t)
-            r.text_ids = t.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_text = len(t)
-            if u.instruct_ids is not None:
-                ins = np.ascontiguousarray(u.instruct_ids, dtype=np.uint32); self._keep.append(ins)
-                r.instruct_ids = ins.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_instruct = len(ins)
-            r.speaker_id = u.speaker.token_id(); r.language_id = u.language.token_id()
-            if u.xvector is not None:
-                xv = np.ascontiguousarray(u.xvector, dtype=np.float32); self._keep.append(xv)
-                r.xvector = xv.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-            if u.ref_codes is not None:          # prepended at decode even without a transcript (lib.rs:1022); ICL needs both
-                rc = np.ascontiguousarray(u.ref_codes, dtype=np.uint32).reshape(-1, 16); self._keep.append(rc)
-                r.ref_codes = rc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref = rc.shape[0]
-                if u.ref_text_ids is not None:
-                    rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); self._keep.append(rt)
-                    r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
-            o = options.to_c()
-            if u.seed is not None:
-                o.seed = int(u.seed); o.has_seed = 1
-            r.opts = o
+            self._fill(reqs[i], u)
         h = ctypes.c_void_p()
         check(lib.q3_session_create(model._h, reqs, self.B, ctypes.byref(h)))
         self._h = h
         if debug:
             check(lib.q3_session_set_debug(self._h, 1))
 
+    def _fill(self, r, u: Utterance):
+        """q3_request of one utterance (the arrays it points to are kept alive by the session)"""
+        r.mode = u.mode()
+        t = np.ascontiguousarray(u.text_ids, dtype=np.uint32); self._keep.append(t)
+        r.text_ids = t.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_text = len(t)
+        if u.instruct_ids is not None:
+            ins = np.ascontiguousarray(u.instruct_ids, dtype=np.uint32); self._keep.append(ins)
+            r.instruct_ids = ins.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_instruct = len(ins)
+        r.speaker_id = u.speaker.token_id(); r.language_id = u.language.token_id()
+        if u.xvector is not None:
+            xv = np.ascontiguousarray(u.xvector, dtype=np.float32); self._keep.append(xv)
+            r.xvector = xv.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        if u.ref_codes is not None:          # prepended at decode even without a transcript (lib.rs:1022); ICL needs both
+            rc = np.ascontiguousarray(u.ref_codes, dtype=np.uint32).reshape(-1, 16); self._keep.append(rc)
+            r.ref_codes = rc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref = rc.shape[0]
+            if u.ref_text_ids is not None:
+                rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); self._keep.append(rt)
+                r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
+        o = self.options.to_c()
+        if u.seed is not None:
+            o.seed = int(u.seed); o.has_seed = 1
+        if u.max_length is not None:
+            o.max_length = int(u.max_length)
+        r.opts = o
+
     def close(self):
         if getattr(self, "_h", None):
             lib.q3_session_free(self._h); self._h = None
 
     __del__ = close
+
+    def replace(self, b: int, utt: Utterance):
+        """Continuous batching (q3_session_replace): row b — normally a finished one whose codes / PCM have been fetched — starts
+        over with `utt` at its frame 0 while the other rows keep going; they are bit-for-bit unaffected."""
+        r = CRequest()
+        self._fill(r, utt)
+        check(lib.q3_session_replace(self._h, int(b), ctypes.byref(r)))
+        self._ref_frames[b] = 0
+
+    def next_chunk_row(self, b: int) -> Tuple[Optional[AudioBuffer], bool]:
+        """StreamingSession::next_chunk for row b of a multi-sequence session: (chunk or None, done)."""
+        spf = self.model.config.samples_per_frame
+        buf = np.zeros(max(self.options.chunk_frames, 1) * spf, dtype=np.float32)
+        n = ctypes.c_size_t(); d = ctypes.c_int()
+        check(lib.q3_session_next_chunk_row(self._h, int(b), buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(n), ctypes.byref(d)))
+        return (AudioBuffer(buf[:n.value].copy()) if n.value else None), bool(d.value)
 
     def prefill(self):
         check(lib.q3_session_prefill(self._h))
@@ -563,6 +585,50 @@ class Qwen3TTS:
                 tot = SynthesisTiming(tot.prefill_ms + t.prefill_ms, tot.generation_ms + t.generation_ms,
                                       tot.generation_frames + t.generation_frames, tot.decode_ms + t.decode_ms)
         return audio, tot
+
+    def synthesize_continuous(self, utts: Sequence[Utterance], options=None, slots: int = 8, poll_frames: int = 32,
+                              decode: bool = True, use_graph: bool = True):
+        """Continuous batching over ONE session of `slots` rows: the first `slots` requests start together; whenever a row ends
+        (EOS, or its own max_length) its codes are collected and the next waiting request is swapped into the row
+        (q3_session_replace) while the other rows keep running — no row idles until the slowest one is done. All requests
+        must share one prefill shape for the initial batch (a server groups them, as synthesize_batch does). Returns
+        (codes per request, PCM per request or None, frames generated, wall seconds of the generation loop)."""
+        import time as _time
+        o = options or SynthesisOptions()
+        utts = list(utts)
+        n0 = min(slots, len(utts))
+        budget = max((u.max_length if u.max_length is not None else o.max_length) for u in utts)
+        first = [Utterance(**{**u.__dict__}) for u in utts[:n0]]
+        if all((u.max_length if u.max_length is not None else o.max_length) < budget for u in first):
+            first[0].max_length = None          # the session's frame budget is the largest limit of its first batch: make room for later rows
+            o = SynthesisOptions(**{**o.__dict__, "max_length": budget})
+        s = Session(self, first, o)
+        owner = list(range(n0)); nxt = n0
+        codes: List[Optional[np.ndarray]] = [None] * len(utts); pcm: List[Optional[np.ndarray]] = [None] * len(utts)
+        frames = 0
+        t0 = _time.perf_counter()
+        try:
+            s.prefill()
+            while any(i is not None for i in owner):
+                s.generate(poll_frames, use_graph=use_graph)
+                for b in range(n0):
+                    i = owner[b]
+                    if i is None:
+                        continue
+                    n, done = s.frames(b)
+                    if not done:
+                        continue
+                    codes[i] = s.codes(b); frames += int(codes[i].shape[0])
+                    if decode:
+                        pcm[i] = s.decode(b)
+                    if nxt < len(utts):
+                        s.replace(b, utts[nxt]); owner[b] = nxt; nxt += 1
+                    else:
+                        owner[b] = None
+            wall = _time.perf_counter() - t0
+        finally:
+            s.close()
+        return codes, pcm, frames, wall
 
     def synthesize_streaming(self, text_ids, speaker: Speaker, language: Language, options=None,
                              continuous: bool = False) -> StreamingSession:

@@ -12,7 +12,7 @@ PRELOAD="-mllvm -amdgpu-kernarg-preload-count=14"
 [ -n "$Q3_NO_PRELOAD" ] && PRELOAD=""
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC $PRELOAD -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value $Q3_BUILD_EXTRA"
 pids=()
-for f in q3_kernels_lm q3_kernels_gemv q3_kernels_codec q3_kernels_prefill q3_engine q3_speaker q3_mimi; do
+for f in q3_kernels_lm q3_kernels_gemv q3_kernels_wide q3_kernels_codec q3_kernels_prefill q3_engine q3_speaker q3_mimi; do
   if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/q3_kernels.h" -nt "$BUILD/$f.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
     pids+=($!)
@@ -27,5 +27,5 @@ if [ ! -f "$BUILD/q3_dp.o" ] || [ "$HERE/q3_dp.cpp" -nt "$BUILD/q3_dp.o" ] || [ 
   pids+=($!)
 fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_gemv.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_kernels_prefill.o" "$BUILD/q3_engine.o" "$BUILD/q3_speaker.o" "$BUILD/q3_mimi.o" "$BUILD/q3_io.o" "$BUILD/q3_dp.o" -ldl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_gemv.o" "$BUILD/q3_kernels_wide.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_kernels_prefill.o" "$BUILD/q3_engine.o" "$BUILD/q3_speaker.o" "$BUILD/q3_mimi.o" "$BUILD/q3_io.o" "$BUILD/q3_dp.o" -ldl
 echo "built $OUT"

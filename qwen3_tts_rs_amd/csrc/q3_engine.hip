@@ -1146,6 +1146,9 @@ struct SeqInfo {
     q3_request req; std::vector<uint32_t> text, instruct, ref_codes, ref_text; std::vector<float> xvec; bool icl = false;
     int prefill_len = 0, trailing_len = 0, row_base = 0, n_rows = 0, trail_base = 0, pad_row = 0;
     int n_frames = 0; bool done = false;
+    // rows end at different frames: a row generates at most `limit` frames (its own max_length) counted from session frame
+    // `start_run` (0, or the session's frame count when the row was swapped in: q3_session_replace)
+    int start_run = 0, limit = 0, stream_pos = 0;
 };
 
 struct ProfAcc { double ms = 0; double bytes = 0; long launches = 0; };
@@ -1158,8 +1161,11 @@ struct q3_session {
     std::vector<SeqInfo> seq;
     q3_options opts{};
     int max_frames = 0, max_seq = 0, prefill_len = 0, n_splits = 1;
+    int* limit = nullptr;                 // [B] per-row frame limits on the device (SampleArgs::limit)
+    int row_cap = 0, repl_base = 0;       // text-row slots of replacement rows: slot b = rows repl_base + b*row_cap .. (q3_session_replace)
     LmBuf tb{}, cb{};
     float *LASTH = nullptr, *LOGITS = nullptr, *CP_IN = nullptr, *CP_LOGITS = nullptr;
+    float* wide_ws = nullptr; size_t wide_ws_bytes = 0;       // slice sums of the wide-session GEMM (B > 16; q3_kernels_wide.hip)
     float *kcache = nullptr, *vcache = nullptr, *ckcache = nullptr, *cvcache = nullptr;
     size_t kv_layer_stride = 0, ckv_layer_stride = 0;
     float *rows = nullptr, *embeds = nullptr, *xvec = nullptr; int n_rows_total = 0;
@@ -1205,11 +1211,10 @@ struct q3_session {
 };
 
 static hipError_t run_linear(q3_session* s, const LinArgs& a_in) {
-#ifdef Q3_TRACE
     LinArgs a = a_in;
+    a.ws = s->wide_ws; a.ws_bytes = s->wide_ws_bytes;
+#ifdef Q3_TRACE
     a.trace = s->trace_next(0, a.M, a.N, a.K, a.epi, a.norm_w ? 1 : 0, a.tiled);
-#else
-    const LinArgs& a = a_in;
 #endif
     if (!s->profile) return launch_linear(a, s->stream);
     // profiling: bracket the launch with event records (inside graph capture these become event-record
@@ -1440,7 +1445,7 @@ static q3_status cp_run(q3_session* s) {
 static void fill_sample_args(q3_session* s, SampleArgs& a) {
     const q3_options& o = s->opts; const q3_config& c = s->m->cfg;
     memset(&a, 0, sizeof a);
-    a.logits = s->LOGITS; a.ld = c.codec_vocab; a.seen = s->seen; a.u = s->U; a.u_stride = s->max_frames + 1;
+    a.logits = s->LOGITS; a.ld = c.codec_vocab; a.seen = s->seen; a.u = s->U; a.u_stride = s->max_frames + 2; a.limit = s->limit;
     a.draw_idx = s->token_count; a.tok = s->tok; a.token_count = s->token_count; a.frame_idx = s->frame_idx; a.pos = s->pos;
     a.vocab = c.codec_vocab; a.B = s->B;
     a.apply_temp = (o.temperature != 1.0 && o.temperature > 0.0) ? 1 : 0;
@@ -1479,8 +1484,9 @@ static q3_status frame_launch(q3_session* s) {
 }
 
 static bool opts_equal_sampling(const q3_options& a, const q3_options& b) {
+    // max_length may differ from row to row (each row stops at its own limit); everything the captured sampler bakes in must not
     return a.temperature == b.temperature && a.top_p == b.top_p && a.repetition_penalty == b.repetition_penalty &&
-           a.max_length == b.max_length && a.top_k == b.top_k && a.eos_token_id == b.eos_token_id &&
+           a.top_k == b.top_k && a.eos_token_id == b.eos_token_id &&
            a.min_new_tokens == b.min_new_tokens && a.chunk_frames == b.chunk_frames;
 }
 
@@ -1531,7 +1537,7 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
             int cap = 6 * r.n_text; if (cap < 75) cap = 75;
             if (q.req.opts.max_length > cap) q.req.opts.max_length = cap;
             if (b == 0) s->opts = q.req.opts;
-            else if (!opts_equal_sampling(q.req.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "ICL sequences of a batch must resolve to the same max_length / repetition_penalty");
+            else if (!opts_equal_sampling(q.req.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "ICL sequences of a batch must resolve to the same repetition_penalty");
         }
         const int n_ins = (int)q.instruct.size();
         const int overlay = r.mode == Q3_MODE_VOICE_DESIGN ? 5 : 6;
@@ -1547,7 +1553,16 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     }
     s->prefill_len = s->seq[0].prefill_len;
     s->n_rows_total = rows;
-    s->max_frames = s->opts.max_length;
+    s->max_frames = 1;
+    for (auto& q : s->seq) {
+        if (q.req.opts.max_length < 1) return set_err(Q3_INVALID_ARG, "max_length must be at least 1");
+        q.limit = q.req.opts.max_length; q.start_run = 0;
+        if (q.limit > s->max_frames) s->max_frames = q.limit;
+        if (q.n_rows > s->row_cap) s->row_cap = q.n_rows;
+    }
+    s->opts.max_length = s->max_frames;
+    if (s->row_cap < 1024) s->row_cap = 1024;      // replacement slots hold any text up to ~1000 tokens (8 MB per row at H = 2048), longer if the batch had one
+    s->repl_base = rows;
     // KV sized for what the path needs (prefill + frames), not the reference's max_new_tokens+256 (lib.rs:450)
     s->max_seq = s->prefill_len + s->max_frames + 1;
     if (s->max_seq > m->rope_len) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds the RoPE table (%d)", s->max_seq, m->rope_len);
@@ -1584,6 +1599,15 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     };
     HIPC(alloc_lm(s->tb, talker_dims(c), s->n_splits));
     HIPC(alloc_lm(s->cb, cp_dims(c), 1));
+    if (B > 16) {     // wide sessions: workspace of the split-K GEMM, sized for the largest projection of either network
+        size_t need = 0;
+        auto upd = [&](int N, int K, int epi) { if (N % 128 == 0 && K % 128 == 0) { const size_t b = gemm_wide_ws_bytes(B, N, K, epi); if (b > need) need = b; } };
+        const int QDt = c.n_heads * HEAD_DIM, KDt = c.n_kv_heads * HEAD_DIM, QDc = c.cp_heads * HEAD_DIM, KDc = c.cp_kv_heads * HEAD_DIM;
+        upd(QDt + 2 * KDt, H, EPI_NONE); upd(H, QDt, EPI_RESID); upd(c.inter, H, EPI_SWIGLU); upd(H, c.inter, EPI_RESID); upd(c.codec_vocab, H, EPI_NONE);
+        upd(QDc + 2 * KDc, c.cp_hidden, EPI_NONE); upd(c.cp_hidden, QDc, EPI_RESID); upd(c.cp_inter, c.cp_hidden, EPI_SWIGLU); upd(c.cp_hidden, c.cp_inter, EPI_RESID);
+        upd(c.cp_vocab, c.cp_hidden, EPI_NONE); upd(c.cp_hidden, H, EPI_NONE);
+        if (need) { HIPC(s->pool.alloc(&s->wide_ws, need / 4)); s->wide_ws_bytes = need; }
+    }
     HIPC(s->pool.alloc(&s->LASTH, (size_t)B * H));
     HIPC(s->pool.alloc(&s->LOGITS, (size_t)B * c.codec_vocab));
     HIPC(s->pool.alloc(&s->CP_IN, (size_t)(B > 16 ? up16(B) : 16) * H));
@@ -1594,7 +1618,13 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     s->ckv_layer_stride = (size_t)B * c.cp_kv_heads * (c.n_groups + 1) * HEAD_DIM;
     HIPC(s->pool.alloc(&s->ckcache, s->ckv_layer_stride * c.cp_layers));
     HIPC(s->pool.alloc(&s->cvcache, s->ckv_layer_stride * c.cp_layers));
-    HIPC(s->pool.alloc(&s->rows, (size_t)rows * H));
+    HIPC(s->pool.alloc(&s->rows, ((size_t)rows + (size_t)B * s->row_cap) * H));      // + one replacement slot per row (q3_session_replace)
+    HIPC(s->pool.alloc(&s->limit, B));
+    {
+        std::vector<int> lim(B);
+        for (int b = 0; b < B; ++b) lim[b] = s->seq[b].limit;
+        HIPC(hipMemcpy(s->limit, lim.data(), B * 4, hipMemcpyHostToDevice));
+    }
     HIPC(s->pool.alloc(&s->embeds, (size_t)B * s->prefill_len * H));
     HIPC(s->pool.alloc(&s->xvec, (size_t)B * H));
     HIPC(s->pool.alloc(&s->ids_dev, (size_t)rows)); HIPC(s->pool.alloc(&s->tr_dev, (size_t)B * s->prefill_len)); HIPC(s->pool.alloc(&s->ci_dev, (size_t)B * s->prefill_len));
@@ -1602,17 +1632,17 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     HIPC(s->pool.alloc(&s->trail_base, B)); HIPC(s->pool.alloc(&s->trail_len, B)); HIPC(s->pool.alloc(&s->pad_row, B));
     HIPC(s->pool.alloc(&s->tok, B)); HIPC(s->pool.alloc(&s->seen, (size_t)B * c.codec_vocab));
     HIPC(s->pool.alloc(&s->frame_idx, B)); HIPC(s->pool.alloc(&s->pos, B)); HIPC(s->pool.alloc(&s->token_count, B));
-    HIPC(s->pool.alloc(&s->U, (size_t)B * (s->max_frames + 1)));
+    HIPC(s->pool.alloc(&s->U, (size_t)B * (s->max_frames + 2)));      // one draw per sampled token (max_frames + 1) + a spare for a frozen row
     HIPC(s->pool.alloc(&s->codes, (size_t)B * s->max_frames * 16));
     // RNG: one PCG stream per sequence, one draw per sampled token
-    std::vector<float> U((size_t)B * (s->max_frames + 1));
+    std::vector<float> U((size_t)B * (s->max_frames + 2), 0.0f);
     for (int b = 0; b < B; ++b) {
         uint64_t st;
         const q3_options& o = reqs[b].opts;
         uint64_t seed = o.seed;
         if (!o.has_seed) seed = (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count() + 0x9E37ULL * b;
         q3_rng_seed(seed, &st);
-        for (int i = 0; i <= s->max_frames; ++i) U[(size_t)b * (s->max_frames + 1) + i] = q3_rng_next(&st);
+        for (int i = 0; i <= s->max_frames; ++i) U[(size_t)b * (s->max_frames + 2) + i] = q3_rng_next(&st);
     }
     HIPC(hipMemcpy(s->U, U.data(), U.size() * 4, hipMemcpyHostToDevice));
     *out = s.release();
@@ -1930,21 +1960,27 @@ static q3_status refresh_codes(q3_session* s) {
     if (s->codes_host_valid) return Q3_OK;
     HIPC(hipStreamSynchronize(s->stream));
     s->codes_host.resize((size_t)s->B * s->max_frames * 16);
-    if (s->frames_run > 0)
-        for (int b = 0; b < s->B; ++b)
+    for (int b = 0; b < s->B; ++b) {
+        int ran = s->frames_run - s->seq[b].start_run;
+        if (ran > s->seq[b].limit) ran = s->seq[b].limit;
+        if (ran > 0)
             HIPC(hipMemcpy(&s->codes_host[(size_t)b * s->max_frames * 16], s->codes + (size_t)b * s->max_frames * 16,
-                           (size_t)s->frames_run * 16 * 4, hipMemcpyDeviceToHost));
+                           (size_t)ran * 16 * 4, hipMemcpyDeviceToHost));
+    }
     std::vector<uint32_t> tok(s->B);
     HIPC(hipMemcpy(tok.data(), s->tok, s->B * 4, hipMemcpyDeviceToHost));
     for (int b = 0; b < s->B; ++b) {
         SeqInfo& q = s->seq[b];
-        int n = s->frames_run; bool done = false;
+        int n = s->frames_run - q.start_run; bool done = false;      // frames this row has run (rows swapped in later started later)
+        if (n > q.limit) n = q.limit;
+        if (n < 0) n = 0;
         if (s->opts.eos_token_id >= 0) {
-            for (int f = 0; f < s->frames_run; ++f)
+            const int ran = n;
+            for (int f = 0; f < ran; ++f)
                 if ((int)s->codes_host[((size_t)b * s->max_frames + f) * 16] == s->opts.eos_token_id) { n = f; done = true; break; }
-            if (!done && (int)tok[b] == s->opts.eos_token_id) done = true;     // EOS sampled for the next frame
+            if (!done && ran < q.limit && (int)tok[b] == s->opts.eos_token_id) done = true;     // EOS sampled for the next frame
         }
-        if (n >= s->max_frames) done = true;
+        if (n >= q.limit) done = true;
         q.n_frames = n; q.done = done;
     }
     s->codes_host_valid = true;
@@ -1952,6 +1988,12 @@ static q3_status refresh_codes(q3_session* s) {
 }
 
 static bool all_done(q3_session* s) { for (auto& q : s->seq) if (!q.done) return false; return true; }
+// frames the session still has to run for its longest-remaining row (lockstep sessions: max_frames - frames_run)
+static int session_remaining(const q3_session* s) {
+    int r = 0;
+    for (const auto& q : s->seq) { const int left = q.limit - (s->frames_run - q.start_run); if (left > r) r = left; }
+    return r;
+}
 
 extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_graph) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
@@ -1959,7 +2001,7 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
     HIPC(hipSetDevice(s->m->device));
     if (s->debug || s->profile) use_graph = 0;
     int todo = n_frames;
-    if (s->frames_run + todo > s->max_frames) todo = s->max_frames - s->frames_run;
+    { const int left = session_remaining(s); if (todo > left) todo = left; }
     if (todo <= 0) return Q3_OK;
     if (use_graph && !s->graph_exec) {
         HIPC(hipStreamSynchronize(s->stream));
@@ -1991,6 +2033,103 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         }
         s->prof_events.clear(); s->prof_event_bytes.clear(); s->prof_pool_next = 0;
     }
+    return Q3_OK;
+}
+
+static q3_status decode_range_on(q3_session* s, int b, int f0, int f1, hipStream_t st, float* pcm_host, size_t cap, size_t* n_samples);
+
+// Continuous batching: swap a finished row of a running session for a new request (include/q3tts.h). The reference keeps all
+// per-utterance state per call (KV caches, sampling context, penalty mask, trailing text: lib.rs:743-756, 1484-1541); here
+// that state is the row's slice of the session's device arrays, so a swap = prefill the request in a one-row side session
+// (the unchanged prefill path) and copy its slice in: K/V extents of the prompt positions, last hidden state, first sampled
+// token, penalty mask, counters, the pre-drawn PCG stream, projected text rows. The captured frame graph is untouched — it
+// only ever reads these arrays — and the other rows do not notice: their state, and therefore their bits, are unchanged.
+extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* req) {
+    if (!s || !req || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "q3_session_replace: bad argument");
+    if (!s->prefilled) return set_err(Q3_INVALID_ARG, "q3_session_replace: session not prefilled");
+    if (s->debug || s->profile) return set_err(Q3_UNSUPPORTED, "q3_session_replace: not on debug / profiling sessions");
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    HIPC(hipSetDevice(m->device));
+    q3_request r = *req;
+    const int limit = r.opts.max_length;
+    if (limit < 1 || limit > s->max_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: max_length %d outside 1..%d (the session's frame budget)", limit, s->max_frames);
+    r.opts.max_length = s->max_frames;                 // the side session draws the row's PCG stream with the host session's stride
+    if (!opts_equal_sampling(r.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request must share the session's sampling options (seed and max_length may differ)");
+    if (r.ref_codes && r.n_ref > 0) return set_err(Q3_UNSUPPORTED, "q3_session_replace: requests with reference codes (ICL) cannot be swapped in");
+    q3_session* side_raw = nullptr;
+    Q3C(q3_session_create(s->m, &r, 1, &side_raw));
+    std::unique_ptr<q3_session> side(side_raw);
+    const SeqInfo& sq = side->seq[0];
+    if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
+    if (side->prefill_len + limit + 1 > s->max_seq) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", side->prefill_len, limit, s->max_seq);
+    Q3C(q3_session_prefill(side.get()));               // ends with a synchronisation of the side stream
+    HIPC(hipStreamSynchronize(s->stream));             // no frame of the host session in flight while its row changes
+    const int H = c.hidden, S = side->prefill_len, nkv = c.n_kv_heads;
+    const size_t row_bytes = (size_t)HEAD_DIM * 4;
+    for (int l = 0; l < c.n_layers; ++l) {
+        const size_t so = (size_t)l * side->kv_layer_stride, dof = (size_t)l * s->kv_layer_stride + (size_t)b * nkv * s->max_seq * HEAD_DIM;
+        HIPC(hipMemcpy2DAsync(s->kcache + dof, s->max_seq * row_bytes, side->kcache + so, side->max_seq * row_bytes, S * row_bytes, nkv, hipMemcpyDeviceToDevice, s->stream));
+        HIPC(hipMemcpy2DAsync(s->vcache + dof, s->max_seq * row_bytes, side->vcache + so, side->max_seq * row_bytes, S * row_bytes, nkv, hipMemcpyDeviceToDevice, s->stream));
+    }
+    auto d2d = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->stream); };
+    HIPC(d2d(s->LASTH + (size_t)b * H, side->LASTH, (size_t)H * 4));
+    HIPC(d2d(s->tok + b, side->tok, 4));
+    HIPC(d2d(s->seen + (size_t)b * c.codec_vocab, side->seen, (size_t)c.codec_vocab));
+    HIPC(d2d(s->token_count + b, side->token_count, 4));
+    HIPC(d2d(s->pos + b, side->pos, 4));
+    HIPC(d2d(s->frame_idx + b, side->frame_idx, 4));
+    HIPC(d2d(s->U + (size_t)b * (s->max_frames + 2), side->U, (size_t)(s->max_frames + 2) * 4));
+    const int row0 = s->repl_base + b * s->row_cap;
+    HIPC(d2d(s->rows + (size_t)row0 * H, side->rows, (size_t)sq.n_rows * H * 4));
+    const int hv[4] = {row0 + (sq.trail_base - sq.row_base), sq.trailing_len, row0 + (sq.pad_row - sq.row_base), limit};
+    HIPC(hipMemcpyAsync(s->trail_base + b, &hv[0], 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->trail_len + b, &hv[1], 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->pad_row + b, &hv[2], 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->limit + b, &hv[3], 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipStreamSynchronize(s->stream));
+    SeqInfo nq = sq;
+    nq.row_base = row0; nq.trail_base = hv[0]; nq.pad_row = hv[2];
+    nq.start_run = s->frames_run; nq.limit = limit; nq.n_frames = 0; nq.done = false; nq.stream_pos = 0; nq.req.opts.max_length = limit;
+    s->seq[b] = nq;
+    s->codes_host_valid = false;
+    return Q3_OK;
+}
+
+// Streaming with several sequences in one session: the next chunk of row b (StreamingSession::next_chunk, lib.rs:1650-1759,
+// one per row). Rows advance in lockstep, so asking row after row costs the frames once: the first call generates them for
+// every row, the others find theirs buffered and only run their vocoder. One row: q3_session_next_chunk (with read-ahead).
+extern "C" q3_status q3_session_next_chunk_row(q3_session* s, int b, float* pcm_host, size_t cap, size_t* n_samples, int* done) {
+    if (!s || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad sequence index");
+    HIPC(hipSetDevice(s->m->device));
+    if (!s->prefilled) Q3C(q3_session_prefill(s));
+    Q3C(refresh_codes(s));
+    SeqInfo& q = s->seq[b];
+    const int chunk = s->opts.chunk_frames > 0 ? s->opts.chunk_frames : 10;
+    while (!q.done && q.n_frames - q.stream_pos < chunk && session_remaining(s) > 0) {
+        Q3C(q3_session_generate(s, chunk - (q.n_frames - q.stream_pos), 1));
+        Q3C(refresh_codes(s));
+    }
+    int avail = q.n_frames - q.stream_pos;
+    if (avail > chunk) avail = chunk;
+    if (avail <= 0) { if (n_samples) *n_samples = 0; if (done) *done = 1; return Q3_OK; }
+    const int spf = samples_per_frame(s->m->cfg);
+    if (s->stream_mode == 1 && !q.icl) {
+        // continuous mode (q3_session_set_stream_mode): left context re-run, sample-exact with the whole-utterance decode
+        const int a0 = q.stream_pos, e = q.stream_pos + avail, c0 = a0 > CODEC_CTX_FRAMES ? a0 - CODEC_CTX_FRAMES : 0;
+        Q3C(codec_reserve(s->m, s->cws, chunk + CODEC_CTX_FRAMES, s->max_frames));
+        HIPC(hipMemcpyAsync(s->cws.frames, s->codes + (size_t)b * s->max_frames * 16, (size_t)e * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
+        Q3C(codec_decode_dev(s->m, s->cws, e, s->stream, nullptr, c0));
+        HIPC(hipStreamSynchronize(s->stream));
+        if (n_samples) *n_samples = (size_t)avail * spf;
+        if (pcm_host) {
+            if (cap < (size_t)avail * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+            HIPC(hipMemcpy(pcm_host, s->cws.pcm + (size_t)(a0 - c0) * spf, (size_t)avail * spf * 4, hipMemcpyDeviceToHost));
+        }
+    } else {
+        Q3C(decode_range_on(s, b, q.stream_pos, q.stream_pos + avail, s->stream, pcm_host, cap, n_samples));
+    }
+    q.stream_pos += avail;
+    if (done) *done = (q.done && q.stream_pos >= q.n_frames) ? 1 : 0;
     return Q3_OK;
 }
 
@@ -2191,10 +2330,10 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
         return Q3_OK;
     };
     q3_status st = Q3_OK;
-    while (st == Q3_OK && s->frames_run < s->max_frames && !all_done(s)) {
+    while (st == Q3_OK && session_remaining(s) > 0 && !all_done(s)) {
         st = q3_session_generate(s, seg_env, use_graph);
         if (st == Q3_OK) st = refresh_codes(s);
-        if (st == Q3_OK && s->frames_run < s->max_frames && !all_done(s)) st = dispatch(false);
+        if (st == Q3_OK && session_remaining(s) > 0 && !all_done(s)) st = dispatch(false);
     }
     const auto t2 = clk::now();
     if (st == Q3_OK) st = dispatch(true);
@@ -2230,7 +2369,7 @@ extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_
     SeqInfo& q = s->seq[0];
     const int chunk = s->opts.chunk_frames > 0 ? s->opts.chunk_frames : 10;
     // generate until chunk_frames frames are buffered or the sequence ends (lib.rs:1663-1748)
-    while (!q.done && q.n_frames - s->stream_pos < chunk && s->frames_run < s->max_frames) {
+    while (!q.done && q.n_frames - s->stream_pos < chunk && session_remaining(s) > 0) {
         int need = chunk - (q.n_frames - s->stream_pos);
         Q3C(q3_session_generate(s, need, 1));
         Q3C(refresh_codes(s));
@@ -2250,7 +2389,7 @@ extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_
     int ahead = 0;
     if (!no_ahead && !q.done && s->graph_exec && !s->debug && !s->profile) {
         ahead = chunk - (q.n_frames - (s->stream_pos + avail));
-        if (ahead > s->max_frames - s->frames_run) ahead = s->max_frames - s->frames_run;
+        if (ahead > session_remaining(s)) ahead = session_remaining(s);
         if (ahead < 0) ahead = 0;
     }
     const bool first = s->stream_pos == 0;
@@ -2512,11 +2651,13 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
     HIPC(pool.alloc(&x, (size_t)M * K)); HIPC(pool.alloc(&y, (size_t)M * N)); HIPC(pool.alloc(&w, wt_elems));
     HIPC(hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(w, wt.data(), wt_elems * 2, hipMemcpyHostToDevice));
     if (bias_host) { HIPC(pool.alloc(&b, (size_t)N)); HIPC(hipMemcpy(b, bias_host, (size_t)N * 4, hipMemcpyHostToDevice)); }
-    const int step = mode == 1 ? Q3_MAX_BATCH : 16;          // up to 64 rows per launch on the 16-row tiles (k_gemv_wide beyond 16)
+    const int step = mode == 1 ? Q3_MAX_BATCH : 16;          // up to 64 rows per launch on the 16-row tiles (wide-session kernels beyond 16)
+    float* ws = nullptr; size_t ws_bytes = 0;
+    if (M > 16 && N % 128 == 0 && K % 128 == 0) { ws_bytes = gemm_wide_ws_bytes(M < step ? M : step, N, K, EPI_NONE); HIPC(pool.alloc(&ws, ws_bytes / 4)); }
     for (int m0 = 0; m0 < M; m0 += step) {
         LinArgs a;
         a.W = w; a.N = N; a.K = K; a.x = x + (size_t)m0 * K; a.ldx = K; a.bias = b; a.y = y + (size_t)m0 * N; a.ldy = N; a.M = (M - m0) < step ? (M - m0) : step; a.epi = EPI_NONE;
-        a.tiled = mode; a.Kpad = kpad_for(mode, K);
+        a.tiled = mode; a.Kpad = kpad_for(mode, K); a.ws = ws; a.ws_bytes = ws_bytes;
         HIPC(launch_linear(a, 0));
     }
     HIPC(hipDeviceSynchronize());
@@ -2626,8 +2767,11 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
         HIPC(hipMemcpy(nw, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
     }
     hipStream_t st; HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    float* ws = nullptr; size_t ws_bytes = 0;
+    if (M > 16 && tiled == 1 && N % 128 == 0 && K % 128 == 0) { ws_bytes = gemm_wide_ws_bytes(M, N, K, epi); HIPC(pool.alloc(&ws, ws_bytes / 4)); }
     auto one = [&](int i) -> hipError_t {
         LinArgs a;
+        a.ws = ws; a.ws_bytes = ws_bytes;
         const int c = i % n_copies;
         a.W = w + (size_t)c * nmat * welems; a.W2 = nmat == 2 ? a.W + welems : nullptr;
         a.N = N; a.K = K; a.Kpad = tiled == 2 ? up128(K) : up32(K); a.tiled = tiled; a.x = x; a.ldx = K; a.y = y; a.ldy = N; a.M = M; a.epi = epi;

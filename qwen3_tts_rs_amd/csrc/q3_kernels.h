@@ -64,9 +64,15 @@ struct LinArgs {
     // side job of any GEMV launch: store zeros to zero[0 .. zero_n) (zero_n % 4 == 0) — how the target of the NEXT
     // split-K launch is cleared without a launch of its own (the buffer must be dead for this launch's consumers)
     float* zero = nullptr; int zero_n = 0;
+    // workspace of the wide-session GEMM (q3_kernels_wide.hip; 17 <= M <= 64): slice sums [S][matrices][M][N] + sum(x^2) [S][M].
+    // nullptr / too small: the launch falls back to k_gemv_wide
+    float* ws = nullptr; size_t ws_bytes = 0;
     Q3_TRACE_FIELD
 };
 hipError_t launch_linear(const LinArgs& a, hipStream_t st);       // dispatches on a.tiled
+// wide sessions: 128 weight rows x one K slice per workgroup + a slice-sum / epilogue launch; hipErrorNotSupported = shape outside the family
+hipError_t launch_gemm_wide(const LinArgs& a, hipStream_t st);
+size_t gemm_wide_ws_bytes(int M, int N, int K, int epi);
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st);   // MFMA bf16x3 kernel (16-row tiles, tiled == 1)
 hipError_t launch_gemv_tiled4(const LinArgs& a, hipStream_t st);  // 4-row tiles on the 4x4x4 16-block MFMA (tiled == 2)
 hipError_t launch_linear_rowmajor(const LinArgs& a, hipStream_t st);   // first-generation VALU kernel
@@ -211,6 +217,10 @@ struct SampleArgs {
     int token_count_static;
     int* frame_idx; int* pos;        // advanced by one after sampling when advance != 0
     int advance;
+    // per-sequence frame limits (nullable): a sequence whose frame_idx has reached limit[b] is FROZEN — its counters
+    // (frame_idx, pos, token_count) stop, so it keeps re-running its last position in bounds while the other rows of the
+    // session go on (rows end at different frames: own max_length, a row swapped in later — q3_session_replace)
+    const int* limit;
     float* logits_hist; int hist_stride_b; int hist_cap;  // optional capture [B][cap][vocab] at index token_count
     int vocab, B;
     float inv_temp; int apply_temp; int greedy;

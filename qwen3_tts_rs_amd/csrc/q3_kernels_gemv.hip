@@ -1096,7 +1096,12 @@ static hipError_t launch_gemv_wide(const LinArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st) {
-    if (a.M > 16) return a.ksplit > 1 ? hipErrorInvalidValue : launch_gemv_wide(a, st);
+    if (a.M > 16) {
+        if (a.ksplit > 1) return hipErrorInvalidValue;
+        static const bool no_gemm = getenv("Q3_WIDE_NO_GEMM") != nullptr;      // A/B aid: wide sessions on k_gemv_wide
+        if (a.ws && !no_gemm) { const hipError_t e = launch_gemm_wide(a, st); if (e != hipErrorNotSupported) return e; }
+        return launch_gemv_wide(a, st);
+    }
     if (a.ksplit == 2) return launch_gemv_sk2(a, st);
     if (a.ksplit != 1) return hipErrorInvalidValue;
     if (a.Kpad % 32 != 0 || a.K % 8 != 0 || a.K > a.Kpad || a.ldx % 4 != 0 || a.M < 1 || a.M > 16 || a.N < 1)

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
             float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
             for (int c = tid; c < a.g_proj_dim / 4; c += 256) pd[c] = ps[c];
-            if (tid == 0) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
+            if (tid == 0 && a.g_frame_idx[b] < a.g_max_frames) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
         }
     }
     // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v)
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
             const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
             float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
             for (int c = c0 + lane; c < c1; c += 64) pd[c] = ps[c];
-            if (h == 0 && lane == 0) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
+            if (h == 0 && lane == 0 && a.g_frame_idx[b] < a.g_max_frames) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
         }
     }
     float2 q = *reinterpret_cast<const float2*>(qkv_row + h * HEAD_DIM + 2 * lane);
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_cp_gather(CpGatherArgs a) {
         row = (int)a.tok[b];
     } else {
         row = block_argmax_first(a.cp_logits + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
-        if (tid == 0) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)row;
+        if (tid == 0 && a.frame_idx[b] < a.max_frames) a.codes[((size_t)b * a.max_frames + a.frame_idx[b]) * 16 + (a.pass - 1)] = (uint32_t)row;
     }
     if (a.qkv_tab) {
         const float4* src = reinterpret_cast<const float4*>(a.qkv_tab + (size_t)row * a.qkv_dim);
@@ -1080,9 +1080,11 @@ __global__ __launch_bounds__(256) void k_frame_embed(FrameEmbedArgs a) {
     __shared__ uint32_t codes_s[16];
     const int b = blockIdx.x;
     const int f = a.frame_idx[b];
-    uint32_t* frame = a.codes + ((size_t)b * a.max_frames + f) * 16;
+    // a frozen sequence (SampleArgs::limit) may sit at frame_idx == max_frames: it records nothing and reads its last slot
+    const bool live = f < a.max_frames;
+    uint32_t* frame = a.codes + ((size_t)b * a.max_frames + (live ? f : a.max_frames - 1)) * 16;
     const int last = block_argmax_first(a.cp_logits_last + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
-    if (threadIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0 && live) {
         frame[0] = a.tok[b];
         frame[a.n_acoustic] = (uint32_t)last;
     }
@@ -1325,8 +1327,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
     if (tid == 0) {
         a.tok[b] = (uint32_t)pick;
         if (seen && pick < V) seen[pick] = 1;
-        if (a.token_count) a.token_count[b] = tc + 1;
-        if (a.advance) { a.frame_idx[b] += 1; a.pos[b] += 1; }
+        const bool frozen = a.advance && a.limit && a.frame_idx[b] >= a.limit[b];      // SampleArgs::limit
+        if (a.token_count && !frozen) a.token_count[b] = tc + 1;
+        if (a.advance && !frozen) { a.frame_idx[b] += 1; a.pos[b] += 1; }
     }
 }
 

@@ -1,0 +1,313 @@
+// q3_kernels_wide.hip — the projections of WIDE sessions (33 .. 64 sequences advancing in one session) as a real GEMM.
+//
+// Why a second family (round 3). With M <= 16 rows a projection is a weight stream: one 16-row weight tile per workgroup,
+// every workgroup reading all of x (q3_kernels_gemv.hip). At M = 64 that shape is upside down — x is M*K*4 = 512 KB
+// (K = 2048) and all 256 workgroups of k_gemv_wide pull it through the L2s (134 MB of L2 -> CU traffic against 16.8 MB of
+// weights): 20 us for the talker's q|k|v, 840 GB/s, neither roof (profiles/r2_gemv_wide_batches.txt). Here a workgroup owns
+// 128 weight rows x ONE K slice: it reads 128 x Ks weights and only the Ks columns of x, splits that slice of x into its
+// three exact bf16 terms ONCE (all 512 threads, into LDS in MFMA B-operand order), and its eight waves — one 16-row weight
+// tile each — run the bf16x3 products against the shared LDS image, no cross-wave reduction at all. The K slices of a row
+// group are summed by a second, tiny launch (k_wide_epilogue) in fixed slice order — deterministic — which also applies
+// 1/rms, bias, residual, SiLU / SwiGLU. Two launches per projection; both are captured in the frame graph.
+//   y[m][n] = epi( sum_s sum_{k in slice s} (x[m][k] * norm_w[k]) * W[n][k]  /  sqrt(mean_k x[m][k]^2 + eps) )
+// Numerics: the same exact bf16x3 arithmetic as the GEMV family; only the summation order differs.
+#include "q3_kernels.h"
+
+#include <math.h>
+
+namespace q3 {
+
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+struct Split3 { u32x4_t hi, mid, lo; };
+// exact 3-way bf16 split of 8 floats (element 2i in the low half of word i) — the split of q3_kernels_gemv.hip
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const uint32_t h = cvt_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const uint32_t m = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        s.hi[i] = h; s.mid[i] = m; s.lo[i] = cvt_pk_bf16(sa, sb);
+    }
+    return s;
+}
+__device__ __forceinline__ f32x4_t mfma_bf16(const u32x4_t& w, const u32x4_t& b, f32x4_t acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ float lane_xor32f(float v, bool upper) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(upper ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor16f(float v, bool odd_row) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(odd_row ? r[0] : r[1]);
+}
+
+struct WideArgs {
+    const uint16_t* W; const uint16_t* W2;      // mode-1 tiled images ([N/16][Kpad/32][64 lanes][8 bf16]); W2: the SwiGLU "up" matrix
+    const float* x; int ldx; const float* norm_w;
+    int M, N, K, kst;                            // kst = k-steps of 32 per tile row of the image (Kpad / 32)
+    int S, Ks, nmat, rgm;                        // K slices, k per slice (multiple of 128), matrices, 128-row groups per matrix
+    float* part;                                 // [S][nmat][M][N] slice sums
+    float* ssq;                                  // [S][M] sum of x^2 per row and slice (fused RMSNorm)
+};
+
+// One workgroup = NWV waves x one 16-row weight tile (128 or 64 weight rows) x one K slice, all M <= 16*MT rows of x.
+// The K slice is walked in 128-column chunks; the requests of chunk c+1 (x, norm weight, weight tiles) are issued before
+// the MFMAs of chunk c, into a second register set — two sets used alternately, no copies.
+template <bool RMS, int MT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_wide_gemm(WideArgs a) {
+    __shared__ __attribute__((aligned(16))) u32x4_t xs[3][MT][4][64];       // [plane][column tile][k-step of the chunk][lane]: 12 KB x MT
+    __shared__ float ssq_s[(MT * 4 + NWV - 1) / NWV][NWV][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m16 = lane & 15, kg = lane >> 4;
+    const int rg = blockIdx.x, s = blockIdx.y;
+    const int mat = rg / a.rgm, rgi = rg - mat * a.rgm;
+    const int tile = rgi * NWV + wave;
+    const bool tile_ok = tile * 16 < a.N;
+    const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(mat ? a.W2 : a.W) + (size_t)(tile_ok ? tile : 0) * a.kst * 64 + lane;
+    const int k_begin = s * a.Ks, k_end = (k_begin + a.Ks) < a.K ? (k_begin + a.Ks) : a.K;
+    constexpr int NIT = (MT * 4 + NWV - 1) / NWV;     // staging items (column tile, k-step) per wave and chunk
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float ss_acc[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) ss_acc[j] = 0.0f;
+
+    struct Set { float4 xa[NIT], xb[NIT], na[NIT], nb[NIT]; u32x4_t wa[4]; };
+    // requests of a chunk: this wave's share of x (and of the norm weight) first — they come back first and feed the staging —
+    // then its four weight tiles
+    auto request = [&](Set& r, int k0) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = wave + NWV * j, t = it >> 2, ks = it & 3;
+            const int m = 16 * t + m16, kk = k0 + (4 * ks + kg) * 8;
+            const bool ok = it < MT * 4 && m < a.M;
+            const float* px = a.x + (size_t)(ok ? m : 0) * a.ldx + kk;
+            r.xa[j] = ok ? *reinterpret_cast<const float4*>(px) : float4{0.f, 0.f, 0.f, 0.f};
+            r.xb[j] = ok ? *reinterpret_cast<const float4*>(px + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (RMS) { r.na[j] = *reinterpret_cast<const float4*>(a.norm_w + kk); r.nb[j] = *reinterpret_cast<const float4*>(a.norm_w + kk + 4); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.wa[i] = __builtin_nontemporal_load(wp + (size_t)((k0 >> 5) + i) * 64);
+    };
+    // staging: split once, park the B operands of the whole workgroup in LDS (lane-linear fragments: conflict-free b128)
+    auto stage = [&](const Set& r) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = wave + NWV * j;
+            if (it < MT * 4) {                       // wave-uniform
+                float xv[8] = {r.xa[j].x, r.xa[j].y, r.xa[j].z, r.xa[j].w, r.xb[j].x, r.xb[j].y, r.xb[j].z, r.xb[j].w};
+                if constexpr (RMS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss_acc[j] = fmaf(xv[e], xv[e], ss_acc[j]);
+                    xv[0] *= r.na[j].x; xv[1] *= r.na[j].y; xv[2] *= r.na[j].z; xv[3] *= r.na[j].w;
+                    xv[4] *= r.nb[j].x; xv[5] *= r.nb[j].y; xv[6] *= r.nb[j].z; xv[7] *= r.nb[j].w;
+                }
+                const Split3 sp = split3(xv);
+                xs[0][it >> 2][it & 3][lane] = sp.hi; xs[1][it >> 2][it & 3][lane] = sp.mid; xs[2][it >> 2][it & 3][lane] = sp.lo;
+            }
+        }
+    };
+    auto multiply = [&](const Set& r) {
+        if (tile_ok) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    acc[t] = mfma_bf16(r.wa[ks], xs[0][t][ks][lane], acc[t]);
+                    acc[t] = mfma_bf16(r.wa[ks], xs[1][t][ks][lane], acc[t]);
+                    acc[t] = mfma_bf16(r.wa[ks], xs[2][t][ks][lane], acc[t]);
+                }
+        }
+    };
+    Set A, B;
+    request(A, k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 256) {
+        stage(A);
+        __syncthreads();
+        if (k0 + 128 < k_end) request(B, k0 + 128);          // in flight under this chunk's MFMAs
+        multiply(A);
+        __syncthreads();                                     // the next staging overwrites xs
+        if (k0 + 128 >= k_end) break;
+        stage(B);
+        __syncthreads();
+        if (k0 + 256 < k_end) request(A, k0 + 256);
+        multiply(B);
+        __syncthreads();
+    }
+    // slice sums: lane (column m16 of tile t, row group kg) holds rows kg*4 .. kg*4+3 — 16 bytes contiguous in n
+    if (tile_ok) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = 16 * t + m16;
+            if (m < a.M)
+                *reinterpret_cast<f32x4_t*>(a.part + (((size_t)s * a.nmat + mat) * a.M + m) * a.N + tile * 16 + kg * 4) = acc[t];
+        }
+    }
+    if constexpr (RMS) {
+        if (rg == 0) {                               // one workgroup per slice reports sum(x^2); fixed order: k-groups, then k-steps
+            const bool upper = lane >= 32, odd = (lane & 16) != 0;
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                float v = ss_acc[j];
+                v += lane_xor16f(v, odd); v += lane_xor32f(v, upper);
+                if (kg == 0) ssq_s[j][wave][m16] = v;
+            }
+            __syncthreads();
+            if (tid < 16 * MT) {
+                // the four k-step items of column tile t are items 4t .. 4t+3: item it was staged by wave it % NWV in pass it / NWV
+                const int t = tid >> 4, mm = tid & 15;
+                float tot = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { const int it = 4 * t + ks; tot += ssq_s[it / NWV][it % NWV][mm]; }
+                if (16 * t + mm < a.M) a.ssq[(size_t)s * a.M + 16 * t + mm] = tot;
+            }
+        }
+    }
+}
+
+struct WideEpiArgs {
+    const float* part; const float* ssq; int S, nmat, M, N, K; float eps;
+    const float* bias; const float* resid; int ldr; float* y; int ldy;
+};
+// slice sums -> y: fixed slice order, then 1/rms, +bias, +residual, SiLU, SwiGLU (the epilogues of the GEMV family)
+template <int EPI, bool RMS>
+__global__ __launch_bounds__(256) void k_wide_epilogue(WideEpiArgs e) {
+    const int m = blockIdx.y, n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= e.N) return;
+    float4 v = {0.f, 0.f, 0.f, 0.f}, v2 = v;
+    const size_t plane = (size_t)e.M * e.N;
+    const float* p = e.part + (size_t)m * e.N + n;
+    // slice sums in groups of eight requests in flight at once (a plain loop over a run-time S waits one memory round trip per
+    // slice: 16 slices = 10 us of a 13 us projection in the first cut); the ADDS keep the slice order
+    for (int s0 = 0; s0 < e.S; s0 += 8) {
+        float4 a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = (s0 + i) < e.S ? (s0 + i) : (e.S - 1);
+            a[i] = *reinterpret_cast<const float4*>(p + (size_t)s * e.nmat * plane);
+            if constexpr (EPI == EPI_SWIGLU) b[i] = *reinterpret_cast<const float4*>(p + ((size_t)s * e.nmat + 1) * plane);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (s0 + i < e.S) {
+                v.x += a[i].x; v.y += a[i].y; v.z += a[i].z; v.w += a[i].w;
+                if constexpr (EPI == EPI_SWIGLU) { v2.x += b[i].x; v2.y += b[i].y; v2.z += b[i].z; v2.w += b[i].w; }
+            }
+        }
+    }
+    if constexpr (RMS) {
+        float tot = 0.0f;
+        for (int s0 = 0; s0 < e.S; s0 += 8) {
+            float q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = e.ssq[(size_t)((s0 + i) < e.S ? (s0 + i) : (e.S - 1)) * e.M + m];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (s0 + i < e.S) tot += q[i];
+        }
+        const float den = sqrtf(tot / (float)e.K + e.eps);
+        v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+        if constexpr (EPI == EPI_SWIGLU) { v2.x = v2.x / den; v2.y = v2.y / den; v2.z = v2.z / den; v2.w = v2.w / den; }
+    }
+    if (e.bias) { const float4 b = *reinterpret_cast<const float4*>(e.bias + n); v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; }
+    if constexpr (EPI == EPI_RESID) {
+        const float4 r = *reinterpret_cast<const float4*>(e.resid + (size_t)m * e.ldr + n);
+        v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
+    }
+    if constexpr (EPI == EPI_SILU || EPI == EPI_SWIGLU) {
+        v.x = v.x / (1.0f + expf(-v.x)); v.y = v.y / (1.0f + expf(-v.y)); v.z = v.z / (1.0f + expf(-v.z)); v.w = v.w / (1.0f + expf(-v.w));
+    }
+    if constexpr (EPI == EPI_SWIGLU) { v.x *= v2.x; v.y *= v2.y; v.z *= v2.z; v.w *= v2.w; }
+    *reinterpret_cast<float4*>(e.y + (size_t)m * e.ldy + n) = v;
+}
+
+template <bool RMS, int NWV>
+hipError_t launch_gemm_t(const WideArgs& w, hipStream_t st) {
+    const dim3 grid(w.rgm * w.nmat, w.S), blk(NWV * 64);
+    const int mt = (w.M + 15) / 16;
+    if (mt <= 2) hipLaunchKernelGGL((k_wide_gemm<RMS, 2, NWV>), grid, blk, 0, st, w);
+    else if (mt == 3) hipLaunchKernelGGL((k_wide_gemm<RMS, 3, NWV>), grid, blk, 0, st, w);
+    else hipLaunchKernelGGL((k_wide_gemm<RMS, 4, NWV>), grid, blk, 0, st, w);
+    return hipGetLastError();
+}
+template <int EPI>
+hipError_t launch_epi_t(const WideEpiArgs& e, bool rms, hipStream_t st) {
+    const dim3 grid((e.N / 4 + 255) / 256, e.M), blk(256);
+    if (rms) hipLaunchKernelGGL((k_wide_epilogue<EPI, true>), grid, blk, 0, st, e);
+    else hipLaunchKernelGGL((k_wide_epilogue<EPI, false>), grid, blk, 0, st, e);
+    return hipGetLastError();
+}
+}  // namespace
+
+// Geometry: 128 weight rows per workgroup, or 64 when that is what it takes to fill the chip with slices of at least two
+// 128-column chunks (the chunk pipeline needs two to overlap anything; fewer, longer slices also mean fewer slice sums).
+static void wide_plan(int N, int nmat, int K, int& rows, int& S, int& Ks) {
+    const int chunks = K / 128;
+    auto plan = [&](int r, int min_chunks, int& s_out, int& ks_out) {
+        const int groups = (N / r) * nmat;
+        int want = 256 / groups;                       // never more workgroups than CUs: the RMS / four-column-tile variants hold one
+                                                       // workgroup per CU (134 VGPRs), so 288 workgroups are two rounds (gate/up: 28.8 -> 38.5 us)
+        int max_s = chunks / min_chunks; if (max_s < 1) max_s = 1;
+        if (want > max_s) want = max_s;
+        if (want < 1) want = 1;
+        const int per = (chunks + want - 1) / want;
+        ks_out = per * 128; s_out = (chunks + per - 1) / per;
+        return groups * s_out;
+    };
+    int s128, k128, s64, k64;
+    const int wg128 = plan(128, 2, s128, k128);
+    if (wg128 >= 192 || N % 64 != 0) { rows = 128; S = s128; Ks = k128; return; }
+    const int wg64 = plan(64, 2, s64, k64);
+    if (wg64 > wg128) { rows = 64; S = s64; Ks = k64; } else { rows = 128; S = s128; Ks = k128; }
+}
+
+size_t gemm_wide_ws_bytes(int M, int N, int K, int epi) {
+    const int nmat = epi == EPI_SWIGLU ? 2 : 1;
+    int rows, S, Ks; wide_plan(N, nmat, K, rows, S, Ks);
+    return ((size_t)S * nmat * M * N + (size_t)S * M) * sizeof(float);
+}
+
+// hipErrorNotSupported: the shape is outside this family (the caller falls back to k_gemv_wide)
+hipError_t launch_gemm_wide(const LinArgs& a, hipStream_t st) {
+    const bool rms = a.norm_w != nullptr;
+    // (M <= 32 stays on k_gemv_wide: two column tiles do not pay for the second launch — 1.7B, B = 32: 6.17 vs 6.79 ms per frame)
+    if (a.tiled != 1 || a.M < 33 || a.M > 64 || a.N % 128 != 0 || a.K % 128 != 0 || a.Kpad != a.K || a.ldx % 4 != 0 || a.ldy % 4 != 0 || !a.ws ||
+        (a.epi == EPI_RESID && a.ldr % 4 != 0) || ((a.epi == EPI_RESID || a.epi == EPI_SILU) && rms) || a.ksplit != 1)
+        return hipErrorNotSupported;
+    WideArgs w{};
+    w.W = a.W; w.W2 = a.W2; w.x = a.x; w.ldx = a.ldx; w.norm_w = a.norm_w; w.M = a.M; w.N = a.N; w.K = a.K; w.kst = a.Kpad >> 5;
+    w.nmat = a.epi == EPI_SWIGLU ? 2 : 1;
+    int rows; wide_plan(a.N, w.nmat, a.K, rows, w.S, w.Ks);
+    w.rgm = a.N / rows;
+    const size_t part_floats = (size_t)w.S * w.nmat * a.M * a.N;
+    if ((part_floats + (size_t)w.S * a.M) * sizeof(float) > a.ws_bytes) return hipErrorNotSupported;
+    w.part = a.ws; w.ssq = a.ws + part_floats;
+    hipError_t e = rows == 128 ? (rms ? launch_gemm_t<true, 8>(w, st) : launch_gemm_t<false, 8>(w, st))
+                               : (rms ? launch_gemm_t<true, 4>(w, st) : launch_gemm_t<false, 4>(w, st));
+    if (e != hipSuccess) return e;
+    WideEpiArgs p{};
+    p.part = w.part; p.ssq = w.ssq; p.S = w.S; p.nmat = w.nmat; p.M = a.M; p.N = a.N; p.K = a.K; p.eps = a.eps;
+    p.bias = a.bias; p.resid = a.resid; p.ldr = a.ldr; p.y = a.y; p.ldy = a.ldy;
+    switch (a.epi) {
+        case EPI_NONE: return launch_epi_t<EPI_NONE>(p, rms, st);
+        case EPI_RESID: return launch_epi_t<EPI_RESID>(p, rms, st);
+        case EPI_SILU: return launch_epi_t<EPI_SILU>(p, rms, st);
+        case EPI_SWIGLU: return launch_epi_t<EPI_SWIGLU>(p, rms, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace q3

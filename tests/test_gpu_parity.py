@@ -889,3 +889,108 @@ def test_bench_two_ranks_same_gpu():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["rccl"]["world"] == 2 and sorted(x[0] for x in out["rccl"]["ranks_seen"]) == [0, 1] and out["rccl"]["same_gpu_test_mode"] is True
     assert out["config"]["utterances_per_gpu"] == 2 and out["weight_broadcast"]["bytes"] > 0
+
+
+# ---------------------------------------------------------------- continuous batching (q3_session_replace, per-row limits, per-row streaming)
+@pytest.mark.gpu
+def test_rows_end_at_their_own_limit(pair):
+    """Each row of a session stops at its own max_length (SampleArgs::limit): the session runs until the longest row is done, a
+    frozen row records nothing further, and every row equals its own batch-1 run bit for bit."""
+    cfg, gm, om = pair
+    lims = [5, 12, 9, 1]
+    utts = [_utts("custom", 7, index=i, hidden=cfg.hidden) for i in range(4)]
+    for i, u in enumerate(utts):
+        u.seed = 50 + i; u.max_length = lims[i]
+    opts = q.SynthesisOptions(max_length=12, seed=1, eos_token_id=None)
+    s = gm.session(utts, opts); s.prefill(); s.generate(100, use_graph=True)
+    for i, u in enumerate(utts):
+        n, done = s.frames(i)
+        assert (n, done) == (lims[i], True)
+        s1 = gm.session([u], opts); s1.prefill(); s1.generate(100, use_graph=False)
+        assert s1.frames(0) == (lims[i], True)
+        np.testing.assert_array_equal(s.codes(i), s1.codes(0))
+        np.testing.assert_array_equal(s.decode(i), s1.decode(0))
+        s1.close()
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [True, False])
+def test_replace_staggered_arrivals(pair, graph):
+    """Continuous batching: nine requests with different lengths, texts and seeds go through a THREE-row session;
+    a row that ends is swapped for the next waiting request at the 4-frame poll (q3_session_replace) while the other rows keep
+    running. Every request's codes and PCM are bit-equal to its own batch-1 run — the swap is invisible to the row that is
+    swapped in (it starts from its own prefill) and to the rows that stay."""
+    cfg, gm, om = pair
+    lens = [6, 14, 9, 4, 11, 7, 13, 5, 8]
+    utts = [_utts("custom", 5 + (i % 4), index=i, hidden=cfg.hidden) for i in range(9)]
+    for i, u in enumerate(utts):
+        u.seed = 300 + i; u.max_length = lens[i]
+    opts = q.SynthesisOptions(max_length=14, seed=1, eos_token_id=None)
+    codes, pcm, frames, wall = gm.synthesize_continuous(utts, opts, slots=3, poll_frames=4, use_graph=graph)
+    assert frames == sum(lens)
+    for i, u in enumerate(utts):
+        s1 = gm.session([u], opts); s1.prefill(); s1.generate(100, use_graph=False)
+        np.testing.assert_array_equal(codes[i], s1.codes(0), err_msg=f"request {i}")
+        np.testing.assert_array_equal(pcm[i], s1.decode(0), err_msg=f"request {i}")
+        s1.close()
+
+
+@pytest.mark.gpu
+def test_replace_with_eos_and_other_modes(pair):
+    """Rows that end by EOS are detected at the poll and replaced; the replacement may be another prompt flavour (x-vector /
+    voice design: a different prefill length — positions are per row) as long as it fits the row; misuse is refused."""
+    cfg, gm, om = pair
+    opts = q.SynthesisOptions(max_length=40, seed=3)                      # EOS on: synthetic weights sample it now and then
+    base = [_utts("custom", 6, index=i, hidden=cfg.hidden) for i in range(2)]
+    s = gm.session(base, opts); s.prefill(); s.generate(8, use_graph=True)
+    n0, d0 = s.frames(0)
+    repl = _utts("clone", 4, index=7, hidden=cfg.hidden); repl.seed = 77; repl.max_length = 10
+    s.replace(0, repl)                                                    # row 0 abandoned mid-utterance: allowed, its frames restart at 0
+    s.generate(200, use_graph=True)
+    s1 = gm.session([repl], opts); s1.prefill(); s1.generate(200, use_graph=False)
+    np.testing.assert_array_equal(s.codes(0), s1.codes(0))
+    s1.close()
+    s2 = gm.session([base[1]], opts); s2.prefill(); s2.generate(200, use_graph=False)      # the row that stayed is untouched
+    np.testing.assert_array_equal(s.codes(1), s2.codes(0))
+    s2.close()
+    design = _utts("design", 3, index=2, hidden=cfg.hidden); design.max_length = 6
+    s.replace(1, design)
+    s.generate(200, use_graph=True)
+    s3 = gm.session([design], opts); s3.prefill(); s3.generate(200, use_graph=False)
+    np.testing.assert_array_equal(s.codes(1), s3.codes(0))
+    s3.close()
+    too_long = _utts("custom", 1100, index=1, hidden=cfg.hidden)
+    with pytest.raises(_lib.Q3Error, match="exceed the session's slot"):
+        s.replace(0, too_long)
+    over = _utts("custom", 3, index=1, hidden=cfg.hidden); over.max_length = 41
+    with pytest.raises(_lib.Q3Error, match="frame budget"):
+        s.replace(0, over)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_streaming_several_rows(pair):
+    """One StreamingSession per row of a three-row session (q3_session_next_chunk_row): chunks of every row equal the chunks
+    of its own batch-1 streaming session, in both chunk-decode modes."""
+    cfg, gm, om = pair
+    utts = [_utts("custom", 6, index=i, hidden=cfg.hidden) for i in range(3)]
+    for i, u in enumerate(utts):
+        u.seed = 20 + i; u.max_length = [23, 10, 17][i]
+    opts = q.SynthesisOptions(max_length=23, seed=1, eos_token_id=None, chunk_frames=7)
+    for continuous in (False, True):
+        s = gm.session(utts, opts)
+        if continuous:
+            _lib.check(_lib.lib.q3_session_set_stream_mode(s._h, 1))
+        got = [[] for _ in utts]; done = [False] * 3
+        while not all(done):
+            for b in range(3):
+                if not done[b]:
+                    chunk, d = s.next_chunk_row(b)
+                    if chunk is not None:
+                        got[b].append(chunk.samples)
+                    done[b] = d or chunk is None
+        s.close()
+        for b, u in enumerate(utts):
+            ref = [c.samples for c in api.StreamingSession(gm, u, opts, continuous=continuous)]
+            assert len(ref) == len(got[b]) and all(np.array_equal(x, y) for x, y in zip(ref, got[b])), (continuous, b)
