@@ -239,7 +239,7 @@ def main():
     # HBM traffic per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_collect.sh) — PMC counters cannot be read from inside the run
     traffic = None; pmc_path = None
-    for cand in (f"r2_pmc_gemv_M{min(B, 16)}.json", f"r1_pmc_gemv_M{min(B, 16)}.json"):
+    for cand in (f"r3_pmc_gemv_M{min(B, 16)}.json", f"r2_pmc_gemv_M{min(B, 16)}.json", f"r1_pmc_gemv_M{min(B, 16)}.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             pmc_path = os.path.join(ROOT, "profiles", cand); break
     if args.model == "1.7b" and pmc_path:
@@ -255,7 +255,7 @@ def main():
             traffic = float(np.mean([v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc.values()]))
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": os.path.basename(pmc_path) if (traffic and pmc_path) else None,
-                "kernel": "k_gemv_mfma / k_gemv_mfma4 / k_gemv_lds (bf16-weight MFMA GEMV family, M = batch)",
+                "kernel": "k_gemv_mfma / k_gemv_sk2 / k_gemv_mfma4 / k_gemv_lds (bf16-weight MFMA GEMV family, M = batch)",
                 "timing": "launch inventory from the engine (profiled frames); each shape replayed from a hipGraph over HBM-resident "
                           "weight copies, HIP events on the launch stream, mean of 5 replays x 200 launches",
                 "launches_per_frame": launches, "avg_launch_us": tot_us / launches, "avg_bytes_per_launch": tot_bytes / launches,

@@ -604,6 +604,106 @@ __global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
     Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SwiGLU pair with 24 rows per workgroup (the talker's gate/up: N = 6144 = 384 sixteen-row tiles on 256 CUs).
+//
+// One tile pair per workgroup gives 384 workgroups: half of the CUs get two (2 x 195 KB of weights + x), the others one,
+// and the launch lasts as long as the loaded half (12.6 us in-kernel, per-CU fetch bound: the timeline prices a CU's
+// bytes at ~18 us/MB). Here a workgroup takes ONE AND A HALF tiles of each matrix — 256 workgroups, one per CU, 260 KB
+// each, and the x rows are read once per 24 weight rows instead of once per 16. Workgroup 2j owns tile 3j and rows 0-7 of
+// tile 3j+1, workgroup 2j+1 rows 8-15 of tile 3j+1 and tile 3j+2. No second weight image: in the 16-row tile layout
+// (slot = row + 16 * k-group) the eight rows of a half are the lanes (0-7 | 8-15) + 16*kg — four aligned 128-byte runs,
+// whole L2 lines — so a half tile is fetched with half of the lanes and no wasted byte; its MFMA simply sees zeros in the
+// other eight A-operand rows. 8 waves split K; groups of 4 k-steps; x / norm weight first, weights second; the bf16x3
+// split shared by the four weight operands of a k-step.
+// ------------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
+    Q3_LIN_APPLY(a, a_in);
+    constexpr int NWAVES = 8, G = 4;
+    __shared__ __attribute__((aligned(16))) float red[NWAVES][4][256];        // [wave][gate full, gate half, up full, up half][col m][row]
+    __shared__ float ssq[NWAVES][4][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int pair = blockIdx.x >> 1, odd = blockIdx.x & 1;
+    const int tile_full = 3 * pair + (odd ? 2 : 0), tile_half = 3 * pair + 1;
+    const bool half_lane = ((m >> 3) == odd);                               // this lane's weight row belongs to this workgroup's half of the shared tile
+    const int S = a.Kpad >> 5;
+    const int s0 = (wave * S) / NWAVES, s1 = ((wave + 1) * S) / NWAVES;
+    const u32x4_t* __restrict__ gF = reinterpret_cast<const u32x4_t*>(a.W) + (size_t)tile_full * S * 64 + lane;
+    const u32x4_t* __restrict__ gH = reinterpret_cast<const u32x4_t*>(a.W) + (size_t)tile_half * S * 64 + lane;
+    const u32x4_t* __restrict__ uF = reinterpret_cast<const u32x4_t*>(a.W2) + (size_t)tile_full * S * 64 + lane;
+    const u32x4_t* __restrict__ uH = reinterpret_cast<const u32x4_t*>(a.W2) + (size_t)tile_half * S * 64 + lane;
+    const int xrow = HALF ? (m & 7) : m, xhalf = HALF ? (m >> 3) * 4 : 0;
+    const bool act = HALF ? xrow < a.M : m < a.M;
+    const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
+    const float* __restrict__ nwp = a.norm_w + kg * 8 + xhalf;
+    f32x4_t aGF = {0.f, 0.f, 0.f, 0.f}, aGH = aGF, aUF = aGF, aUH = aGF;
+    float ss = 0.0f;
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    for (int sb = s0; sb < s1; sb += G) {
+        float4 xa[G], xb[G], na[G], nb[G];
+        u32x4_t wgf[G], wgh[G], wuf[G], wuh[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+            const int ko = s * 32;
+            xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!HALF) xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            na[i] = *reinterpret_cast<const float4*>(nwp + ko);
+            if constexpr (!HALF) nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
+            wgf[i] = Q3_WLOAD(gF + (size_t)s * 64); wuf[i] = Q3_WLOAD(uF + (size_t)s * 64);
+            wgh[i] = half_lane ? Q3_WLOAD(gH + (size_t)s * 64) : zero4;
+            wuh[i] = half_lane ? Q3_WLOAD(uH + (size_t)s * 64) : zero4;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Split3 sp[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const bool valid = act && (sb + i) < s1;
+            if constexpr (HALF) { xb[i] = ror8(xa[i]); nb[i] = ror8(na[i]); }
+            sp[i] = gemv_prep<true>(valid, xa[i], xb[i], na[i], nb[i], ss);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            aGF = mfma3(wgf[i], sp[i], aGF); aUF = mfma3(wuf[i], sp[i], aUF);
+            aGH = mfma3(wgh[i], sp[i], aGH); aUH = mfma3(wuh[i], sp[i], aUH);
+        }
+    }
+    zero_job(a.zero, a.zero_n, blockIdx.x, gridDim.x, tid, NWAVES * 64);
+    *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = aGF;
+    *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = aGH;
+    *reinterpret_cast<f32x4_t*>(&red[wave][2][m * 16 + kg * 4]) = aUF;
+    *reinterpret_cast<f32x4_t*>(&red[wave][3][m * 16 + kg * 4]) = aUH;
+    ssq[wave][kg][m] = ss;
+    __syncthreads();
+    // 24 rows x 16 columns: thread (col, r24); rows 0-15 = the full tile, 16-23 = this workgroup's half of the shared tile
+    if (tid < 384) {
+        const int col = tid / 24, r = tid - col * 24;
+        if (col < a.M) {
+            const bool full = r < 16;
+            const int row16 = full ? r : (odd * 8 + (r - 16));          // row inside its 16-row tile
+            const int which = full ? 0 : 1, idx = col * 16 + row16;
+            float g = 0.0f, u = 0.0f, tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) { g += red[w][which][idx]; u += red[w][2 + which][idx]; }
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tot += ssq[w][q][col];
+            const float den = sqrtf(tot / (float)a.K + a.eps);
+            g = g / den; u = u / den;
+            const int n = (full ? tile_full : tile_half) * 16 + row16;
+            if (n < a.N) a.y[(size_t)col * a.ldy + n] = (g / (1.0f + expf(-g))) * u;
+        }
+    }
+}
+
 template <int EPI, bool RMS>
 static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     const int tiles = (a.N + 15) / 16;
@@ -633,6 +733,15 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     if (force == 8) big = false; else if (force == 16) big = true;
     // the two-matrix SwiGLU tile at K = 2048 (talker gate/up, 50 MB): 4 waves — three workgroups fit a CU and the stream
     // keeps more bytes in flight: 14.1 us at M = 8 against 15.9 (8 waves) / 16.5 (16 waves); M = 1: 13.3 / 14.4 / 15.8
+    if constexpr (EPI == EPI_SWIGLU && RMS) {
+        // 24 rows per workgroup where that is what puts one workgroup on every CU (the talker's gate/up: 384 tiles -> 256)
+        static const bool no24 = getenv("Q3_GEMV_NO_GU24") != nullptr;      // A/B aid
+        if (!no24 && force == 0 && tiles % 3 == 0 && tiles / 3 * 2 >= 224 && tiles / 3 * 2 <= 288 && S >= 64 && S % 8 == 0 && a.K == a.Kpad && !a.bias) {
+            if (a.M <= 8) hipLaunchKernelGGL((k_gemv_gu24<true>), dim3(tiles / 3 * 2), dim3(512), 0, st, Q3_LIN_PASS(a));
+            else hipLaunchKernelGGL((k_gemv_gu24<false>), dim3(tiles / 3 * 2), dim3(512), 0, st, Q3_LIN_PASS(a));
+            return hipGetLastError();
+        }
+    }
     const bool four = force == 4 || (force == 0 && EPI == EPI_SWIGLU && S == 64 && tiles >= 256);
     // M <= 8: half-row interleaved x loads (one x instruction per k-step). Q3_GEMV_NO_HALF=1 keeps the two-instruction form (A/B aid).
     static const bool no_half = getenv("Q3_GEMV_NO_HALF") != nullptr;

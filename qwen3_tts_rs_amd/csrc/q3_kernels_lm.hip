@@ -707,11 +707,12 @@ hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
 // the first value is used, so the launch costs one memory round trip (two with the folded gather).
 //   * lane l holds head dims 2l, 2l+1 (one 8-byte load per row and lane, 512-byte rows fully coalesced); the
 //     rotate-half partner d +- 64 is lane l ^ 32.
-//   * the NK partial dot products of a lane are reduced by a TRANSPOSING butterfly: at each of the first log2(NK)
-//     steps a lane hands half of its values to its partner and keeps the other half (17 exchanges instead of 96 for 16
-//     keys); afterwards lane l holds the complete score of key (l * NK) >> 6.
+//   * the NK partial dot products of a lane are reduced by a TRANSPOSING butterfly: across the two row pairs a lane hands half
+//     of its values to lane ^ 32 / ^ 16 (v_permlane32/16_swap) and keeps the other half while more than four are alive, the
+//     last four are summed over their 16-lane row by DPP rotations — VALU latency throughout (the first cut chained 17
+//     ds_bpermute round trips of ~60 ns each); afterwards a lane of row r holds the complete scores of four keys.
 //   * softmax exactly in the reference's form, exp(s - max) / sum with the sum taken in key order (each weight is
-//     broadcast with v_readlane), then sum_p w_p * V[p] in key order.
+//     broadcast with v_readlane from the row that holds it), then sum_p w_p * V[p] in key order.
 // Slot p of the NK key slots is the cached row p for p < pos, the new token (registers, never the just-written
 // memory) for p == pos, and masked beyond. The q-head-0 wave of each kv group appends K / V.
 // ------------------------------------------------------------------------------------------------

@@ -6,7 +6,9 @@ M=${1:-8}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/pmc"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-SHAPES=("talker_qkv 4096 2048 0 1" "talker_o 2048 2048 1 0" "talker_gateup 6144 2048 3 1" "talker_down 2048 6144 1 0" "codec_head 3072 2048 0 0" "cp_qkv 4096 1024 0 1" "cp_o 1024 2048 1 0" "cp_gateup 3072 1024 3 1" "cp_down 1024 3072 1 0" "cp_lm_head 2048 1024 0 1" "cp_mtp_proj 1024 2048 0 0")
+# name N K epilogue fused-norm tiling (-1 = the engine's unsplit choice, 3 = split-K in two: what the frame loop launches for the o / down projections at 3 <= M <= 16)
+SK=-1; if [ "$M" -ge 3 ] && [ "$M" -le 16 ]; then SK=3; fi
+SHAPES=("talker_qkv 4096 2048 0 1 -1" "talker_o 2048 2048 1 0 $SK" "talker_gateup 6144 2048 3 1 -1" "talker_down 2048 6144 1 0 $SK" "codec_head 3072 2048 0 0 -1" "cp_qkv 4096 1024 0 1 -1" "cp_o 1024 2048 1 0 $SK" "cp_gateup 3072 1024 3 1 -1" "cp_down 1024 3072 1 0 $SK" "cp_lm_head 2048 1024 0 1 -1" "cp_mtp_proj 1024 2048 0 0 -1")
 for shape in "${SHAPES[@]}"; do set -- $shape
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/$1_$ctr" -o p -- python "$ROOT/tools/pmc_gemv.py" $@ $M > "$OUT/$1_$ctr.log" 2>&1
