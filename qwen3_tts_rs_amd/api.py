@@ -148,6 +148,7 @@ class Utterance:
     ref_text_ids: Optional[Sequence[int]] = None     # ICL voice clone: reference transcript token ids
     seed: Optional[int] = None                       # overrides options.seed for this sequence
     max_length: Optional[int] = None                 # overrides options.max_length for this sequence (rows of a session end at their own limit)
+    options: Optional["SynthesisOptions"] = None     # this sequence's own sampling options (SynthesisOptions is per call in the reference); default: the session's
 
     def mode(self) -> int:
         if self.instruct_ids is not None:
@@ -193,7 +194,8 @@ class Session:
             if u.ref_text_ids is not None:
                 rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); self._keep.append(rt)
                 r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
-        o = self.options.to_c()
+        o = (u.options or self.options).to_c()
+        o.chunk_frames = self.options.chunk_frames           # the streaming chunk is a property of the session
         if u.seed is not None:
             o.seed = int(u.seed); o.has_seed = 1
         if u.max_length is not None:
@@ -212,7 +214,7 @@ class Session:
         r = CRequest()
         self._fill(r, utt)
         check(lib.q3_session_replace(self._h, int(b), ctypes.byref(r)))
-        self._ref_frames[b] = 0
+        self._ref_frames[b] = 0 if utt.ref_codes is None else int(np.asarray(utt.ref_codes).reshape(-1, 16).shape[0])
 
     def next_chunk_row(self, b: int) -> Tuple[Optional[AudioBuffer], bool]:
         """StreamingSession::next_chunk for row b of a multi-sequence session: (chunk or None, done)."""

@@ -1162,6 +1162,7 @@ struct q3_session {
     q3_options opts{};
     int max_frames = 0, max_seq = 0, prefill_len = 0, n_splits = 1;
     int* limit = nullptr;                 // [B] per-row frame limits on the device (SampleArgs::limit)
+    SampleRow* sample_rows = nullptr;     // [B] per-row sampling options on the device (SampleArgs::rows)
     int row_cap = 0, repl_base = 0;       // text-row slots of replacement rows: slot b = rows repl_base + b*row_cap .. (q3_session_replace)
     LmBuf tb{}, cb{};
     float *LASTH = nullptr, *LOGITS = nullptr, *CP_IN = nullptr, *CP_LOGITS = nullptr;
@@ -1442,19 +1443,30 @@ static q3_status cp_run(q3_session* s) {
     return Q3_OK;
 }
 
+// sampling options of one request -> the sampler's per-row record (sampling.rs:140-319 branch conditions)
+static SampleRow sample_row(const q3_options& o) {
+    SampleRow r{};
+    r.apply_temp = (o.temperature != 1.0 && o.temperature > 0.0) ? 1 : 0;
+    r.inv_temp = (float)(1.0 / o.temperature);
+    r.greedy = o.temperature < 0.01 ? 1 : 0;
+    r.top_k = o.top_k; r.use_top_p = (o.top_p < 1.0 && o.top_p > 0.0) ? 1 : 0; r.top_p = (float)o.top_p;
+    r.use_rep = (o.repetition_penalty != 1.0 && !(fabs(o.repetition_penalty - 1.0) < 1e-9)) ? 1 : 0;
+    r.rep_pen = (float)o.repetition_penalty; r.rep_inv = 1.0f / (float)o.repetition_penalty;
+    r.eos_id = o.eos_token_id; r.min_new_tokens = o.min_new_tokens;
+    return r;
+}
+
 static void fill_sample_args(q3_session* s, SampleArgs& a) {
-    const q3_options& o = s->opts; const q3_config& c = s->m->cfg;
+    const q3_config& c = s->m->cfg;
     memset(&a, 0, sizeof a);
     a.logits = s->LOGITS; a.ld = c.codec_vocab; a.seen = s->seen; a.u = s->U; a.u_stride = s->max_frames + 2; a.limit = s->limit;
     a.draw_idx = s->token_count; a.tok = s->tok; a.token_count = s->token_count; a.frame_idx = s->frame_idx; a.pos = s->pos;
     a.vocab = c.codec_vocab; a.B = s->B;
-    a.apply_temp = (o.temperature != 1.0 && o.temperature > 0.0) ? 1 : 0;
-    a.inv_temp = (float)(1.0 / o.temperature);
-    a.greedy = o.temperature < 0.01 ? 1 : 0;
-    a.top_k = o.top_k; a.use_top_p = (o.top_p < 1.0 && o.top_p > 0.0) ? 1 : 0; a.top_p = (float)o.top_p;
-    a.use_rep = (o.repetition_penalty != 1.0 && !(fabs(o.repetition_penalty - 1.0) < 1e-9)) ? 1 : 0;
-    a.rep_pen = (float)o.repetition_penalty; a.rep_inv = 1.0f / (float)o.repetition_penalty;
-    a.eos_id = o.eos_token_id; a.min_new_tokens = o.min_new_tokens; a.codec_eos = CODEC_EOS; a.use_suppress = 1;
+    const SampleRow r = sample_row(s->opts);          // scalar fields = the first request's (every row reads its own through a.rows)
+    a.apply_temp = r.apply_temp; a.inv_temp = r.inv_temp; a.greedy = r.greedy; a.top_k = r.top_k; a.use_top_p = r.use_top_p; a.top_p = r.top_p;
+    a.use_rep = r.use_rep; a.rep_pen = r.rep_pen; a.rep_inv = r.rep_inv; a.eos_id = r.eos_id; a.min_new_tokens = r.min_new_tokens;
+    a.rows = s->sample_rows;
+    a.codec_eos = CODEC_EOS; a.use_suppress = 1;
     if (s->debug && s->logits_hist) { a.logits_hist = s->logits_hist; a.hist_stride_b = (s->max_frames + 1) * c.codec_vocab; a.hist_cap = s->max_frames + 1; }
 }
 
@@ -1483,12 +1495,6 @@ static q3_status frame_launch(q3_session* s) {
     return Q3_OK;
 }
 
-static bool opts_equal_sampling(const q3_options& a, const q3_options& b) {
-    // max_length may differ from row to row (each row stops at its own limit); everything the captured sampler bakes in must not
-    return a.temperature == b.temperature && a.top_p == b.top_p && a.repetition_penalty == b.repetition_penalty &&
-           a.top_k == b.top_k && a.eos_token_id == b.eos_token_id &&
-           a.min_new_tokens == b.min_new_tokens && a.chunk_frames == b.chunk_frames;
-}
 
 extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out) {
     if (!m || !reqs || !out) return set_err(Q3_INVALID_ARG, "q3_session_create: null argument");
@@ -1504,7 +1510,8 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     for (int b = 0; b < batch; ++b) {
         const q3_request& r = reqs[b];
         const bool icl_req = r.mode == Q3_MODE_VOICE_CLONE && r.n_ref > 0 && r.ref_codes && r.ref_text_ids;
-        if (!icl_req && !opts_equal_sampling(r.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "all requests of a batch must share sampling options (seed may differ)");
+        if (r.opts.chunk_frames != s->opts.chunk_frames) return set_err(Q3_UNSUPPORTED, "all requests of a batch must share chunk_frames (the streaming chunk is a property of the session)");
+        if (!(r.opts.temperature >= 0.0) || r.opts.repetition_penalty <= 0.0) return set_err(Q3_INVALID_ARG, "bad sampling options");
         if (r.mode < 0 || r.mode > 2) return set_err(Q3_INVALID_ARG, "bad mode %d", r.mode);
         if (r.n_text < 0 || r.n_instruct < 0 || (r.n_text > 0 && !r.text_ids) || (r.n_instruct > 0 && !r.instruct_ids))
             return set_err(Q3_INVALID_ARG, "bad token id arrays");
@@ -1537,7 +1544,6 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
             int cap = 6 * r.n_text; if (cap < 75) cap = 75;
             if (q.req.opts.max_length > cap) q.req.opts.max_length = cap;
             if (b == 0) s->opts = q.req.opts;
-            else if (!opts_equal_sampling(q.req.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "ICL sequences of a batch must resolve to the same repetition_penalty");
         }
         const int n_ins = (int)q.instruct.size();
         const int overlay = r.mode == Q3_MODE_VOICE_DESIGN ? 5 : 6;
@@ -1620,10 +1626,12 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     HIPC(s->pool.alloc(&s->cvcache, s->ckv_layer_stride * c.cp_layers));
     HIPC(s->pool.alloc(&s->rows, ((size_t)rows + (size_t)B * s->row_cap) * H));      // + one replacement slot per row (q3_session_replace)
     HIPC(s->pool.alloc(&s->limit, B));
+    HIPC(s->pool.alloc(&s->sample_rows, B));
     {
-        std::vector<int> lim(B);
-        for (int b = 0; b < B; ++b) lim[b] = s->seq[b].limit;
+        std::vector<int> lim(B); std::vector<SampleRow> sr(B);
+        for (int b = 0; b < B; ++b) { lim[b] = s->seq[b].limit; sr[b] = sample_row(s->seq[b].req.opts); }
         HIPC(hipMemcpy(s->limit, lim.data(), B * 4, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(s->sample_rows, sr.data(), B * sizeof(SampleRow), hipMemcpyHostToDevice));
     }
     HIPC(s->pool.alloc(&s->embeds, (size_t)B * s->prefill_len * H));
     HIPC(s->pool.alloc(&s->xvec, (size_t)B * H));
@@ -1974,11 +1982,12 @@ static q3_status refresh_codes(q3_session* s) {
         int n = s->frames_run - q.start_run; bool done = false;      // frames this row has run (rows swapped in later started later)
         if (n > q.limit) n = q.limit;
         if (n < 0) n = 0;
-        if (s->opts.eos_token_id >= 0) {
+        const int eos = q.req.opts.eos_token_id;                     // per row (SampleRow)
+        if (eos >= 0) {
             const int ran = n;
             for (int f = 0; f < ran; ++f)
-                if ((int)s->codes_host[((size_t)b * s->max_frames + f) * 16] == s->opts.eos_token_id) { n = f; done = true; break; }
-            if (!done && ran < q.limit && (int)tok[b] == s->opts.eos_token_id) done = true;     // EOS sampled for the next frame
+                if ((int)s->codes_host[((size_t)b * s->max_frames + f) * 16] == eos) { n = f; done = true; break; }
+            if (!done && ran < q.limit && (int)tok[b] == eos) done = true;     // EOS sampled for the next frame
         }
         if (n >= q.limit) done = true;
         q.n_frames = n; q.done = done;
@@ -2012,7 +2021,8 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "hipStreamEndCapture: %s", hipGetErrorString(e));
         HIPC(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
     }
-    const bool eos_on = s->opts.eos_token_id >= 0;
+    bool eos_on = false;
+    for (const auto& q : s->seq) eos_on = eos_on || q.req.opts.eos_token_id >= 0;
     const int check_every = 32;
     while (todo > 0) {
         const int burst = eos_on ? (todo < check_every ? todo : check_every) : todo;
@@ -2051,15 +2061,17 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     HIPC(hipSetDevice(m->device));
     q3_request r = *req;
-    const int limit = r.opts.max_length;
-    if (limit < 1 || limit > s->max_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: max_length %d outside 1..%d (the session's frame budget)", limit, s->max_frames);
+    const int limit_req = r.opts.max_length;
+    if (limit_req < 1 || limit_req > s->max_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: max_length %d outside 1..%d (the session's frame budget)", limit_req, s->max_frames);
     r.opts.max_length = s->max_frames;                 // the side session draws the row's PCG stream with the host session's stride
-    if (!opts_equal_sampling(r.opts, s->opts)) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request must share the session's sampling options (seed and max_length may differ)");
-    if (r.ref_codes && r.n_ref > 0) return set_err(Q3_UNSUPPORTED, "q3_session_replace: requests with reference codes (ICL) cannot be swapped in");
     q3_session* side_raw = nullptr;
     Q3C(q3_session_create(s->m, &r, 1, &side_raw));
     std::unique_ptr<q3_session> side(side_raw);
     const SeqInfo& sq = side->seq[0];
+    // (sampling options are per row — SampleRow —, resolved by the side session: an ICL request's repetition-penalty floor and
+    // length cap, lib.rs:913-929, come along)
+    if (side->opts.chunk_frames != s->opts.chunk_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: chunk_frames is a property of the session");
+    const int limit = limit_req < sq.limit ? limit_req : sq.limit;
     if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
     if (side->prefill_len + limit + 1 > s->max_seq) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", side->prefill_len, limit, s->max_seq);
     Q3C(q3_session_prefill(side.get()));               // ends with a synchronisation of the side stream
@@ -2078,7 +2090,8 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     HIPC(d2d(s->token_count + b, side->token_count, 4));
     HIPC(d2d(s->pos + b, side->pos, 4));
     HIPC(d2d(s->frame_idx + b, side->frame_idx, 4));
-    HIPC(d2d(s->U + (size_t)b * (s->max_frames + 2), side->U, (size_t)(s->max_frames + 2) * 4));
+    // the row's pre-drawn PCG stream: the side session drew max_frames(side) + 1 >= limit + 1 of them (an ICL cap may make it the shorter one)
+    HIPC(d2d(s->U + (size_t)b * (s->max_frames + 2), side->U, (size_t)((side->max_frames < s->max_frames ? side->max_frames : s->max_frames) + 2) * 4));
     const int row0 = s->repl_base + b * s->row_cap;
     HIPC(d2d(s->rows + (size_t)row0 * H, side->rows, (size_t)sq.n_rows * H * 4));
     const int hv[4] = {row0 + (sq.trail_base - sq.row_base), sq.trailing_len, row0 + (sq.pad_row - sq.row_base), limit};
@@ -2086,6 +2099,8 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     HIPC(hipMemcpyAsync(s->trail_len + b, &hv[1], 4, hipMemcpyHostToDevice, s->stream));
     HIPC(hipMemcpyAsync(s->pad_row + b, &hv[2], 4, hipMemcpyHostToDevice, s->stream));
     HIPC(hipMemcpyAsync(s->limit + b, &hv[3], 4, hipMemcpyHostToDevice, s->stream));
+    const SampleRow srow = sample_row(sq.req.opts);
+    HIPC(hipMemcpyAsync(s->sample_rows + b, &srow, sizeof srow, hipMemcpyHostToDevice, s->stream));
     HIPC(hipStreamSynchronize(s->stream));
     SeqInfo nq = sq;
     nq.row_base = row0; nq.trail_base = hv[0]; nq.pad_row = hv[2];
@@ -2178,15 +2193,15 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
     if (f0 < 0 || f1 < f0 || f1 > s->seq[b].n_frames) return set_err(Q3_INVALID_ARG, "bad frame range [%d,%d) of %d", f0, f1, s->seq[b].n_frames);
     const int T = f1 - f0, spf = samples_per_frame(s->m->cfg);
     const SeqInfo& q = s->seq[b];
-    if (!q.ref_codes.empty() && s->prefilled && s->ref_codes_dev && f0 == 0 && f1 == q.n_frames) {
+    if (!q.ref_codes.empty() && s->prefilled && f0 == 0 && f1 == q.n_frames) {
         // ICL full-utterance decode (lib.rs:1022-1041): decode [ref_frames ; generated], then cut the first
         // ref_len * samples / total_frames samples
         const int n_ref = (int)(q.ref_codes.size() / 16), total = n_ref + T;
         const size_t all = (size_t)total * spf, cut = (size_t)n_ref * all / (size_t)(total > 0 ? total : 1);
         if (n_samples) *n_samples = all - cut;
         Q3C(codec_reserve(s->m, s->cws, total));
-        size_t roff = 0; for (int i = 0; i < b; ++i) roff += s->seq[i].ref_codes.size();
-        HIPC(hipMemcpyAsync(s->cws.frames, s->ref_codes_dev + roff, (size_t)n_ref * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
+        // the row's reference frames from the host copy (a row swapped in by q3_session_replace brings its own)
+        HIPC(hipMemcpyAsync(s->cws.frames, q.ref_codes.data(), (size_t)n_ref * 16 * 4, hipMemcpyHostToDevice, s->stream));
         if (T > 0) HIPC(hipMemcpyAsync(s->cws.frames + (size_t)n_ref * 16, s->codes + (size_t)b * s->max_frames * 16, (size_t)T * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
         Q3C(codec_decode_dev(s->m, s->cws, total, s->stream, nullptr));
         HIPC(hipStreamSynchronize(s->stream));

@@ -207,6 +207,15 @@ struct FrameEmbedArgs {
 };
 hipError_t launch_frame_embed(const FrameEmbedArgs& a, hipStream_t st);
 
+// per-sequence sampling options (SynthesisOptions is per call in the reference, lib.rs:1786-1836): when SampleArgs::rows is
+// set, row b's values replace the scalar fields below, so the sequences of one session — and a row swapped in later — may
+// differ in temperature, top-k / top-p, repetition penalty, EOS id and min_new_tokens while sharing one captured sampler
+struct SampleRow {
+    float inv_temp; int apply_temp; int greedy;
+    int top_k; float top_p; int use_top_p;
+    float rep_pen, rep_inv; int use_rep;
+    int eos_id; int min_new_tokens; int pad;
+};
 struct SampleArgs {
     const float* logits; int ld;     // [B][vocab]
     uint8_t* seen;                   // [B][vocab] or nullptr
@@ -217,6 +226,7 @@ struct SampleArgs {
     int token_count_static;
     int* frame_idx; int* pos;        // advanced by one after sampling when advance != 0
     int advance;
+    const SampleRow* rows;           // per-sequence options (nullable), see SampleRow
     // per-sequence frame limits (nullable): a sequence whose frame_idx has reached limit[b] is FROZEN — its counters
     // (frame_idx, pos, token_count) stop, so it keeps re-running its last position in bounds while the other rows of the
     // session go on (rows end at different frames: own max_length, a row swapped in later — q3_session_replace)

@@ -1139,6 +1139,11 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
     __shared__ int s_keep, s_cut, s_pick;
 
     const int b = blockIdx.x, tid = threadIdx.x, V = a.vocab;
+    if (a.rows) {            // this sequence's own options (SampleRow): a uniform load, the scalar fields of the copy are overwritten
+        const SampleRow r = a.rows[b];
+        a.inv_temp = r.inv_temp; a.apply_temp = r.apply_temp; a.greedy = r.greedy; a.top_k = r.top_k; a.top_p = r.top_p; a.use_top_p = r.use_top_p;
+        a.rep_pen = r.rep_pen; a.rep_inv = r.rep_inv; a.use_rep = r.use_rep; a.eos_id = r.eos_id; a.min_new_tokens = r.min_new_tokens;
+    }
     const float* lg = a.logits + (size_t)b * a.ld;
     uint8_t* seen = a.seen ? a.seen + (size_t)b * V : nullptr;
     const int tc = a.token_count ? a.token_count[b] : a.token_count_static;

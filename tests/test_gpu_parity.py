@@ -994,3 +994,71 @@ def test_streaming_several_rows(pair):
         for b, u in enumerate(utts):
             ref = [c.samples for c in api.StreamingSession(gm, u, opts, continuous=continuous)]
             assert len(ref) == len(got[b]) and all(np.array_equal(x, y) for x, y in zip(ref, got[b])), (continuous, b)
+
+
+@pytest.mark.gpu
+def test_replace_icl_rows(pair):
+    """ICL requests (reference codes + reference text: repetition penalty floored at 1.5, length capped, reference frames
+    prepended and cut at decode) can be swapped into a running session, and so can a plain request afterwards: every row
+    carries its own sampler settings (SampleRow), read by the captured sampler from device memory."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(5)
+    def icl(i, n_ref, n_text, n_ref_text):
+        xv = rng.standard_normal(cfg.hidden).astype(np.float32)
+        ref = rng.integers(0, 2048, size=(n_ref, 16)).astype(np.uint32)
+        return q.Utterance(synthetic_prompt(n_text, i), language=q.Language.French, xvector=xv, ref_codes=ref,
+                           ref_text_ids=synthetic_prompt(n_ref_text, 40 + i), seed=60 + i)
+    a, b, c = icl(0, 4, 5, 3), icl(1, 4, 7, 3), icl(2, 6, 4, 2)
+    a.max_length = 9; b.max_length = 14; c.max_length = 11
+    opts = q.SynthesisOptions(max_length=20, seed=1, eos_token_id=None)
+    s = gm.session([a, b], opts); s.prefill(); s.generate(9, use_graph=True)
+    assert s.frames(0) == (9, True)
+    pcm_a = s.decode(0)
+    s.replace(0, c)                                     # a different prefill length (6 reference frames instead of 4)
+    s.generate(100, use_graph=True)
+    for row, u, pcm_row in ((0, c, None), (1, b, None)):
+        s1 = gm.session([u], opts); s1.prefill(); s1.generate(100, use_graph=False)
+        np.testing.assert_array_equal(s.codes(row), s1.codes(0))
+        np.testing.assert_array_equal(s.decode(row), s1.decode(0))
+        s1.close()
+    s1 = gm.session([a], opts); s1.prefill(); s1.generate(100, use_graph=False)
+    np.testing.assert_array_equal(pcm_a, s1.decode(0)); s1.close()
+    plain = _utts("custom", 5, index=3, hidden=cfg.hidden); plain.max_length = 5     # no ICL penalty floor: its own sampler row
+    s.replace(1, plain); s.generate(100, use_graph=True)
+    s1 = gm.session([plain], opts); s1.prefill(); s1.generate(100, use_graph=False)
+    np.testing.assert_array_equal(s.codes(1), s1.codes(0))
+    np.testing.assert_array_equal(s.decode(1), s1.decode(0)); s1.close()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_rows_with_their_own_sampling_options(pair):
+    """SynthesisOptions is per call in the reference (lib.rs:1786-1836), so requests that share a session may differ in
+    every sampler setting: greedy, temperature / top-k / top-p, repetition penalty, min_new_tokens and the EOS id.  Each
+    row of the mixed batch equals the same request run alone, and equals the oracle with that request's options."""
+    cfg, gm, om = pair
+    base = dict(max_length=12, seed=1)
+    variants = [q.SynthesisOptions(temperature=0.0, eos_token_id=None, **base),                                 # greedy
+                q.SynthesisOptions(temperature=1.3, top_k=5, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, **base),
+                q.SynthesisOptions(temperature=0.7, top_k=0, top_p=0.8, repetition_penalty=1.4, eos_token_id=None, **base),
+                q.SynthesisOptions(min_new_tokens=4, **base),                                                   # default sampler, EOS live
+                q.SynthesisOptions(temperature=0.9, top_k=50, top_p=0.9, repetition_penalty=1.05, eos_token_id=None, **base)]
+    utts = []
+    for i, o in enumerate(variants):
+        u = _utts("custom", 5 + i, index=i, hidden=cfg.hidden); u.seed = 70 + i; u.options = o
+        utts.append(u)
+    host = q.SynthesisOptions(**base)
+    for use_graph in (False, True):
+        s = gm.session(utts, host); s.prefill(); s.generate(100, use_graph=use_graph)
+        for i, u in enumerate(utts):
+            s1 = gm.session([u], u.options); s1.prefill(); s1.generate(100, use_graph=False)
+            np.testing.assert_array_equal(s.codes(i), s1.codes(0))
+            np.testing.assert_array_equal(s.decode(i), s1.decode(0)); s1.close()
+            osess = O.OracleSession(om, u, u.options)
+            np.testing.assert_array_equal(s.codes(i), osess.generate()); osess.close()
+        s.close()
+    # and a request with other options swapped into a finished slot
+    s = gm.session(utts[:2], host); s.prefill(); s.generate(100, use_graph=True)
+    s.replace(0, utts[2]); s.generate(100, use_graph=True)
+    s1 = gm.session([utts[2]], utts[2].options); s1.prefill(); s1.generate(100, use_graph=False)
+    np.testing.assert_array_equal(s.codes(0), s1.codes(0)); s1.close(); s.close()

@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 3, job p: per-kernel breakdown of the B = 64 frame (rocprofv3 kernel trace)
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+bash tools/prof_frame.sh 1.7b 64 60 512 2>&1 | tail -45 | cut -c1-160
+cp gpurun_out/frameprof/frame_1.7b_b64.txt gpurun_out/r5p_frame_b64.txt 2>/dev/null
