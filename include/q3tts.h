@@ -164,8 +164,8 @@ q3_status q3_synth_fill(uint64_t seed, const char* name, int dtype, float scale,
  * as its own batch-1 run. One restriction: the sequences of a batch must have equal PREFILL lengths
  * (same mode and, for voice design / ICL, same instruct / reference lengths — text length is free, it
  * rides along as trailing text); otherwise Q3_UNSUPPORTED. Group requests by prefill shape, one session each.
- * Every request keeps its own q3_options (temperature, top-k / top-p, repetition penalty, min_new_tokens, EOS id, seed,
- * max_length: one sampler row per sequence on the device); only chunk_frames must be the same for all of them. */
+ * Every request keeps its own q3_options — temperature, top-k / top-p, repetition penalty, min_new_tokens, EOS id, seed,
+ * max_length: one sampler row per sequence on the device; only chunk_frames must be the same for all of them. */
 q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out);
 void      q3_session_free(q3_session* s);
 /* prefill_custom_voice / _voice_clone / _voice_design + run_prefill_layers (talker.rs:451-627,
@@ -200,8 +200,8 @@ q3_status q3_session_next_chunk_row(q3_session* s, int b, float* pcm_host, size_
  * done; fetch its codes / PCM first) — by a new request, which then starts at its frame 0 while the other rows go on. The
  * reference keeps all per-utterance state per call (KV caches, SamplingContext, penalty mask, trailing text:
  * lib.rs:743-756; StreamingSession lib.rs:1484-1541); here it is row b's slice of the session's device state, refilled
- * from a one-row prefill of `req`. The request carries its own q3_options (sampler settings, seed, EOS id, max_length:
- * SynthesisOptions is per call in the reference, lib.rs:1786-1836 — only chunk_frames must equal the session's); it must
+ * from a one-row prefill of `req`. The request carries its own q3_options — sampler settings, seed, EOS id, max_length
+ * (SynthesisOptions is per call in the reference, lib.rs:1786-1836; only chunk_frames must equal the session's); it must
  * fit the row (max_length <= the session's largest; text rows <= max(1024, the longest of the original batch); prompt +
  * max_length within the row's KV extent). Any mode fits any session (an ICL request's repetition-penalty floor of 1.5,
  * lib.rs:1154-1160, is resolved into its own row). Each row of a session stops at its own opts.max_length;

@@ -1090,6 +1090,16 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
         float* T2 = other({Y, YA});
         for (int uu = 0; uu < 3; ++uu) {
             const ResUnitW& R = Bk.res[uu];
+            const float* nxt_a = uu < 2 ? Bk.res[uu + 1].a1 : (b < 3 ? m->blk[b + 1].a : m->fin_a);
+            const float* nxt_ib = uu < 2 ? Bk.res[uu + 1].ib1 : (b < 3 ? m->blk[b + 1].ib : m->fin_ib);
+            {   // 96 / 192 channels: the whole unit in one launch (raw tensor updated in place, activated copy into T2)
+                ResUnitArgs r{};
+                r.xa = YA; r.y = Y; r.ya = T2; r.w1pk = m->pk(R.c1w); r.w2pk = m->pk(R.c2w); r.b1 = R.c1b; r.b2 = R.c2b;
+                r.mid_a = R.a2; r.mid_ib = R.ib2; r.post_a = nxt_a; r.post_ib = nxt_ib; r.C = Cc; r.L = L; r.dil = dils[uu];
+                const hipError_t e = launch_resunit(r, st);
+                if (e == hipSuccess) { float* t = YA; YA = T2; T2 = t; continue; }
+                if (e != hipErrorNotSupported) HIPC(e);
+            }
             {   // conv7 (dilated) on the activated input; output activated with act2
                 ConvArgs a; a.x = YA; a.w = R.c1w; a.wpk = m->pk(R.c1w); a.b = R.c1b; a.y = T2; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 7; a.dil = dils[uu];
                 a.post_a = R.a2; a.post_ib = R.ib2;

@@ -256,6 +256,15 @@ struct ConvArgs {
 hipError_t launch_pack_conv_w(const float* w, void* out, int cout, int cin, int K, hipStream_t st);
 size_t packed_conv_w_bytes(int cout, int cin, int K);
 hipError_t launch_conv1d(const ConvArgs& a, hipStream_t st);
+// a whole residual unit (decoder_block.rs:81-92) in one launch: y += conv1x1(snake_mid(conv7_dil(xa) + b1)) + b2, ya = snake_post(y).
+// hipErrorNotSupported (nothing launched) outside 96 / 192 channels with packed weights: the caller runs the two convs.
+struct ResUnitArgs {
+    const float* xa; float* y; float* ya;
+    const void* w1pk; const void* w2pk; const float* b1; const float* b2;
+    const float* mid_a; const float* mid_ib; const float* post_a; const float* post_ib;
+    int C, L, dil;
+};
+hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st);
 // polyphase transposed conv: wp = per-phase causal-conv weights [stride][cout][cin][taps]
 hipError_t launch_transconv1d_taps(const float* x, const float* wp, const float* b, float* y, int cin, int cout, int L,
                                    int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st,

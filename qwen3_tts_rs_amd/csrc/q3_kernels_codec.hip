@@ -590,6 +590,246 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// A whole residual unit in one launch (decoder_block.rs:81-92: x + conv1(snake2(conv7_dil(snake1(x))))) for the layers
+// whose channel range fits one workgroup (96 and 192 channels: 74 % of the decoder's activation bytes).
+// As two launches the unit moves six C x L tensors through HBM (conv7: read act, write mid; 1x1: read mid, read
+// residual, write raw, write act) and the 1x1 runs at 9-21 % MFMA occupancy, bound by exactly that traffic
+// (profiles/r2_pmc_vocoder_mfma_T640.txt). Here the workgroup (C/32 waves, wave = 32 channels x 128 time columns) keeps
+// the conv7 result on chip: bias + SnakeBeta in the accumulators, split into the three bf16 planes, parked in LDS in
+// B-operand order (the x staging area is reused, 64 columns at a time, so the LDS footprint — and the occupancy — stay
+// those of the conv7 kernel), multiplied by the 1x1 weights, residual added from the raw tensor IN PLACE (a column is
+// read and written by the one workgroup that owns it), activated copy for the next consumer written beside it.
+// Four tensors instead of six, one launch instead of two, the x tile staged once for all channels.
+// Arithmetic per output element: exactly the two-launch sequence (same MFMA order, same split, same epilogue
+// expressions) — bit-identical, tested.
+// ------------------------------------------------------------------------------------------------
+struct ResUnitDev {
+    const float* xa;                 // snake1(x) [C][L]: the conv7 operand (written by the producer's epilogue)
+    float* y;                        // raw x [C][L]: residual in, unit output out (in place)
+    float* ya;                       // snake_next(output) [C][L] (must not alias xa: neighbours still read its halo), or nullptr
+    const void* w1pk; const void* w2pk;
+    const float* b1; const float* b2;
+    const float* mid_a; const float* mid_ib;       // SnakeBeta between the two convs
+    const float* post_a; const float* post_ib;     // the next consumer's SnakeBeta
+    int C, L, dil;
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
+    constexpr int K = 7, T_M = 4, NT = 64 * NW, C = 32 * NW, T_WG = 128;
+    constexpr int XPB = 80, NOCT = 4;                             // x staging: 32 channels per stage (as k_conv_bf16x3)
+    constexpr int XP2 = C * 2 + 16;                               // mid rows: all C channels of a column, odd number of 16-byte slots
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // max(x staging [3][W][80], mid [3][64][XP2])
+    __shared__ float s_prm[6][C];                                 // b1, mid_a, mid_ib, b2, post_a, post_ib
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int t0 = (int)blockIdx.x * T_WG;
+    for (int i = tid; i < C; i += NT) {
+        s_prm[0][i] = a.b1 ? a.b1[i] : 0.0f; s_prm[1][i] = a.mid_a[i]; s_prm[2][i] = a.mid_ib[i];
+        s_prm[3][i] = a.b2 ? a.b2[i] : 0.0f;
+        s_prm[4][i] = a.post_a ? a.post_a[i] : 0.0f; s_prm[5][i] = a.post_a ? a.post_ib[i] : 0.0f;
+    }
+    const int halo = (K - 1) * a.dil, W = T_WG + halo;
+    const unsigned plane32 = (unsigned)W * XPB, bfrag = (unsigned)(li * XPB + lk * 16);
+    constexpr int nc16 = C / 16;
+
+    f32x16_t acc[T_M];
+#pragma unroll
+    for (int j = 0; j < T_M; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    auto rsrc = [&](const void* p) {
+        const uint64_t pa = reinterpret_cast<uint64_t>(p);
+        const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)pa);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(pu), 0, 0x7fffffff, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t w1rs = rsrc(a.w1pk), w2rs = rsrc(a.w2pk);
+    auto load_A = [&](cu32x4_t (&A)[3], int ci0, int kk, int c16l) {
+        const int tile = (wave * K + kk) * nc16 + (ci0 >> 4) + c16l;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            A[pl] = __builtin_bit_cast(cu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(w1rs, lane * 16, (tile * 3 + pl) * 1024, 0));
+    };
+    // ---- conv7: the main loop of k_conv_bf16x3<7, 1, 4, NW, 1> ----
+    for (int ci0 = 0; ci0 < C; ci0 += 32) {
+        constexpr int n16 = 2, n_steps = K * n16;
+        cu32x4_t A[2][3];
+        load_A(A[0], ci0, 0, 0);
+        __syncthreads();
+        constexpr int NCHK = (T_WG + (K - 1) * 9 + 63) / 64, NBF = (NOCT * NCHK + NW - 1) / NW;
+        constexpr int NB = NBF < 1 ? 1 : (NBF > 4 ? 4 : NBF);
+        const int n_items = NOCT * ((W + 63) >> 6);
+        for (int c0 = wave; c0 < n_items; c0 += NB * NW) {
+            float v[NB][8];
+            bool ok[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int c = c0 + i * NW;
+                const int q = c % NOCT, tt = (c / NOCT) * 64 + lane;
+                const int ca = ci0 + q * 8, t = t0 - halo + tt;
+                ok[i] = c < n_items && tt < W && t >= 0 && t < a.L;
+                const int tc = t < 0 ? 0 : (t < a.L ? t : a.L - 1);
+                const float* xr = a.xa + (size_t)ca * a.L + tc;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = xr[(size_t)e * a.L];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int c = c0 + i * NW;
+                if (c >= n_items) break;                             // wave-uniform
+                const int q = c % NOCT, tt = (c / NOCT) * 64 + lane;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = ok[i] ? v[i][e] : 0.0f;
+                if (tt < W) {
+                    cu32x4_t h, m, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { uint32_t hh, mm, ll; split3_pair(v[i][2 * e], v[i][2 * e + 1], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+                    unsigned char* row = smem + (unsigned)tt * XPB + q * 16;
+                    *reinterpret_cast<cu32x4_t*>(row) = h;
+                    *reinterpret_cast<cu32x4_t*>(row + plane32) = m;
+                    *reinterpret_cast<cu32x4_t*>(row + 2 * plane32) = l;
+                }
+            }
+        }
+        __syncthreads();
+        auto do_step = [&](const cu32x4_t (&Af)[3], int s) {
+            const int kk = s >> 1, c16l = s & 1;
+            cu32x4_t B[T_M][3];
+            const unsigned so = (unsigned)(kk * a.dil * XPB + c16l * 32);
+            const unsigned char* bp0 = smem + (bfrag + so);
+            const unsigned char* bp1 = smem + (bfrag + so + plane32);
+            const unsigned char* bp2 = smem + (bfrag + so + 2 * plane32);
+#pragma unroll
+            for (int tm = 0; tm < T_M; ++tm) {
+                B[tm][0] = *reinterpret_cast<const cu32x4_t*>(bp0 + tm * (32 * XPB));
+                B[tm][1] = *reinterpret_cast<const cu32x4_t*>(bp1 + tm * (32 * XPB));
+                B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp2 + tm * (32 * XPB));
+            }
+#pragma unroll
+            for (int tm = 0; tm < T_M; ++tm) acc[tm] = mfma6(Af, B[tm], acc[tm]);
+        };
+        auto fetch = [&](cu32x4_t (&Ad)[3], int sp) {
+            sp = sp < n_steps - 1 ? sp : n_steps - 1;
+            __builtin_amdgcn_sched_barrier(0); load_A(Ad, ci0, sp >> 1, sp & 1); __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int st = 0; st < n_steps; st += 2) {                  // 14 steps: pairs of straight-line code, prefetch unconditional
+            fetch(A[1], st + 1); do_step(A[0], st);
+            fetch(A[0], st + 2); do_step(A[1], st + 1);
+        }
+    }
+    // ---- the 1x1 conv over the activated conv7 result, 64 columns (two column tiles) at a time ----
+    auto load_A2 = [&](cu32x4_t (&A)[3], int s) {
+        const int tile = wave * nc16 + s;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            A[pl] = __builtin_bit_cast(cu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (tile * 3 + pl) * 1024, 0));
+    };
+    constexpr unsigned plane2 = 64u * XP2;
+    const unsigned bfrag2 = (unsigned)(li * XP2 + lk * 16);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        cu32x4_t A2[3][3];
+        load_A2(A2[0], 0); load_A2(A2[1], 1);                       // in flight across the barriers and the activation below
+        // the residual of this half: 32 values per lane, requested before anything waits (one batch, see the PRE note above)
+        float rs[2][16];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int o = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+                const int t = t0 + half * 64 + tm * 32 + li;
+                rs[tm][reg] = t < a.L ? a.y[(size_t)o * a.L + t] : 0.0f;
+            }
+        __syncthreads();                                            // every wave is done reading the area (x tiles / previous half)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const f32x16_t& ac = acc[half * 2 + tm];
+            unsigned char* row = smem + (unsigned)(tm * 32 + li) * XP2 + wave * 64 + lk * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pi = wave * 32 + 8 * g + 4 * lk + j;
+                    v[j] = snake_f(ac[4 * g + j] + s_prm[0][pi], s_prm[1][pi], s_prm[2][pi]);
+                }
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split3_pair(v[0], v[1], h0, m0, l0); split3_pair(v[2], v[3], h1, m1, l1);
+                *reinterpret_cast<uint2*>(row + g * 16) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(row + g * 16 + plane2) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(row + g * 16 + 2 * plane2) = make_uint2(l0, l1);
+            }
+        }
+        __syncthreads();
+        f32x16_t acc2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+        auto step2 = [&](const cu32x4_t (&Af)[3], int s) {
+            cu32x4_t B[2][3];
+            const unsigned char* bp = smem + (bfrag2 + (unsigned)s * 32);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                B[tm][0] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2));
+                B[tm][1] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2) + plane2);
+                B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2) + 2 * plane2);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) acc2[tm] = mfma6(Af, B[tm], acc2[tm]);
+        };
+        auto fetch2 = [&](cu32x4_t (&Ad)[3], int sp) {
+            sp = sp < nc16 - 1 ? sp : nc16 - 1;
+            __builtin_amdgcn_sched_barrier(0); load_A2(Ad, sp); __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(nc16 % 3 == 0, "ring of three");
+        for (int s = 0; s < nc16; s += 3) {                          // two steps of prefetch: a step is only 12 MFMAs
+            fetch2(A2[2], s + 2); step2(A2[0], s);
+            fetch2(A2[0], s + 3); step2(A2[1], s + 1);
+            fetch2(A2[1], s + 4); step2(A2[2], s + 2);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int pi = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            const float bias = s_prm[3][pi], pa = s_prm[4][pi], pib = s_prm[5][pi];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int t = t0 + half * 64 + tm * 32 + li;
+                if (t < a.L) {
+                    float v = acc2[tm][reg] + bias;
+                    v = rs[tm][reg] + v;
+                    const size_t oi = (size_t)pi * a.L + t;
+                    a.y[oi] = v;
+                    if (a.ya) a.ya[oi] = a.post_a ? snake_f(v, pa, pib) : v;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st) {
+    static const bool off = getenv("Q3_CONV_F32") != nullptr || getenv("Q3_CODEC_NO_UNIT_FUSE") != nullptr;    // A/B aids
+    // 192 channels = six waves per workgroup: measured 1803 us per unit against 1050 + 414 for the two launches (the conv7
+    // already prefers two 96-channel workgroups over one of 192: 1.32 vs 1.50 ms) — off unless Q3_CODEC_UNIT_FUSE_192=1
+    static const bool fuse192 = getenv("Q3_CODEC_UNIT_FUSE_192") != nullptr;
+    if (off || !r.w1pk || !r.w2pk || (r.C != 96 && !(r.C == 192 && fuse192)) || r.L < 4096 || (r.dil != 1 && r.dil != 3 && r.dil != 9) ||
+        !r.mid_a || !r.xa || !r.y || r.ya == r.xa)
+        return hipErrorNotSupported;
+    ResUnitDev a{};
+    a.xa = r.xa; a.y = r.y; a.ya = r.ya; a.w1pk = r.w1pk; a.w2pk = r.w2pk; a.b1 = r.b1; a.b2 = r.b2;
+    a.mid_a = r.mid_a; a.mid_ib = r.mid_ib; a.post_a = r.post_a; a.post_ib = r.post_ib; a.C = r.C; a.L = r.L; a.dil = r.dil;
+    const int W = 128 + 6 * r.dil;
+    const size_t lds_x = (size_t)3 * W * 80, lds_mid = (size_t)3 * 64 * (r.C * 2 + 16);
+    const size_t lds = lds_x > lds_mid ? lds_x : lds_mid;
+    const dim3 grid((r.L + 127) / 128);
+    if (r.C == 96) hipLaunchKernelGGL(k_resunit_bf16x3<3>, grid, dim3(192), lds, st, a);
+    else hipLaunchKernelGGL(k_resunit_bf16x3<6>, grid, dim3(384), lds, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Short sequences (streaming chunks: the pre-transformer and ConvNeXt linears at L <= 32). The tiled kernel above walks
 // cin in 32 serial stages of (weight round trip, two barriers) with 8-16 workgroups on the chip: 29-52 us for a
 // 10-column product whose 3-6 MB of weights stream in 2 us. Here a workgroup owns one 32-co tile and the single column
@@ -604,10 +844,11 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
     constexpr int NR = 16 / W;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
     const int co32 = blockIdx.x, co0 = co32 * 32;
+    const int tc = (int)blockIdx.y * 32 + li;                       // column tile blockIdx.y (one tile for the streaming chunks)
     const cu32x4_t* __restrict__ wpk = reinterpret_cast<const cu32x4_t*>(a.wpk);
     const float* __restrict__ x = a.x;
     const int nc16 = a.cin >> 4, nseg = a.cin >> 7;
-    const bool tok = li < a.L;
+    const bool tok = tc < a.L;
     float tot[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) tot[j] = 0.0f;
@@ -627,7 +868,7 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ci = seg * 128 + i * 16 + lk * 8 + e;
-                    xv[i][e] = tok ? x[(size_t)ci * a.L + li] : 0.0f;
+                    xv[i][e] = tok ? x[(size_t)ci * a.L + tc] : 0.0f;
                 }
             if (a.snake_a) {
 #pragma unroll
@@ -666,7 +907,7 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
             float v = tot[j] + (a.b ? a.b[o] : 0.0f);
             v = conv_act(v, a.act);
             if (a.scale) v = v * a.scale[o];
-            const size_t oi = (size_t)o * a.oL + (size_t)li * a.ostride + a.ooff;
+            const size_t oi = (size_t)o * a.oL + (size_t)tc * a.ostride + a.ooff;
             if (a.resid) v = a.resid[oi] + v;
             if (a.act == 2) v = fminf(fmaxf(v, -1.0f), 1.0f);
             if (a.post_a) {
@@ -705,6 +946,9 @@ static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) 
             else { if (pre) Q3_CV(CO_M == 1, false, 32); else Q3_CV(false, false, 32); }
         }
 #undef Q3_CV
+    // (64 channels per stage for the two-tap phases of the transposed convs — a 32-channel stage is only four MFMA steps
+    // between two barriers — was measured and lost at every width: 614 -> 645, 791 -> 903, 880 -> 1209, 841 -> 1260 us;
+    // the larger x tile costs the 96-channel geometry its third workgroup per CU)
     } else {
         hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, blk, lds, st, ap);
     }
@@ -736,9 +980,17 @@ static hipError_t launch_conv_bf16x3(const ConvDev& a, int phases, hipStream_t s
     static const bool off = getenv("Q3_CONV_F32") != nullptr;        // A/B aid: force the f32-MFMA generation
     if (off || !a.wpk || a.cin % 16 || a.cout % 32) return hipErrorNotSupported;
     static const bool no_small = getenv("Q3_CONV_NO_SMALL") != nullptr;   // A/B aid
-    if (conv_segmented(a.k, a.cin) && a.L <= 32 && phases == 1 && a.cout % 64 == 0 && !no_small) {
-        if (a.cin >= 1024) hipLaunchKernelGGL(k_lin_small_bf16x3<8>, dim3(a.cout / 32), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL(k_lin_small_bf16x3<4>, dim3(a.cout / 32), dim3(256), 0, st, a);
+    // ... and, since it is the same bits, for the narrow deep linears of a whole utterance too (the pre-transformer's o / down
+    // projections, 1024 -> 512 at 640 frames: 80 workgroups of the tiled kernel walk 8 serial stages, 38.8 us; as 320
+    // one-shot workgroups of 32 x 32 outputs the chip is full once). Only while the grid stays within two rounds —
+    // wider outputs (q|k|v, gate|up, the ConvNeXt linears) are already full grids and gain nothing.
+    static const bool no_small_tiles = getenv("Q3_CONV_NO_SMALL_TILES") != nullptr;   // A/B aid
+    const long small_wgs = (long)(a.cout / 32) * ((a.L + 31) / 32);
+    const bool small_tiles = a.L > 32 && a.cin >= 1024 && small_wgs <= 512 && !no_small_tiles;
+    if (conv_segmented(a.k, a.cin) && (a.L <= 32 || small_tiles) && phases == 1 && a.cout % 64 == 0 && !no_small) {
+        const dim3 grid(a.cout / 32, (a.L + 31) / 32);
+        if (a.cin >= 1024) hipLaunchKernelGGL(k_lin_small_bf16x3<8>, grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(k_lin_small_bf16x3<4>, grid, dim3(256), 0, st, a);
         return hipGetLastError();
     }
     switch (a.k) {

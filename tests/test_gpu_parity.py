@@ -516,6 +516,34 @@ def test_full_size_decoder_stages(T):
 
 
 @pytest.mark.gpu
+def test_fused_residual_unit_is_bit_identical(tmp_path):
+    """96 / 192-channel residual units run as ONE launch (conv7 + SnakeBeta + 1x1 + residual, the intermediate kept in
+    LDS; decoder_block.rs:81-92). Per output element it performs the two-launch arithmetic in the same order, so the PCM
+    must be the same bits as with Q3_CODEC_NO_UNIT_FUSE=1 (another process: the switch is read once). 26 frames: both
+    widths take the fused path, the last time tile of each layer is partial, all three dilations see real history."""
+    import subprocess, sys
+    code = (
+        "import sys, numpy as np, qwen3_tts_rs_amd as q\n"
+        "from qwen3_tts_rs_amd import synth\n"
+        "t = q.tiny()\n"
+        "cfg = q.Q3Config(text_dim=t.text_dim, hidden=t.hidden, inter=t.inter, n_layers=t.n_layers, n_heads=t.n_heads,"
+        " n_kv_heads=t.n_kv_heads, cp_hidden=t.cp_hidden, cp_inter=t.cp_inter, cp_layers=t.cp_layers, cp_heads=t.cp_heads,"
+        " cp_kv_heads=t.cp_kv_heads, name='tiny-lm-full-decoder')\n"
+        "m = q.Qwen3TTS.from_synthetic(cfg, seed=synth.DEFAULT_SEED)\n"
+        "codes = np.random.default_rng(26).integers(0, 2048, size=(26, 16)).astype(np.uint32)\n"
+        "np.save(sys.argv[1], m.decode_codes(codes).samples)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, extra in (("fused.npy", {}), ("split.npy", {"Q3_CODEC_NO_UNIT_FUSE": "1"})):
+        out = str(tmp_path / name)
+        r = subprocess.run([sys.executable, "-c", code, out], cwd=root, env={**os.environ, **extra}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert outs[0].shape == (26 * 1920,) and np.abs(outs[0]).max() > 0.01
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
 def test_weight_arena_broadcast_plumbing(pair):
     """The one data-parallel collective: the weight arena, wrapped without a copy as a torch tensor over
     the library's device pointer, goes through a real RCCL broadcast (world size 1 here — the 8-GPU run is the driver's;

@@ -33,7 +33,7 @@ if frames:
     print(f"per frame ({frames} frames in the segment): {len(seg)/frames:.1f} kernels, {span/frames/1e6:.3f} ms span, {busy/frames/1e6:.3f} ms busy")
 agg = collections.defaultdict(lambda: [0, 0, 0])
 for i, (s, e, name, g, w) in enumerate(seg):
-    short = name.replace("void q3::", "").replace("q3::", "").split("(")[0]
+    short = name.replace("(anonymous namespace)::", "").replace("void q3::", "").replace("q3::", "").replace("void ", "").split("(")[0]
     a = agg[(short, g // max(w, 1), w)]
     a[0] += 1; a[1] += e - s
     if i + 1 < len(seg):

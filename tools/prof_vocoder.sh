@@ -16,7 +16,7 @@ span = seg[-1][1] - seg[0][0]; busy = sum(e - s for s, e, *_ in seg)
 print(f"one decode: {len(seg)} kernels, span {span/1e6:.2f} ms, busy {busy/1e6:.2f} ms")
 agg = collections.OrderedDict()
 for s, e, name, g, w in seg:
-    short = name.replace("void q3::", "").replace("q3::", "").split("(")[0]
+    short = name.replace("(anonymous namespace)::", "").replace("void q3::", "").replace("q3::", "").replace("void ", "").split("(")[0]
     k = (short, g // max(w, 1))
     a = agg.setdefault(k, [0, 0]); a[0] += 1; a[1] += e - s
 print(f"{'kernel':40s} {'WGs':>8s} {'calls':>6s} {'total ms':>9s} {'avg us':>9s} {'%':>6s}")
@@ -25,7 +25,7 @@ for (short, wgs), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
 print("\nlaunch order (launches > 40 us):")
 for i, (s, e, name, g, w) in enumerate(seg):
     if e - s > 40000:
-        short = name.replace("void q3::", "").replace("q3::", "").split("(")[0]
+        short = name.replace("(anonymous namespace)::", "").replace("void q3::", "").replace("q3::", "").replace("void ", "").split("(")[0]
         print(f"{i:4d} {short:60s} {g // max(w, 1):7d} WGs {(e - s)/1e3:9.1f} us  gap {((s - seg[i-1][1]) if i else 0)/1e3:6.1f}")
 PY
 tail -1 "$OUT/run.log"; cat "$OUT/vocoder_T${1:-640}.txt"
