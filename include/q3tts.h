@@ -167,6 +167,12 @@ q3_status q3_synth_fill(uint64_t seed, const char* name, int dtype, float scale,
  * Every request keeps its own q3_options — temperature, top-k / top-p, repetition penalty, min_new_tokens, EOS id, seed,
  * max_length: one sampler row per sequence on the device; only chunk_frames must be the same for all of them. */
 q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out);
+/* The same with capacity for later arrivals (q3_session_replace): code buffers and the pre-drawn PCG streams are sized for
+ * max(frame_budget, the largest max_length of `reqs`) frames per row, the KV extent of a row for
+ * max(prompt_budget, the batch's prefill length) prompt positions + those frames. The rows of `reqs` behave exactly as
+ * under q3_session_create (each ends at its own max_length). No reference counterpart (one utterance per call). */
+q3_status q3_session_create_reserved(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget,
+                                     q3_session** out);
 void      q3_session_free(q3_session* s);
 /* prefill_custom_voice / _voice_clone / _voice_design + run_prefill_layers (talker.rs:451-627,
  * 823-841), build_trailing_text (lib.rs:508-519) and the first sampling decision

@@ -75,6 +75,7 @@ SYMBOLS = {
     "q3_model_finalize": (c_int, [c_void_p]),
     "q3_synth_fill": (c_int, [ctypes.c_uint64, c_char_p, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int64, c_void_p]),
     "q3_session_create": (c_int, [c_void_p, P(CRequest), c_int, P(c_void_p)]),
+    "q3_session_create_reserved": (c_int, [c_void_p, P(CRequest), c_int, c_int, c_int, P(c_void_p)]),
     "q3_session_free": (None, [c_void_p]),
     "q3_session_prefill": (c_int, [c_void_p]),
     "q3_session_generate": (c_int, [c_void_p, c_int, c_int]),

@@ -161,7 +161,11 @@ class Utterance:
 class Session:
     """A batch of utterances on one GPU (q3_session). Owns KV pages, RNG streams, penalty masks."""
 
-    def __init__(self, model: "Qwen3TTS", utts: Sequence[Utterance], options: SynthesisOptions, debug: bool = False):
+    def __init__(self, model: "Qwen3TTS", utts: Sequence[Utterance], options: SynthesisOptions, debug: bool = False,
+                 frame_budget: int = 0, prompt_budget: int = 0):
+        """frame_budget / prompt_budget > 0: capacity (frames per row / prompt positions per row) for requests swapped in
+        later with a larger max_length or a longer prompt (q3_session_create_reserved); the rows of `utts` still end at
+        their own limits."""
         self.model = model
         self.B = len(utts)
         self.options = options
@@ -171,7 +175,10 @@ class Session:
         for i, u in enumerate(utts):
             self._fill(reqs[i], u)
         h = ctypes.c_void_p()
-        check(lib.q3_session_create(model._h, reqs, self.B, ctypes.byref(h)))
+        if frame_budget > 0 or prompt_budget > 0:
+            check(lib.q3_session_create_reserved(model._h, reqs, self.B, int(frame_budget), int(prompt_budget), ctypes.byref(h)))
+        else:
+            check(lib.q3_session_create(model._h, reqs, self.B, ctypes.byref(h)))
         self._h = h
         if debug:
             check(lib.q3_session_set_debug(self._h, 1))
@@ -599,12 +606,11 @@ class Qwen3TTS:
         o = options or SynthesisOptions()
         utts = list(utts)
         n0 = min(slots, len(utts))
-        budget = max((u.max_length if u.max_length is not None else o.max_length) for u in utts)
-        first = [Utterance(**{**u.__dict__}) for u in utts[:n0]]
-        if all((u.max_length if u.max_length is not None else o.max_length) < budget for u in first):
-            first[0].max_length = None          # the session's frame budget is the largest limit of its first batch: make room for later rows
-            o = SynthesisOptions(**{**o.__dict__, "max_length": budget})
-        s = Session(self, first, o)
+        budget = max((u.max_length if u.max_length is not None else (u.options or o).max_length) for u in utts)
+        # capacity for the longest request and the longest prompt, whenever they arrive (prompt positions: instruct + role /
+        # codec overlay rows + ICL reference frames; 16 covers the fixed part of every prompt kind, talker.rs:451-627)
+        prompt = max((0 if u.instruct_ids is None else len(u.instruct_ids)) + (0 if u.ref_codes is None else int(np.asarray(u.ref_codes).reshape(-1, 16).shape[0])) + 16 for u in utts)
+        s = Session(self, utts[:n0], o, frame_budget=budget, prompt_budget=prompt)
         owner = list(range(n0)); nxt = n0
         codes: List[Optional[np.ndarray]] = [None] * len(utts); pcm: List[Optional[np.ndarray]] = [None] * len(utts)
         frames = 0

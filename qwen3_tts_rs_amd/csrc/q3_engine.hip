@@ -1506,7 +1506,15 @@ static q3_status frame_launch(q3_session* s) {
 }
 
 
+static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out);
 extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out) {
+    return session_create(m, reqs, batch, 0, 0, out);
+}
+extern "C" q3_status q3_session_create_reserved(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out) {
+    if (frame_budget < 0 || prompt_budget < 0) return set_err(Q3_INVALID_ARG, "q3_session_create_reserved: budgets must be >= 0");
+    return session_create(m, reqs, batch, frame_budget, prompt_budget, out);
+}
+static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out) {
     if (!m || !reqs || !out) return set_err(Q3_INVALID_ARG, "q3_session_create: null argument");
     if (!m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
     if (batch < 1 || batch > Q3_MAX_BATCH) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..%d sequences per session)", batch, Q3_MAX_BATCH);
@@ -1569,7 +1577,7 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     }
     s->prefill_len = s->seq[0].prefill_len;
     s->n_rows_total = rows;
-    s->max_frames = 1;
+    s->max_frames = frame_budget > 1 ? frame_budget : 1;          // room for rows that arrive later with a larger limit (continuous batching)
     for (auto& q : s->seq) {
         if (q.req.opts.max_length < 1) return set_err(Q3_INVALID_ARG, "max_length must be at least 1");
         q.limit = q.req.opts.max_length; q.start_run = 0;
@@ -1580,7 +1588,7 @@ extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int 
     if (s->row_cap < 1024) s->row_cap = 1024;      // replacement slots hold any text up to ~1000 tokens (8 MB per row at H = 2048), longer if the batch had one
     s->repl_base = rows;
     // KV sized for what the path needs (prefill + frames), not the reference's max_new_tokens+256 (lib.rs:450)
-    s->max_seq = s->prefill_len + s->max_frames + 1;
+    s->max_seq = (prompt_budget > s->prefill_len ? prompt_budget : s->prefill_len) + s->max_frames + 1;   // prompt_budget: later rows with longer prompts
     if (s->max_seq > m->rope_len) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds the RoPE table (%d)", s->max_seq, m->rope_len);
     {
         static const int ns_env = [] { const char* e = getenv("Q3_ATTN_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid

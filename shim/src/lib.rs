@@ -48,6 +48,7 @@ pub mod ffi {
         pub fn q3_session_run(s: *mut c_void, use_graph: i32, pcm: *mut *mut f32, cap: *const usize, n: *mut usize, t: *mut Q3Timing) -> i32;
         pub fn q3_session_next_chunk(s: *mut c_void, pcm: *mut f32, cap: usize, n: *mut usize, done: *mut i32) -> i32;
         pub fn q3_session_next_chunk_row(s: *mut c_void, b: i32, pcm: *mut f32, cap: usize, n: *mut usize, done: *mut i32) -> i32;
+        pub fn q3_session_create_reserved(m: *mut c_void, reqs: *const Q3Request, batch: i32, frame_budget: i32, prompt_budget: i32, out: *mut *mut c_void) -> i32;
         pub fn q3_session_replace(s: *mut c_void, b: i32, req: *const Q3Request) -> i32;
         pub fn q3_session_frames(s: *mut c_void, b: i32, n_frames: *mut i32, done: *mut i32) -> i32;
         pub fn q3_session_codes(s: *mut c_void, b: i32, codes: *mut u32, cap_frames: i32, n_frames: *mut i32) -> i32;

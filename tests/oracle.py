@@ -218,6 +218,8 @@ class OracleSession:
         o = to_ooptions(options)
         if utt.seed is not None:
             o.seed = int(utt.seed); o.has_seed = 1
+        if getattr(utt, "max_length", None) is not None:       # per-request frame limit (Utterance.max_length), as Session._fill
+            o.max_length = int(utt.max_length)
         r.opts = o
         self.h = olib.q3o_session_new(model.h, ctypes.byref(r))
         if not self.h:

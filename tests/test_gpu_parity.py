@@ -1090,3 +1090,44 @@ def test_rows_with_their_own_sampling_options(pair):
     s.replace(0, utts[2]); s.generate(100, use_graph=True)
     s1 = gm.session([utts[2]], utts[2].options); s1.prefill(); s1.generate(100, use_graph=False)
     np.testing.assert_array_equal(s.codes(0), s1.codes(0)); s1.close(); s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_continuous_batching_fuzz(pair, seed):
+    """Random traffic through one three-row session: twelve requests of all four prompt kinds (CustomVoice, VoiceDesign,
+    x-vector clone, ICL clone), random text lengths, frame limits, sampler settings and EOS handling, swapped into whichever
+    row ends first at a random poll interval. Every request must come out with the codes and the PCM of its own batch-1
+    run (the reference keeps all state per call: lib.rs:743-756) — whatever its neighbours were doing."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(1000 + seed)
+    def options():
+        kind = rng.integers(0, 4)
+        eos = None if rng.integers(0, 2) else q.SynthesisOptions().eos_token_id
+        if kind == 0: return q.SynthesisOptions(temperature=0.0, eos_token_id=eos, max_length=16, seed=1)
+        if kind == 1: return q.SynthesisOptions(temperature=1.2, top_k=int(rng.integers(2, 40)), top_p=1.0, eos_token_id=eos, max_length=16, seed=1)
+        if kind == 2: return q.SynthesisOptions(temperature=0.8, top_k=0, top_p=0.85, repetition_penalty=1.3, eos_token_id=eos, max_length=16, seed=1)
+        return q.SynthesisOptions(eos_token_id=eos, min_new_tokens=int(rng.integers(0, 5)), max_length=16, seed=1)
+    def request(i, kind):
+        n_text = int(rng.integers(1, 13))
+        if kind == 3:
+            u = q.Utterance(synthetic_prompt(n_text, i), language=q.Language.French, xvector=rng.standard_normal(cfg.hidden).astype(np.float32),
+                            ref_codes=rng.integers(0, 2048, size=(int(rng.integers(2, 7)), 16)).astype(np.uint32),
+                            ref_text_ids=synthetic_prompt(int(rng.integers(1, 5)), 90 + i))
+        else:
+            u = _utts(("custom", "design", "clone")[kind], n_text, index=i, hidden=cfg.hidden)
+        u.seed = 500 + 17 * i + seed; u.max_length = int(rng.integers(3, 15)); u.options = options()
+        return u
+    utts = [request(i, 0) for i in range(3)] + [request(i, int(rng.integers(0, 4))) for i in range(3, 12)]
+    host = q.SynthesisOptions(max_length=16, seed=1)
+    codes, pcm, frames, _ = gm.synthesize_continuous(utts, host, slots=3, poll_frames=int(rng.choice([1, 3, 8])), use_graph=bool(seed != 1))
+    assert frames == sum(c.shape[0] for c in codes)
+    for i, u in enumerate(utts):
+        s1 = gm.session([u], u.options); s1.prefill(); s1.generate(100, use_graph=False)
+        np.testing.assert_array_equal(codes[i], s1.codes(0), err_msg=f"request {i}")
+        np.testing.assert_array_equal(pcm[i], s1.decode(0), err_msg=f"request {i}")
+        s1.close()
+    if seed == 0:                                                      # and against the oracle, request by request
+        for i, u in enumerate(utts):
+            osess = O.OracleSession(om, u, u.options)
+            np.testing.assert_array_equal(codes[i], osess.generate(), err_msg=f"request {i} vs oracle"); osess.close()
