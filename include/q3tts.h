@@ -213,6 +213,30 @@ q3_status q3_session_next_chunk_row(q3_session* s, int b, float* pcm_host, size_
  * lib.rs:1154-1160, is resolved into its own row). Each row of a session stops at its own opts.max_length;
  * q3_session_generate returns early once every row is done. Other rows are bit-for-bit unaffected. */
 q3_status q3_session_replace(q3_session* s, int b, const q3_request* req);
+/* ---------------- continuous batcher: a queue of requests through the rows of one session ----------------
+ * The serving loop around q3_session_replace, native: requests of any prompt kind, length and options are queued; a step
+ * fills free rows from the queue, runs up to n_frames frames of the shared frame graph and collects the rows that ended.
+ * No thread of its own — the host calls q3_batcher_step from its loop; calls may interleave freely, one thread at a time.
+ * Each request's codes / PCM are those of its own batch-1 run (per-call state of the reference: lib.rs:743-756). No
+ * reference counterpart (one utterance per call). */
+typedef struct q3_batcher q3_batcher;
+enum { Q3_TICKET_QUEUED = 0, Q3_TICKET_RUNNING = 1, Q3_TICKET_DONE = 2, Q3_TICKET_FAILED = 3 };
+/* slots = rows of the session (1..64); frame_budget = largest max_length a request may ask for; prompt_budget = prefill
+ * positions a row can hold (0: those of the first request) — see q3_session_create_reserved */
+q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget, int prompt_budget, q3_batcher** out);
+void      q3_batcher_free(q3_batcher* b);
+/* Queue a request (deep copy: the caller's arrays may go away). want_pcm != 0: the finished row is vocoded
+ * (q3_session_decode, ICL prompts included); else only its codes are kept. */
+q3_status q3_batcher_submit(q3_batcher* b, const q3_request* req, int want_pcm, int64_t* ticket);
+/* One scheduling round. A request that cannot be placed (prompt or text longer than a row holds) fails alone: its ticket
+ * carries the status and message. n_finished counts tickets that reached DONE or FAILED in this call. */
+q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph, int* n_running, int* n_queued, int* n_finished);
+/* state (Q3_TICKET_*); n_frames: frames of a finished ticket, frames run so far of a running one; n_samples: PCM samples held */
+q3_status q3_batcher_poll(q3_batcher* b, int64_t ticket, int* state, int* n_frames, size_t* n_samples);
+/* Copy a finished ticket's results out ([n_frames][16] u32; n_samples f32) and release it. A FAILED ticket returns its
+ * status (message in q3_last_error) and is released too. */
+q3_status q3_batcher_fetch(q3_batcher* b, int64_t ticket, uint32_t* codes_host, int cap_frames, float* pcm_host, size_t cap_samples);
+
 /* Chunk decode mode of q3_session_next_chunk. 0 (default) = each chunk decoded as an independent utterance, exactly
  * as the reference does (lib.rs:1755-1758: audible seams, every chunk restarts from zero padding). 1 = continuous:
  * the vocoder's front runs over all frames so far and its convolutional stack over the chunk plus 12 frames of left

@@ -86,6 +86,12 @@ SYMBOLS = {
     "q3_session_next_chunk": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, P(ctypes.c_size_t), P(c_int)]),
     "q3_session_next_chunk_row": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_size_t, P(ctypes.c_size_t), P(c_int)]),
     "q3_session_replace": (c_int, [c_void_p, c_int, c_void_p]),
+    "q3_batcher_create": (c_int, [c_void_p, c_int, c_int, c_int, P(c_void_p)]),
+    "q3_batcher_free": (None, [c_void_p]),
+    "q3_batcher_submit": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64)]),
+    "q3_batcher_step": (c_int, [c_void_p, c_int, c_int, P(c_int), P(c_int), P(c_int)]),
+    "q3_batcher_poll": (c_int, [c_void_p, ctypes.c_int64, P(c_int), P(c_int), P(ctypes.c_size_t)]),
+    "q3_batcher_fetch": (c_int, [c_void_p, ctypes.c_int64, c_void_p, c_int, c_void_p, ctypes.c_size_t]),
     "q3_session_set_debug": (c_int, [c_void_p, c_int]),
     "q3_session_prefill_len": (c_int, [c_void_p, c_int, P(c_int), P(c_int)]),
     "q3_session_get": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_size_t]),

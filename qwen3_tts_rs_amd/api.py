@@ -158,6 +158,33 @@ class Utterance:
         return 0
 
 
+def fill_request(r, u: "Utterance", options: "SynthesisOptions", keep: list):
+    """q3_request of one utterance; the arrays it points to are appended to `keep` (the caller keeps them alive)"""
+    r.mode = u.mode()
+    t = np.ascontiguousarray(u.text_ids, dtype=np.uint32); keep.append(t)
+    r.text_ids = t.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_text = len(t)
+    if u.instruct_ids is not None:
+        ins = np.ascontiguousarray(u.instruct_ids, dtype=np.uint32); keep.append(ins)
+        r.instruct_ids = ins.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_instruct = len(ins)
+    r.speaker_id = u.speaker.token_id(); r.language_id = u.language.token_id()
+    if u.xvector is not None:
+        xv = np.ascontiguousarray(u.xvector, dtype=np.float32); keep.append(xv)
+        r.xvector = xv.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    if u.ref_codes is not None:          # prepended at decode even without a transcript (lib.rs:1022); ICL needs both
+        rc = np.ascontiguousarray(u.ref_codes, dtype=np.uint32).reshape(-1, 16); keep.append(rc)
+        r.ref_codes = rc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref = rc.shape[0]
+        if u.ref_text_ids is not None:
+            rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); keep.append(rt)
+            r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
+    o = (u.options or options).to_c()
+    o.chunk_frames = options.chunk_frames           # the streaming chunk is a property of the session
+    if u.seed is not None:
+        o.seed = int(u.seed); o.has_seed = 1
+    if u.max_length is not None:
+        o.max_length = int(u.max_length)
+    r.opts = o
+
+
 class Session:
     """A batch of utterances on one GPU (q3_session). Owns KV pages, RNG streams, penalty masks."""
 
@@ -184,30 +211,7 @@ class Session:
             check(lib.q3_session_set_debug(self._h, 1))
 
     def _fill(self, r, u: Utterance):
-        """q3_request of one utterance (the arrays it points to are kept alive by the session)"""
-        r.mode = u.mode()
-        t = np.ascontiguousarray(u.text_ids, dtype=np.uint32); self._keep.append(t)
-        r.text_ids = t.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_text = len(t)
-        if u.instruct_ids is not None:
-            ins = np.ascontiguousarray(u.instruct_ids, dtype=np.uint32); self._keep.append(ins)
-            r.instruct_ids = ins.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_instruct = len(ins)
-        r.speaker_id = u.speaker.token_id(); r.language_id = u.language.token_id()
-        if u.xvector is not None:
-            xv = np.ascontiguousarray(u.xvector, dtype=np.float32); self._keep.append(xv)
-            r.xvector = xv.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-        if u.ref_codes is not None:          # prepended at decode even without a transcript (lib.rs:1022); ICL needs both
-            rc = np.ascontiguousarray(u.ref_codes, dtype=np.uint32).reshape(-1, 16); self._keep.append(rc)
-            r.ref_codes = rc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref = rc.shape[0]
-            if u.ref_text_ids is not None:
-                rt = np.ascontiguousarray(u.ref_text_ids, dtype=np.uint32); self._keep.append(rt)
-                r.ref_text_ids = rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)); r.n_ref_text = len(rt)
-        o = (u.options or self.options).to_c()
-        o.chunk_frames = self.options.chunk_frames           # the streaming chunk is a property of the session
-        if u.seed is not None:
-            o.seed = int(u.seed); o.has_seed = 1
-        if u.max_length is not None:
-            o.max_length = int(u.max_length)
-        r.opts = o
+        fill_request(r, u, self.options, self._keep)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -326,6 +330,63 @@ class Session:
         w = ctypes.c_double(); k = ctypes.c_double()
         check(lib.q3_session_frame_bytes(self._h, kv_len, ctypes.byref(w), ctypes.byref(k)))
         return w.value, k.value
+
+
+class Batcher:
+    """Continuous batcher (q3_batcher): requests of any prompt kind, length and options queue up and run through the rows of
+    one session; `step` fills free rows, runs a few frames of the shared frame graph and collects finished rows. The
+    scheduling loop is native — this class only marshals requests and results."""
+    QUEUED, RUNNING, DONE, FAILED = 0, 1, 2, 3
+
+    def __init__(self, model: "Qwen3TTS", slots: int = 8, frame_budget: int = 2048, prompt_budget: int = 0,
+                 options: Optional[SynthesisOptions] = None):
+        self.model = model
+        self.options = options or SynthesisOptions()
+        h = ctypes.c_void_p()
+        check(lib.q3_batcher_create(model._h, int(slots), int(frame_budget), int(prompt_budget), ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.q3_batcher_free(self._h); self._h = None
+
+    __del__ = close
+
+    def submit(self, utt: Utterance, want_pcm: bool = True) -> int:
+        """Queue one request; returns its ticket. The request is copied by the library."""
+        keep = []                                   # alive until the call returns: the library copies the request
+        r = CRequest(); fill_request(r, utt, self.options, keep)
+        t = ctypes.c_int64()
+        check(lib.q3_batcher_submit(self._h, ctypes.byref(r), 1 if want_pcm else 0, ctypes.byref(t)))
+        return int(t.value)
+
+    def step(self, n_frames: int = 32, use_graph: bool = True) -> Tuple[int, int, int]:
+        """One scheduling round: (rows running, requests queued, tickets finished in this call)."""
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib.q3_batcher_step(self._h, int(n_frames), 1 if use_graph else 0, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def poll(self, ticket: int) -> Tuple[int, int, int]:
+        st, n, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+        check(lib.q3_batcher_poll(self._h, int(ticket), ctypes.byref(st), ctypes.byref(n), ctypes.byref(ns)))
+        return st.value, n.value, ns.value
+
+    def fetch(self, ticket: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """(codes [n][16] u32, PCM or None) of a finished ticket, which is released; a failed ticket raises its error."""
+        st, n, ns = self.poll(ticket)
+        codes = np.zeros((n, 16), np.uint32); pcm = np.zeros(ns, np.float32)
+        check(lib.q3_batcher_fetch(self._h, int(ticket), codes.ctypes.data_as(ctypes.c_void_p), n,
+                                   pcm.ctypes.data_as(ctypes.c_void_p) if ns else None, ns))
+        return codes, (pcm if ns else None)
+
+    def run_all(self, utts: Sequence[Utterance], want_pcm: bool = True, poll_frames: int = 32, use_graph: bool = True):
+        """Submit everything, step until the queue is drained; results in request order (a failed request raises)."""
+        tickets = [self.submit(u, want_pcm) for u in utts]
+        while True:
+            running, queued, _ = self.step(poll_frames, use_graph)
+            if running == 0 and queued == 0:
+                break
+        return [self.fetch(t) for t in tickets]
 
 
 class StreamingSession:
@@ -599,9 +660,11 @@ class Qwen3TTS:
                               decode: bool = True, use_graph: bool = True):
         """Continuous batching over ONE session of `slots` rows: the first `slots` requests start together; whenever a row ends
         (EOS, or its own max_length) its codes are collected and the next waiting request is swapped into the row
-        (q3_session_replace) while the other rows keep running — no row idles until the slowest one is done. All requests
-        must share one prefill shape for the initial batch (a server groups them, as synthesize_batch does). Returns
-        (codes per request, PCM per request or None, frames generated, wall seconds of the generation loop)."""
+        (q3_session_replace) while the other rows keep running — no row idles until the slowest one is done. The requests
+        may be of any prompt kind and length: when the first `slots` of them do not share one prefill shape the session is
+        opened on copies of the first request and the others are swapped in before the first frame (each prefilled on the
+        side, as later arrivals are). Returns (codes per request, PCM per request or None, frames generated, wall seconds
+        of the generation loop)."""
         import time as _time
         o = options or SynthesisOptions()
         utts = list(utts)
@@ -610,13 +673,17 @@ class Qwen3TTS:
         # capacity for the longest request and the longest prompt, whenever they arrive (prompt positions: instruct + role /
         # codec overlay rows + ICL reference frames; 16 covers the fixed part of every prompt kind, talker.rs:451-627)
         prompt = max((0 if u.instruct_ids is None else len(u.instruct_ids)) + (0 if u.ref_codes is None else int(np.asarray(u.ref_codes).reshape(-1, 16).shape[0])) + 16 for u in utts)
-        s = Session(self, utts[:n0], o, frame_budget=budget, prompt_budget=prompt)
+        mixed = len({self.prefill_shape(u) for u in utts[:n0]}) > 1
+        s = Session(self, [utts[0]] * n0 if mixed else utts[:n0], o, frame_budget=budget, prompt_budget=prompt)
         owner = list(range(n0)); nxt = n0
         codes: List[Optional[np.ndarray]] = [None] * len(utts); pcm: List[Optional[np.ndarray]] = [None] * len(utts)
         frames = 0
         t0 = _time.perf_counter()
         try:
             s.prefill()
+            if mixed:
+                for b in range(1, n0):
+                    s.replace(b, utts[b])
             while any(i is not None for i in owner):
                 s.generate(poll_frames, use_graph=use_graph)
                 for b in range(n0):

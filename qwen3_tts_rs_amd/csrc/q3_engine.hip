@@ -870,6 +870,11 @@ static inline void dev_free(void* p) { dev_cache().put(p); }
 
 struct DevPool {
     std::vector<void*> ptrs;
+    // lazy: the zero-fills of a run of allocations are only ISSUED (null stream, in order with the synchronous hipMemcpy
+    // uploads that may follow) and settle() waits for all of them once — a session is ~45 buffers, and a memset + a device
+    // synchronisation each was 2-3 ms of every q3_session_create (the side session of a continuous-batching swap)
+    bool lazy = false;
+    hipError_t settle() { return hipStreamSynchronize(nullptr); }
     template <typename T> hipError_t alloc(T** p, size_t count) {
         void* q = nullptr;
         hipError_t e = dev_malloc(&q, (count ? count : 1) * sizeof(T));
@@ -880,7 +885,7 @@ struct DevPool {
         // blocks started coming from the cache instead of a slow hipMalloc)
         hipError_t m = hipMemsetAsync(q, 0, (count ? count : 1) * sizeof(T), nullptr);
         if (m != hipSuccess) return m;
-        return hipStreamSynchronize(nullptr);
+        return lazy ? hipSuccess : hipStreamSynchronize(nullptr);
     }
     ~DevPool() { for (void* p : ptrs) dev_free(p); }
 };
@@ -1166,7 +1171,7 @@ struct ProfShape { int M, N, K, epi, rms, produce, tiled, count; };
 
 struct q3_session {
     q3_model* m = nullptr; int B = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; bool owns_stream = true;     // the side session of a swap borrows its host's stream
     DevPool pool;
     std::vector<SeqInfo> seq;
     q3_options opts{};
@@ -1506,7 +1511,8 @@ static q3_status frame_launch(q3_session* s) {
 }
 
 
-static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out);
+static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out,
+                                hipStream_t borrow = nullptr);
 extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out) {
     return session_create(m, reqs, batch, 0, 0, out);
 }
@@ -1514,7 +1520,8 @@ extern "C" q3_status q3_session_create_reserved(q3_model* m, const q3_request* r
     if (frame_budget < 0 || prompt_budget < 0) return set_err(Q3_INVALID_ARG, "q3_session_create_reserved: budgets must be >= 0");
     return session_create(m, reqs, batch, frame_budget, prompt_budget, out);
 }
-static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out) {
+static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out,
+                                hipStream_t borrow) {
     if (!m || !reqs || !out) return set_err(Q3_INVALID_ARG, "q3_session_create: null argument");
     if (!m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
     if (batch < 1 || batch > Q3_MAX_BATCH) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..%d sequences per session)", batch, Q3_MAX_BATCH);
@@ -1604,11 +1611,15 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
     }
     {   // the frame loop is a chain of ~600 short dependent kernels per frame: give its queue the highest priority so
         // that its workgroups are dispatched ahead of the vocoder segments running beside it (q3_session_run)
-        int least = 0, greatest = 0;
-        HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPC(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
+        if (borrow) { s->stream = borrow; s->owns_stream = false; }      // q3_session_replace: no second queue for a one-row prefill
+        else {
+            int least = 0, greatest = 0;
+            HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPC(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
+        }
     }
     const int B = batch, H = c.hidden, CH = c.cp_hidden;
+    s->pool.lazy = true;
     auto alloc_lm = [&](LmBuf& b, const LmDims& d, int nsplit) -> hipError_t {
         const int QD = d.nh * HEAD_DIM, KD = d.nkv * HEAD_DIM;
         const size_t R = batch > 16 ? (size_t)up16(batch) : 16;     // rows: up to 16 for multi-row steps (B <= 16), else one row per sequence
@@ -1671,6 +1682,8 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
         for (int i = 0; i <= s->max_frames; ++i) U[(size_t)b * (s->max_frames + 2) + i] = q3_rng_next(&st);
     }
     HIPC(hipMemcpy(s->U, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+    HIPC(s->pool.settle());                 // every zero-fill has landed before a kernel on the session's own stream can run
+    s->pool.lazy = false;
     *out = s.release();
     return Q3_OK;
 }
@@ -1693,7 +1706,7 @@ q3_session::~q3_session() {
     if (pcm_all) dev_free(pcm_all);
     if (dec_ev) (void)hipEventDestroy(dec_ev);
     if (dec_stream) (void)hipStreamDestroy(dec_stream);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && owns_stream) (void)hipStreamDestroy(stream);
 }
 
 extern "C" void q3_session_free(q3_session* s) { delete s; }
@@ -2082,9 +2095,15 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     const int limit_req = r.opts.max_length;
     if (limit_req < 1 || limit_req > s->max_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: max_length %d outside 1..%d (the session's frame budget)", limit_req, s->max_frames);
     r.opts.max_length = s->max_frames;                 // the side session draws the row's PCG stream with the host session's stride
+    static const bool timing = getenv("Q3_REPLACE_TIMING") != nullptr;      // development aid: where a swap's milliseconds go
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[q3 replace] %-8s %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+    };
     q3_session* side_raw = nullptr;
-    Q3C(q3_session_create(s->m, &r, 1, &side_raw));
+    Q3C(session_create(s->m, &r, 1, 0, 0, &side_raw, s->stream));      // on the host's stream: its frames and this prefill are serial anyway
     std::unique_ptr<q3_session> side(side_raw);
+    lap("create");
     const SeqInfo& sq = side->seq[0];
     // (sampling options are per row — SampleRow —, resolved by the side session: an ICL request's repetition-penalty floor and
     // length cap, lib.rs:913-929, come along)
@@ -2093,6 +2112,7 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
     if (side->prefill_len + limit + 1 > s->max_seq) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", side->prefill_len, limit, s->max_seq);
     Q3C(q3_session_prefill(side.get()));               // ends with a synchronisation of the side stream
+    lap("prefill");
     HIPC(hipStreamSynchronize(s->stream));             // no frame of the host session in flight while its row changes
     const int H = c.hidden, S = side->prefill_len, nkv = c.n_kv_heads;
     const size_t row_bytes = (size_t)HEAD_DIM * 4;
@@ -2125,12 +2145,209 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     nq.start_run = s->frames_run; nq.limit = limit; nq.n_frames = 0; nq.done = false; nq.stream_pos = 0; nq.req.opts.max_length = limit;
     s->seq[b] = nq;
     s->codes_host_valid = false;
+    lap("copies");
+    side.reset();
+    lap("free");
     return Q3_OK;
 }
 
 // Streaming with several sequences in one session: the next chunk of row b (StreamingSession::next_chunk, lib.rs:1650-1759,
 // one per row). Rows advance in lockstep, so asking row after row costs the frames once: the first call generates them for
 // every row, the others find theirs buffered and only run their vocoder. One row: q3_session_next_chunk (with read-ahead).
+// ------------------------------------------------------------------------------------------------
+// Continuous batcher: a queue of requests through the rows of ONE session (the native form of what a serving loop does
+// with q3_session_replace). No thread of its own: the host calls q3_batcher_step from its loop — submit / step / poll /
+// fetch may interleave freely (one thread at a time). A step fills free rows from the queue (one-row side prefill + state
+// copy, rows of any prompt kind), runs up to n_frames frames of the shared frame graph, and collects the rows that ended
+// (codes, and the PCM if the request asked for it). Every request gets the bits of its own batch-1 run.
+// ------------------------------------------------------------------------------------------------
+struct BatReq {
+    q3_request r{}; std::vector<uint32_t> text, instruct, ref_codes, ref_text; std::vector<float> xvec;
+    void own(const q3_request& q, int hidden) {
+        r = q;
+        text.assign(q.text_ids, q.text_ids + (q.text_ids ? q.n_text : 0));
+        instruct.assign(q.instruct_ids, q.instruct_ids + (q.instruct_ids ? q.n_instruct : 0));
+        ref_codes.assign(q.ref_codes, q.ref_codes + (q.ref_codes ? (size_t)q.n_ref * 16 : 0));
+        ref_text.assign(q.ref_text_ids, q.ref_text_ids + (q.ref_text_ids ? q.n_ref_text : 0));
+        if (q.xvector) xvec.assign(q.xvector, q.xvector + hidden);
+        fix();
+    }
+    void fix() {      // pointers into this object's own storage (after a move of the object)
+        r.text_ids = text.empty() ? nullptr : text.data(); r.n_text = (int32_t)text.size();
+        r.instruct_ids = instruct.empty() ? nullptr : instruct.data(); r.n_instruct = (int32_t)instruct.size();
+        r.ref_codes = ref_codes.empty() ? nullptr : ref_codes.data(); r.n_ref = (int32_t)(ref_codes.size() / 16);
+        r.ref_text_ids = ref_text.empty() ? nullptr : ref_text.data(); r.n_ref_text = (int32_t)ref_text.size();
+        r.xvector = xvec.empty() ? nullptr : xvec.data();
+    }
+};
+struct BatTicket {
+    BatReq req; int state = Q3_TICKET_QUEUED; int row = -1; bool want_pcm = false;
+    std::vector<uint32_t> codes; std::vector<float> pcm; int n_frames = 0;
+    q3_status st = Q3_OK; std::string err;
+};
+struct q3_batcher {
+    q3_model* m = nullptr; int slots = 0, frame_budget = 0, prompt_budget = 0, chunk_frames = 0;
+    q3_session* s = nullptr;
+    std::vector<int64_t> owner;                       // ticket running in each row, -1 = free
+    std::vector<int64_t> queue;                       // FIFO of waiting tickets
+    std::unordered_map<int64_t, std::unique_ptr<BatTicket>> t;
+    int64_t next_id = 1;
+};
+
+// a row that has nothing to do: frozen on the device from its current frame on (rows of a freshly opened session that no
+// request occupies yet)
+static q3_status session_idle_row(q3_session* s, int b) {
+    SeqInfo& q = s->seq[b];
+    int ran = s->frames_run - q.start_run; if (ran < 0) ran = 0; if (ran > q.limit) ran = q.limit;
+    q.limit = ran;
+    HIPC(hipMemcpy(s->limit + b, &q.limit, sizeof(int), hipMemcpyHostToDevice));
+    s->codes_host_valid = false;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget, int prompt_budget, q3_batcher** out) {
+    if (!m || !out) return set_err(Q3_INVALID_ARG, "q3_batcher_create: null argument");
+    if (!m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
+    if (slots < 1 || slots > Q3_MAX_BATCH) return set_err(Q3_UNSUPPORTED, "q3_batcher_create: %d rows unsupported (1..%d)", slots, Q3_MAX_BATCH);
+    if (frame_budget < 1 || prompt_budget < 0) return set_err(Q3_INVALID_ARG, "q3_batcher_create: frame_budget must be >= 1, prompt_budget >= 0");
+    std::unique_ptr<q3_batcher> b(new q3_batcher());
+    b->m = m; b->slots = slots; b->frame_budget = frame_budget; b->prompt_budget = prompt_budget;
+    b->owner.assign(slots, -1);
+    *out = b.release();
+    return Q3_OK;
+}
+extern "C" void q3_batcher_free(q3_batcher* b) {
+    if (!b) return;
+    if (b->s) q3_session_free(b->s);
+    delete b;
+}
+extern "C" q3_status q3_batcher_submit(q3_batcher* b, const q3_request* req, int want_pcm, int64_t* ticket) {
+    if (!b || !req || !ticket) return set_err(Q3_INVALID_ARG, "q3_batcher_submit: null argument");
+    if (req->opts.max_length < 1 || req->opts.max_length > b->frame_budget)
+        return set_err(Q3_UNSUPPORTED, "q3_batcher_submit: max_length %d outside 1..%d (the batcher's frame budget)", req->opts.max_length, b->frame_budget);
+    if (req->n_text < 0 || req->n_instruct < 0 || req->n_ref < 0 || req->n_ref_text < 0) return set_err(Q3_INVALID_ARG, "q3_batcher_submit: negative length");
+    std::unique_ptr<BatTicket> t(new BatTicket());
+    t->req.own(*req, b->m->cfg.hidden); t->want_pcm = want_pcm != 0;
+    const int64_t id = b->next_id++;
+    b->t[id] = std::move(t);
+    b->queue.push_back(id);
+    *ticket = id;
+    return Q3_OK;
+}
+
+static void bat_fail(BatTicket& t, q3_status st) { t.state = Q3_TICKET_FAILED; t.st = st; t.err = q3_last_error(); t.row = -1; }
+
+// the row's sequence has ended: keep its codes (and PCM), free the row
+static q3_status bat_collect(q3_batcher* b, int row) {
+    BatTicket& t = *b->t[b->owner[row]];
+    int n = 0;
+    Q3C(q3_session_codes(b->s, row, nullptr, 0, &n));
+    t.codes.resize((size_t)n * 16); t.n_frames = n;
+    if (n > 0) Q3C(q3_session_codes(b->s, row, t.codes.data(), n, &n));
+    if (t.want_pcm && n > 0) {
+        size_t ns = 0;
+        t.pcm.resize((size_t)n * samples_per_frame(b->m->cfg));
+        Q3C(q3_session_decode(b->s, row, 0, n, t.pcm.data(), t.pcm.size(), &ns));
+        t.pcm.resize(ns);
+    }
+    t.state = Q3_TICKET_DONE; t.row = -1;
+    b->owner[row] = -1;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph, int* n_running, int* n_queued, int* n_finished) {
+    if (!b) return set_err(Q3_INVALID_ARG, "q3_batcher_step: null batcher");
+    if (n_frames < 1) return set_err(Q3_INVALID_ARG, "q3_batcher_step: n_frames must be >= 1");
+    int finished = 0;
+    size_t qpos = 0;
+    // open the session on the first request that fits (it takes row 0; the other rows start idle): `slots` copies share one
+    // prefill shape by construction, whatever the queue holds
+    while (!b->s && qpos < b->queue.size()) {
+        const int64_t id = b->queue[qpos++];
+        BatTicket& t = *b->t[id];
+        b->chunk_frames = t.req.r.opts.chunk_frames;
+        std::vector<q3_request> reqs((size_t)b->slots, t.req.r);
+        q3_session* s = nullptr;
+        q3_status st = q3_session_create_reserved(b->m, reqs.data(), b->slots, b->frame_budget, b->prompt_budget, &s);
+        if (st == Q3_OK) st = q3_session_prefill(s);
+        if (st != Q3_OK) { if (s) q3_session_free(s); bat_fail(t, st); finished++; continue; }
+        b->s = s;
+        for (int r = 1; r < b->slots; ++r) Q3C(session_idle_row(s, r));
+        t.state = Q3_TICKET_RUNNING; t.row = 0; b->owner[0] = id;
+    }
+    b->queue.erase(b->queue.begin(), b->queue.begin() + (long)qpos);
+    if (!b->s) { if (n_running) *n_running = 0; if (n_queued) *n_queued = 0; if (n_finished) *n_finished = finished; return Q3_OK; }
+    auto fill = [&]() -> q3_status {               // free rows <- waiting requests
+        for (int r = 0; r < b->slots && !b->queue.empty(); ++r) {
+            if (b->owner[r] >= 0) continue;
+            while (!b->queue.empty()) {
+                const int64_t id = b->queue.front(); b->queue.erase(b->queue.begin());
+                BatTicket& t = *b->t[id];
+                t.req.r.opts.chunk_frames = b->chunk_frames;        // the one option a session shares
+                const q3_status st = q3_session_replace(b->s, r, &t.req.r);
+                if (st != Q3_OK) { bat_fail(t, st); finished++; continue; }     // does not fit: the ticket carries the reason; try the next one
+                t.state = Q3_TICKET_RUNNING; t.row = r; b->owner[r] = id;
+                break;
+            }
+        }
+        return Q3_OK;
+    };
+    Q3C(fill());
+    Q3C(q3_session_generate(b->s, n_frames, use_graph));
+    for (int r = 0; r < b->slots; ++r) {
+        if (b->owner[r] < 0) continue;
+        int n = 0, done = 0;
+        Q3C(q3_session_frames(b->s, r, &n, &done));
+        if (done) { Q3C(bat_collect(b, r)); finished++; }
+    }
+    Q3C(fill());                                   // the next step starts with full rows
+    int running = 0;
+    for (int r = 0; r < b->slots; ++r) running += b->owner[r] >= 0 ? 1 : 0;
+    if (n_running) *n_running = running;
+    if (n_queued) *n_queued = (int)b->queue.size();
+    if (n_finished) *n_finished = finished;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_batcher_poll(q3_batcher* b, int64_t ticket, int* state, int* n_frames, size_t* n_samples) {
+    if (!b) return set_err(Q3_INVALID_ARG, "q3_batcher_poll: null batcher");
+    auto it = b->t.find(ticket);
+    if (it == b->t.end()) return set_err(Q3_INVALID_ARG, "q3_batcher_poll: unknown ticket %lld", (long long)ticket);
+    const BatTicket& t = *it->second;
+    if (state) *state = t.state;
+    int nf = t.n_frames;
+    if (t.state == Q3_TICKET_RUNNING && b->s && t.row >= 0) {       // frames run so far (an EOS inside them is only looked at when the row is collected)
+        const SeqInfo& q = b->s->seq[t.row];
+        nf = b->s->frames_run - q.start_run; if (nf > q.limit) nf = q.limit; if (nf < 0) nf = 0;
+    }
+    if (n_frames) *n_frames = nf;
+    if (n_samples) *n_samples = t.pcm.size();
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_batcher_fetch(q3_batcher* b, int64_t ticket, uint32_t* codes_host, int cap_frames, float* pcm_host, size_t cap_samples) {
+    if (!b) return set_err(Q3_INVALID_ARG, "q3_batcher_fetch: null batcher");
+    auto it = b->t.find(ticket);
+    if (it == b->t.end()) return set_err(Q3_INVALID_ARG, "q3_batcher_fetch: unknown ticket %lld", (long long)ticket);
+    BatTicket& t = *it->second;
+    if (t.state == Q3_TICKET_FAILED) {
+        const q3_status st = t.st; const std::string err = t.err;
+        b->t.erase(it);
+        return set_err(st, "%s", err.c_str());
+    }
+    if (t.state != Q3_TICKET_DONE) return set_err(Q3_INVALID_ARG, "q3_batcher_fetch: ticket %lld has not finished", (long long)ticket);
+    if (codes_host) {
+        if (cap_frames < t.n_frames) return set_err(Q3_INVALID_ARG, "codes buffer too small (%d < %d frames)", cap_frames, t.n_frames);
+        memcpy(codes_host, t.codes.data(), t.codes.size() * 4);
+    }
+    if (pcm_host) {
+        if (cap_samples < t.pcm.size()) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+        memcpy(pcm_host, t.pcm.data(), t.pcm.size() * 4);
+    }
+    b->t.erase(it);
+    return Q3_OK;
+}
+
 extern "C" q3_status q3_session_next_chunk_row(q3_session* s, int b, float* pcm_host, size_t cap, size_t* n_samples, int* done) {
     if (!s || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad sequence index");
     HIPC(hipSetDevice(s->m->device));

@@ -50,6 +50,12 @@ pub mod ffi {
         pub fn q3_session_next_chunk_row(s: *mut c_void, b: i32, pcm: *mut f32, cap: usize, n: *mut usize, done: *mut i32) -> i32;
         pub fn q3_session_create_reserved(m: *mut c_void, reqs: *const Q3Request, batch: i32, frame_budget: i32, prompt_budget: i32, out: *mut *mut c_void) -> i32;
         pub fn q3_session_replace(s: *mut c_void, b: i32, req: *const Q3Request) -> i32;
+        pub fn q3_batcher_create(m: *mut c_void, slots: i32, frame_budget: i32, prompt_budget: i32, out: *mut *mut c_void) -> i32;
+        pub fn q3_batcher_free(b: *mut c_void);
+        pub fn q3_batcher_submit(b: *mut c_void, req: *const Q3Request, want_pcm: i32, ticket: *mut i64) -> i32;
+        pub fn q3_batcher_step(b: *mut c_void, n_frames: i32, use_graph: i32, n_running: *mut i32, n_queued: *mut i32, n_finished: *mut i32) -> i32;
+        pub fn q3_batcher_poll(b: *mut c_void, ticket: i64, state: *mut i32, n_frames: *mut i32, n_samples: *mut usize) -> i32;
+        pub fn q3_batcher_fetch(b: *mut c_void, ticket: i64, codes: *mut u32, cap_frames: i32, pcm: *mut f32, cap_samples: usize) -> i32;
         pub fn q3_session_frames(s: *mut c_void, b: i32, n_frames: *mut i32, done: *mut i32) -> i32;
         pub fn q3_session_codes(s: *mut c_void, b: i32, codes: *mut u32, cap_frames: i32, n_frames: *mut i32) -> i32;
         pub fn q3_session_decode(s: *mut c_void, b: i32, f0: i32, f1: i32, pcm: *mut f32, cap: usize, n: *mut usize) -> i32;
@@ -457,5 +463,55 @@ impl Iterator for StreamingSession<'_> {
             Ok(None) => None,
             Err(e) => Some(Err(e)),
         }
+    }
+}
+
+/// Continuous batching (no reference counterpart: the reference synthesizes one utterance per call). A queue of requests
+/// through the rows of one engine session — `submit_*` queue, `step` runs one scheduling round, `fetch` returns a
+/// finished request's audio. Every request gets the samples of its own `synthesize_*` call.
+pub struct Batcher<'a> { b: *mut c_void, model: &'a Qwen3TTS }
+impl Drop for Batcher<'_> { fn drop(&mut self) { unsafe { q3_batcher_free(self.b) } } }
+impl<'a> Batcher<'a> {
+    pub fn new(model: &'a Qwen3TTS, slots: usize, frame_budget: usize, prompt_budget: usize) -> Result<Self> {
+        let mut b = std::ptr::null_mut();
+        check(unsafe { q3_batcher_create(model.model, slots as i32, frame_budget as i32, prompt_budget as i32, &mut b) })?;
+        Ok(Self { b, model })
+    }
+    fn submit(&self, r: &Req) -> Result<i64> {
+        let req = Q3Request { mode: r.mode, text_ids: r.text.as_ptr(), n_text: r.text.len() as i32,
+            instruct_ids: if r.instruct.is_empty() { std::ptr::null() } else { r.instruct.as_ptr() }, n_instruct: r.instruct.len() as i32,
+            speaker_id: r.speaker, language_id: r.language, xvector: r.xvector.map(|x| x.as_ptr()).unwrap_or(std::ptr::null()), opts: r.opts.to_c(),
+            ref_codes: r.ref_codes.map(|c| c.as_ptr()).unwrap_or(std::ptr::null()), n_ref: r.ref_codes.map(|c| c.len() / 16).unwrap_or(0) as i32,
+            ref_text_ids: r.ref_text.map(|c| c.as_ptr()).unwrap_or(std::ptr::null()), n_ref_text: r.ref_text.map(|c| c.len()).unwrap_or(0) as i32 };
+        let mut t = 0i64;
+        check(unsafe { q3_batcher_submit(self.b, &req, 1, &mut t) })?;      // the engine copies the request
+        Ok(t)
+    }
+    /// queue what `synthesize_with_voice` would run; returns the ticket
+    pub fn submit_with_voice(&self, text: &str, speaker: Speaker, language: Language, options: Option<SynthesisOptions>) -> Result<i64> {
+        let (o, ids) = (options.unwrap_or_default(), self.model.encode(text)?);
+        self.submit(&Req { mode: 0, text: &ids, instruct: &[], speaker: speaker.token_id(), language: language.token_id(), xvector: None,
+                           ref_codes: None, ref_text: None, opts: &o })
+    }
+    /// queue what `synthesize_voice_design` would run
+    pub fn submit_voice_design(&self, text: &str, instruct: &str, language: Language, options: Option<SynthesisOptions>) -> Result<i64> {
+        let (o, ids, ins) = (options.unwrap_or_default(), self.model.encode(text)?, self.model.encode(instruct)?);
+        self.submit(&Req { mode: 2, text: &ids, instruct: &ins, speaker: 0, language: language.token_id(), xvector: None, ref_codes: None,
+                           ref_text: None, opts: &o })
+    }
+    /// one scheduling round of up to `n_frames` frames: (rows running, requests queued, tickets finished in this call)
+    pub fn step(&self, n_frames: usize) -> Result<(usize, usize, usize)> {
+        let (mut a, mut q, mut f) = (0i32, 0i32, 0i32);
+        check(unsafe { q3_batcher_step(self.b, n_frames as i32, 1, &mut a, &mut q, &mut f) })?;
+        Ok((a as usize, q as usize, f as usize))
+    }
+    /// `Ok(None)` while the ticket is queued or running; a finished ticket is returned once and released
+    pub fn fetch(&self, ticket: i64) -> Result<Option<AudioBuffer>> {
+        let (mut st, mut n, mut ns) = (0i32, 0i32, 0usize);
+        check(unsafe { q3_batcher_poll(self.b, ticket, &mut st, &mut n, &mut ns) })?;
+        if st < 2 { return Ok(None) }
+        let mut pcm = vec![0f32; ns];
+        check(unsafe { q3_batcher_fetch(self.b, ticket, std::ptr::null_mut(), 0, pcm.as_mut_ptr(), ns) })?;
+        Ok(Some(AudioBuffer::new(pcm, 24000)))
     }
 }

@@ -115,6 +115,33 @@ def test_b8_b16_graph_codes(gm17, B, sampling):
     assert len(rep) <= max(1, B // 8), rep          # near-ties are rare: at most one per eight sequences
 
 
+def test_continuous_batching_1_7b(gm17):
+    """Continuous batching at the benchmark's own size: the 16 fixture sequences (512-token prompts, default sampling) with
+    frame limits between 6 and 32 go through ONE eight-row hipGraph session — whenever a row reaches its limit the next
+    waiting request is prefilled on the side and swapped into it (q3_session_replace) while the other seven keep running.
+    Every request's codes must be the oracle's for that sequence, cut at its limit (a row's i-th random draw and its
+    arithmetic do not depend on its neighbours or on when it started)."""
+    ref = np.load(os.path.join(G, "bench_1_7b_codes.npz"))["default_codes"]
+    limits = [6, 32, 11, 24, 9, 32, 17, 28, 32, 7, 20, 13, 32, 10, 26, 15]
+    utts = []
+    for i, L in enumerate(limits):
+        u = bench_utt(i); u.max_length = L
+        utts.append(u)
+    opts = q.SynthesisOptions(max_length=N_FRAMES, eos_token_id=None, seed=42)
+    codes, _, frames, _ = gm17.synthesize_continuous(utts, opts, slots=8, poll_frames=4, decode=False, use_graph=True)
+    assert frames == sum(limits)
+    bad = []
+    for i, L in enumerate(limits):
+        assert codes[i].shape == (L, 16), (i, codes[i].shape)
+        if not (codes[i] == ref[i][:L]).all():
+            o1 = q.SynthesisOptions(max_length=L, eos_token_id=None, seed=42)
+            ok, rep = _adjudicate("1.7b", utts[i], o1, codes[i], f"1_7b_continuous_seq{i}")
+            assert ok, rep
+            bad.append(rep)
+    assert len(bad) <= 2, bad
+    _dump("bench_parity_1_7b_continuous.json", {"requests": len(limits), "slots": 8, "frames": int(frames), "limits": limits, "near_tie_divergences": bad})
+
+
 def test_b32_session_1_7b(gm17):
     """One session carrying 32 utterances at 1.7B (wide-batch GEMV, two attention splits): the 16 sequences the oracle fixture
     holds are compared with it, the other 16 with their own 8-utterance sessions (HIP vs HIP, bit-exact)."""

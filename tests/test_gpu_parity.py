@@ -1118,7 +1118,8 @@ def test_continuous_batching_fuzz(pair, seed):
             u = _utts(("custom", "design", "clone")[kind], n_text, index=i, hidden=cfg.hidden)
         u.seed = 500 + 17 * i + seed; u.max_length = int(rng.integers(3, 15)); u.options = options()
         return u
-    utts = [request(i, 0) for i in range(3)] + [request(i, int(rng.integers(0, 4))) for i in range(3, 12)]
+    # seed 0: the first batch shares one prefill shape (one batched prefill); the others: any kinds from the first row on
+    utts = [request(i, 0 if seed == 0 else int(rng.integers(0, 4))) for i in range(3)] + [request(i, int(rng.integers(0, 4))) for i in range(3, 12)]
     host = q.SynthesisOptions(max_length=16, seed=1)
     codes, pcm, frames, _ = gm.synthesize_continuous(utts, host, slots=3, poll_frames=int(rng.choice([1, 3, 8])), use_graph=bool(seed != 1))
     assert frames == sum(c.shape[0] for c in codes)
@@ -1131,3 +1132,57 @@ def test_continuous_batching_fuzz(pair, seed):
         for i, u in enumerate(utts):
             osess = O.OracleSession(om, u, u.options)
             np.testing.assert_array_equal(codes[i], osess.generate(), err_msg=f"request {i} vs oracle"); osess.close()
+
+
+@pytest.mark.gpu
+def test_native_batcher(pair):
+    """q3_batcher: the native serving loop. Requests of all four prompt kinds with their own options are queued — some before
+    the first step, some while others are running — and every one comes back with the codes and PCM of its batch-1 run. A
+    request that cannot be placed fails alone, with the engine's message, and the queue moves on."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(77)
+    def request(i, kind, L):
+        n_text = int(rng.integers(1, 11))
+        if kind == 3:
+            u = q.Utterance(synthetic_prompt(n_text, i), language=q.Language.French, xvector=rng.standard_normal(cfg.hidden).astype(np.float32),
+                            ref_codes=rng.integers(0, 2048, size=(4, 16)).astype(np.uint32), ref_text_ids=synthetic_prompt(3, 90 + i))
+        else:
+            u = _utts(("custom", "design", "clone")[kind], n_text, index=i, hidden=cfg.hidden)
+        u.seed = 900 + i; u.max_length = L
+        u.options = q.SynthesisOptions(temperature=0.0 if i % 3 == 0 else 0.9, eos_token_id=None, max_length=16, seed=1)
+        return u
+    utts = [request(i, k, L) for i, (k, L) in enumerate([(1, 5), (0, 12), (3, 7), (2, 9), (0, 3), (1, 14), (3, 6), (2, 11), (0, 8)])]
+    b = q.Batcher(gm, slots=3, frame_budget=16, prompt_budget=40, options=q.SynthesisOptions(max_length=16, seed=1))
+    tickets = [b.submit(u) for u in utts[:5]]
+    assert b.poll(tickets[0])[0] == q.Batcher.QUEUED
+    finished = 0
+    running, queued, f = b.step(4); finished += f
+    assert running == 3 and queued == 2 and f == 0                       # three rows busy (limits 5 / 12 / 7), two requests waiting
+    tickets += [b.submit(u) for u in utts[5:]]                           # late arrivals
+    too_long = q.Utterance(synthetic_prompt(1100, 5), q.Speaker.Ryan, q.Language.English); too_long.max_length = 4
+    bad = b.submit(too_long)
+    with pytest.raises(_lib.Q3Error, match="frame budget"):
+        over = _utts("custom", 4, index=1, hidden=cfg.hidden); over.max_length = 17
+        b.submit(over)
+    for _ in range(200):
+        running, queued, f = b.step(3); finished += f
+        if running == 0 and queued == 0:
+            break
+    assert finished == len(utts) + 1
+    assert b.poll(bad)[0] == q.Batcher.FAILED
+    with pytest.raises(_lib.Q3Error, match="exceed the session's slot"):
+        b.fetch(bad)
+    for i, (u, t) in enumerate(zip(utts, tickets)):
+        assert b.poll(t)[0] == q.Batcher.DONE
+        codes, pcm = b.fetch(t)
+        s1 = gm.session([u], u.options); s1.prefill(); s1.generate(100, use_graph=False)
+        np.testing.assert_array_equal(codes, s1.codes(0), err_msg=f"request {i}")
+        np.testing.assert_array_equal(pcm, s1.decode(0), err_msg=f"request {i}"); s1.close()
+    with pytest.raises(_lib.Q3Error, match="unknown ticket"):
+        b.poll(tickets[0])                                              # released by fetch
+    # the batcher stays usable after draining: a new request goes into an idle row of the same session
+    t = b.submit(utts[2]); b.step(50)
+    codes, _ = b.fetch(t)
+    s1 = gm.session([utts[2]], utts[2].options); s1.prefill(); s1.generate(100, use_graph=False)
+    np.testing.assert_array_equal(codes, s1.codes(0)); s1.close()
+    b.close()

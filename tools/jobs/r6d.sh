@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 3, job 6d: side session on the host's stream — swap cost; continuous tests; eos_mix through the native batcher
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+Q3_REPLACE_TIMING=1 python tools/dev/time_replace.py 2>&1 | tail -14
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "batcher or fuzz or replace or batch_equals or stream" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_bench_config_parity.py -m gpu -x -q -k "continuous" 2>&1 | tail -3
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/r6d_bench.json
+python -c "
+import json; d=json.load(open('gpurun_out/r6d_bench.json')); print(d['value'], d['ms_per_step'], d.get('latency'), d.get('eos_mix'))"
