@@ -2292,13 +2292,27 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
         }
         return Q3_OK;
     };
-    Q3C(fill());
-    Q3C(q3_session_generate(b->s, n_frames, use_graph));
-    for (int r = 0; r < b->slots; ++r) {
-        if (b->owner[r] < 0) continue;
-        int n = 0, done = 0;
-        Q3C(q3_session_frames(b->s, r, &n, &done));
-        if (done) { Q3C(bat_collect(b, r)); finished++; }
+    // Run in pieces that end where the next row reaches its frame limit: that row is collected and refilled at once instead of
+    // idling to the end of the step (a row that ends on EOS is noticed at q3_session_generate's 32-frame check or at the
+    // end of the piece)
+    for (int left = n_frames; left > 0;) {
+        Q3C(fill());
+        int piece = left, busy = 0;
+        for (int r = 0; r < b->slots; ++r) {
+            if (b->owner[r] < 0) continue;
+            const SeqInfo& q = b->s->seq[r];
+            const int rem = q.limit - (b->s->frames_run - q.start_run);
+            if (rem > 0) { busy++; if (rem < piece) piece = rem; }
+        }
+        if (busy > 0) { Q3C(q3_session_generate(b->s, piece, use_graph)); left -= piece; }
+        int collected = 0;
+        for (int r = 0; r < b->slots; ++r) {
+            if (b->owner[r] < 0) continue;
+            int n = 0, done = 0;
+            Q3C(q3_session_frames(b->s, r, &n, &done));
+            if (done) { Q3C(bat_collect(b, r)); finished++; collected++; }
+        }
+        if (busy == 0 && collected == 0) break;          // nothing runs and nothing is waiting for a row
     }
     Q3C(fill());                                   // the next step starts with full rows
     int running = 0;
