@@ -1268,21 +1268,44 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     LinArgs a;
     a.N = QD + 2 * KD; a.K = d.H; set_w(a, w.qkv, B, a.N, a.K); a.x = b.X; a.ldx = d.H; a.norm_w = w.in_ln; a.eps = d.eps;
     a.y = b.QKV; a.ldy = QD + 2 * KD; a.M = B; a.epi = EPI_NONE;
-    if (!skip_qkv) HIPC(run_linear(s, a));       // skip: the caller already filled b.QKV (code predictor layer 0, table rows)
+    // Wide sessions: the q|k|v GEMM hands its K-slice sums straight to the attention kernel, which adds them on the 3 x 128
+    // values it needs (AttnArgs::qkv_part) — the slice-sum launch in between (93 per frame at 1.7B, 5.2 us + gap each) is gone.
+    // Only for the one-launch decode attention (static one-row steps); Q3_WIDE_NO_QKV_FUSE=1: off (A/B aid)
+    static const bool qkv_fuse = getenv("Q3_WIDE_NO_QKV_FUSE") == nullptr;
+    WidePartial wp{nullptr, nullptr, 0};
+    if (!skip_qkv) {       // skip: the caller already filled b.QKV (code predictor layer 0, table rows)
+        bool fused = false;
+        if (qkv_fuse && B > 32 && rows_per_seq == 1 && !s->legacy_attn && !s->profile && !s->debug && s->wide_ws) {
+            LinArgs a2 = a; a2.ws = s->wide_ws; a2.ws_bytes = s->wide_ws_bytes;
+            const hipError_t e = launch_gemm_wide_partial(a2, s->stream, &wp);
+            if (e == hipSuccess && wp.S <= 8) fused = true;
+            else if (e != hipSuccess && e != hipErrorNotSupported) HIPC(e);
+            else if (e == hipSuccess) { wp = WidePartial{nullptr, nullptr, 0}; }       // more than eight slices: let the slice-sum launch redo it
+        }
+        if (!fused) { wp = WidePartial{nullptr, nullptr, 0}; HIPC(run_linear(s, a)); }
+    }
     AttnArgs t{};
     t.qkv = b.QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
     t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
+    if (wp.part) { t.qkv_part = wp.part; t.qkv_ssq = wp.ssq; t.qkv_S = wp.S; t.qkv_K = d.H; t.qkv_eps = d.eps; }
     // Split-K projections (LinArgs::ksplit, k_gemv_sk2): o-proj and down-proj with N <= 2048 and K >= 2048 at 3 .. 16 rows
     // run as two K halves that meet in the output through order-independent atomic adds. The output buffer must hold zeros:
     // SUM is cleared by this layer's attention launch (its last reader was the previous down-proj), X by the gate/up
     // launch (its last reader is this layer's o-proj, as the residual).
     const bool first2 = !s->legacy_attn && rows_per_seq == 2 && !pos_dev && pos_static == 0;
     const bool attn3 = !first2 && (s->legacy_attn || rows_per_seq > 1);
-    const bool sk_rows = s->ksplit && B >= 3 && B <= 16 && d.H <= 2048 && d.H % 4 == 0;
+    // Wide sessions (B > 16, round 3): the same kernel over blocks of 16 rows (grid plane z) — one launch instead of the
+    // split-K GEMM + slice-sum pair for exactly the narrow outputs where the second launch hurt most (B = 64, code
+    // predictor o / down: 9.4 + 4.9 us -> one launch). Q3_WIDE_NO_SK2=1: off (A/B aid)
+    static const bool wide_sk2 = getenv("Q3_WIDE_NO_SK2") == nullptr;
+    const bool sk_rows = s->ksplit && B >= 3 && (B <= 16 || (wide_sk2 && B <= Q3_MAX_BATCH && rows_per_seq == 1)) && d.H <= 2048 && d.H % 4 == 0;
     const bool o_sk = sk_rows && !first2 && !attn3 && w.o.t1 && QD >= 2048 && up32(QD) / 32 >= 16;
-    const bool dn_sk = sk_rows && w.down.t1 && w.gate.t1 && d.I >= 2048 && up32(d.I) / 32 >= 16;
+    // (beyond 32 rows the 25 MB talker down-proj is re-read by every 16-row block — 32.0 us at B = 64 against 16.5 + 4.8 for
+    // the GEMM pair — while the smaller matrices win: code predictor o 14.6 -> 6.8, down 15.7 -> 9.2, talker o 14.4 -> 11.7 us)
+    const bool dn_big = B > 32 && (size_t)d.I * d.H * 2 > ((size_t)12 << 20);
+    const bool dn_sk = sk_rows && !dn_big && w.down.t1 && w.gate.t1 && d.I >= 2048 && up32(d.I) / 32 >= 16;
     if (first2) {
         if (fold) {                                 // pass-1 gather folded: row 2b+1 = table row tok[b]
             t.g_tok = fold->tok; t.g_qkv_tab = fold->qkv_tab; t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim;

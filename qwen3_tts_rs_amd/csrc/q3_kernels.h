@@ -145,8 +145,17 @@ struct AttnArgs {
     // side job (launch_attn_fused / launch_attn_cp): store zeros to zero[0 .. zero_n) — clears the target of the split-K
     // o-projection that follows (LinArgs::ksplit)
     float* zero = nullptr; int zero_n = 0;
+    // wide sessions (launch_attn_fused / launch_attn_cp): q|k|v arrives as the K-slice sums of the split-K GEMM
+    // (launch_gemm_wide_partial: qkv_part[s][row][ld_qkv], sum(x^2) per slice qkv_ssq[s][row]) and the kernel does what
+    // k_wide_epilogue would have — slices added in order, then / sqrt(mean(x^2) + eps) — on the 3 x 128 values it needs:
+    // one launch less per layer. qkv is unused then. qkv_S <= 8.
+    const float* qkv_part = nullptr; const float* qkv_ssq = nullptr; int qkv_S = 0, qkv_K = 0; float qkv_eps = 0.0f;
     Q3_TRACE_FIELD
 };
+// the GEMM of launch_gemm_wide WITHOUT its slice-sum launch (EPI_NONE with a fused input norm only): the consumer adds
+// the slices. hipErrorNotSupported: shape outside the family.
+struct WidePartial { const float* part; const float* ssq; int S; };
+hipError_t launch_gemm_wide_partial(const LinArgs& a, hipStream_t st, WidePartial* out);
 constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
 // planes of positions [0, n_pos) of every (sequence, kv head) pair, from the f32 cache launch_qknorm_rope_kv filled
 hipError_t launch_kv_planes(const float* kcache, const float* vcache, int max_seq, int n_pairs, int n_pos, int tiles_alloc,
@@ -285,6 +294,40 @@ hipError_t launch_norm_codebook(const float* esum, const float* usage, float* ou
 
 #if defined(__HIPCC__)
 // zero side job (LinArgs::zero / AttnArgs::zero): workgroup `wg` of `nwg` clears its share with 16-byte stores
+// q|k|v columns col0 / col1 (.. +VEC-1) of activation row b from the slice sums (AttnArgs::qkv_part): the arithmetic of
+// k_wide_epilogue<EPI_NONE, RMS> — v = 0; v += slice s (ascending); v / sqrt(sum_s ssq / K + eps) — with every load of
+// the eight possible slices in flight at once
+template <typename V, int NC>
+__device__ __forceinline__ void qkv_from_slices(const AttnArgs& a, int b, const int (&col)[NC], V (&out)[NC]) {
+    const size_t plane = (size_t)a.B * a.ld_qkv;
+    const float* p0 = a.qkv_part + (size_t)b * a.ld_qkv;
+    V x[NC][8]; float q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = i < a.qkv_S ? i : a.qkv_S - 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c][i] = *reinterpret_cast<const V*>(p0 + (size_t)s * plane + col[c]);
+        q[i] = a.qkv_ssq[(size_t)s * a.B + b];
+    }
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < a.qkv_S) tot += q[i];
+    const float den = sqrtf(tot / (float)a.qkv_K + a.qkv_eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if constexpr (sizeof(V) == 8) {
+            float2 v = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < a.qkv_S) { v.x += x[c][i].x; v.y += x[c][i].y; }
+            out[c].x = v.x / den; out[c].y = v.y / den;
+        } else {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < a.qkv_S) v += x[c][i];
+            out[c] = v / den;
+        }
+    }
+}
 __device__ __forceinline__ void zero_job(float* z, int n, int wg, int nwg, int tid, int nthreads) {
     if (!z) return;
     const int per = (((n + nwg - 1) / nwg) + 3) & ~3;

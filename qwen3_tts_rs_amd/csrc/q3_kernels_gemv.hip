@@ -326,6 +326,12 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
     const int half = blockIdx.y;
+    if (gridDim.z > 1) {                             // wide sessions: blockIdx.z = block of 16 activation rows (each block is its own two-addend sum)
+        const int r0 = (int)blockIdx.z * 16;
+        a.x += (size_t)r0 * a.ldx; a.y += (size_t)r0 * a.ldy;
+        if (a.resid) a.resid += (size_t)r0 * a.ldr;
+        a.M = (a.M - r0) < 16 ? (a.M - r0) : 16;
+    }
     const int S = a.Kpad >> 5;                       // k-steps of 32
     const int h0 = (half * S) / 2, h1 = ((half + 1) * S) / 2, Sh = h1 - h0;
     const int s0 = h0 + (wave * Sh) / NWAVES, s1 = h0 + ((wave + 1) * Sh) / NWAVES;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) acc0 = mfma3(g.wa[i], sp[i], acc0);
     }
     Q3T_W(2);
-    zero_job(a.zero, a.zero_n, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, NWAVES * 64);
+    zero_job(a.zero, a.zero_n, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z, tid, NWAVES * 64);
     *reinterpret_cast<f32x4_t*>(&red[wave][m * 16 + kg * 4]) = acc0;
     Q3T(6);
     __syncthreads();
@@ -394,10 +400,10 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
 }
 
 static hipError_t launch_gemv_sk2(const LinArgs& a, hipStream_t st) {
-    if (a.norm_w || (a.epi != EPI_NONE && a.epi != EPI_RESID) || a.tiled != 1 || a.M > 16) return hipErrorInvalidValue;
+    if (a.norm_w || (a.epi != EPI_NONE && a.epi != EPI_RESID) || a.tiled != 1 || a.M > 64) return hipErrorInvalidValue;
     const int tiles = (a.N + 15) / 16, S = a.Kpad >> 5;
     if (S < 16) return hipErrorInvalidValue;
-    const dim3 grid(tiles, 2), blk(512);
+    const dim3 grid(tiles, 2, (a.M + 15) / 16), blk(512);     // M > 16 (wide sessions): one grid plane per 16 rows
     const bool g6 = ((S / 2) % 48) == 0;             // a wave's slice is a multiple of 6 k-steps (K = 3072, 6144): no ragged group
     const bool half = a.M <= 8;
 #define Q3_SK2(E, GG, H) hipLaunchKernelGGL((k_gemv_sk2<E, GG, H>), grid, blk, 0, st, Q3_LIN_PASS(a))
@@ -1137,6 +1143,7 @@ __global__ __launch_bounds__(512) void k_gemv_wide(Q3_LIN_PRE, LinArgs a_in) {
             }
         }
     }
+    zero_job(a.zero, a.zero_n, blockIdx.x, gridDim.x, tid, NWAVES * 64);      // behind the loads of the main loop (vmcnt retires in order)
     if constexpr (RMS) {
         // per-row sum(x^2) of this wave's K slice: the 8 lanes with equal lane >> 3 share a row
 #pragma unroll
@@ -1206,6 +1213,7 @@ static hipError_t launch_gemv_wide(const LinArgs& a, hipStream_t st) {
 
 hipError_t launch_gemv_tiled(const LinArgs& a, hipStream_t st) {
     if (a.M > 16) {
+        if (a.ksplit == 2) return launch_gemv_sk2(a, st);
         if (a.ksplit > 1) return hipErrorInvalidValue;
         static const bool no_gemm = getenv("Q3_WIDE_NO_GEMM") != nullptr;      // A/B aid: wide sessions on k_gemv_wide
         if (a.ws && !no_gemm) { const hipError_t e = launch_gemm_wide(a, st); if (e != hipErrorNotSupported) return e; }

@@ -517,8 +517,16 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v)
     for (int j = wave; j <= NREP; j += 4) {
         const bool is_q = j < NREP;
-        const float* src = qkv_row + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM);
-        float x1 = src[lane], x2 = src[lane + 64];
+        const int scol = is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM;
+        const float* src = qkv_row + scol;
+        float x1, x2, pv1 = 0.f, pv2 = 0.f;
+        const bool from_slices = a.qkv_part && !a.g_logits;
+        if (from_slices) {          // the k job brings its v along: one round trip
+            const int vcol = QD + KD + kvh * HEAD_DIM;
+            const int cols[4] = {scol + lane, scol + lane + 64, is_q ? scol + lane : vcol + lane, is_q ? scol + lane + 64 : vcol + lane + 64};
+            float o[4]; qkv_from_slices<float, 4>(a, b, cols, o);
+            x1 = o[0]; x2 = o[1]; pv1 = o[2]; pv2 = o[3];
+        } else { x1 = src[lane]; x2 = src[lane + 64]; }
         const float ss = wave_sum(x1 * x1 + x2 * x2);
         const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
         const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
@@ -530,7 +538,9 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
         if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
         else {
             const float* vs = qkv_row + QD + KD + kvh * HEAD_DIM;
-            const float v1 = vs[lane], v2 = vs[lane + 64];
+            float v1, v2;
+            if (from_slices) { v1 = pv1; v2 = pv2; }
+            else { v1 = vs[lane]; v2 = vs[lane + 64]; }
             s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
             if (split == pos / chunk) {
                 float* kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM;
@@ -815,9 +825,16 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
             if (h == 0 && lane == 0 && a.g_frame_idx[b] < a.g_max_frames) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
         }
     }
-    float2 q = *reinterpret_cast<const float2*>(qkv_row + h * HEAD_DIM + 2 * lane);
-    float2 k = *reinterpret_cast<const float2*>(qkv_row + QD + kvh * HEAD_DIM + 2 * lane);
-    const float2 v = *reinterpret_cast<const float2*>(qkv_row + QD + KD + kvh * HEAD_DIM + 2 * lane);
+    float2 q, k, v;
+    if (a.qkv_part && !a.g_logits) {      // wide sessions: the slice sums of the split-K GEMM (see AttnArgs::qkv_part)
+        const int cols[3] = {h * HEAD_DIM + 2 * lane, QD + kvh * HEAD_DIM + 2 * lane, QD + KD + kvh * HEAD_DIM + 2 * lane};
+        float2 o[3]; qkv_from_slices<float2, 3>(a, b, cols, o);        // all 24 slice loads of the lane in flight at once
+        q = o[0]; k = o[1]; v = o[2];
+    } else {
+        q = *reinterpret_cast<const float2*>(qkv_row + h * HEAD_DIM + 2 * lane);
+        k = *reinterpret_cast<const float2*>(qkv_row + QD + kvh * HEAD_DIM + 2 * lane);
+        v = *reinterpret_cast<const float2*>(qkv_row + QD + KD + kvh * HEAD_DIM + 2 * lane);
+    }
 
     Q3T_W(1);
     // side job behind the last load (vmcnt retires in issue order: a store ahead of the loads would sit in front of every wait for them)

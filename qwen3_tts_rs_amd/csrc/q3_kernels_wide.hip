@@ -182,11 +182,13 @@ __global__ __launch_bounds__(NWV * 64) void k_wide_gemm(WideArgs a) {
 struct WideEpiArgs {
     const float* part; const float* ssq; int S, nmat, M, N, K; float eps;
     const float* bias; const float* resid; int ldr; float* y; int ldy;
+    float* zero; int zero_n;                      // side job (LinArgs::zero): clears the target of a later split-K projection
 };
 // slice sums -> y: fixed slice order, then 1/rms, +bias, +residual, SiLU, SwiGLU (the epilogues of the GEMV family)
 template <int EPI, bool RMS>
 __global__ __launch_bounds__(256) void k_wide_epilogue(WideEpiArgs e) {
     const int m = blockIdx.y, n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    zero_job(e.zero, e.zero_n, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, threadIdx.x, 256);
     if (n >= e.N) return;
     float4 v = {0.f, 0.f, 0.f, 0.f}, v2 = v;
     const size_t plane = (size_t)e.M * e.N;
@@ -280,8 +282,14 @@ size_t gemm_wide_ws_bytes(int M, int N, int K, int epi) {
     return ((size_t)S * nmat * M * N + (size_t)S * M) * sizeof(float);
 }
 
+static hipError_t gemm_wide_impl(const LinArgs& a, hipStream_t st, WidePartial* partial);
+hipError_t launch_gemm_wide_partial(const LinArgs& a, hipStream_t st, WidePartial* out) {
+    if (!out || a.epi != EPI_NONE || !a.norm_w || a.bias || a.zero) return hipErrorNotSupported;
+    return gemm_wide_impl(a, st, out);
+}
 // hipErrorNotSupported: the shape is outside this family (the caller falls back to k_gemv_wide)
-hipError_t launch_gemm_wide(const LinArgs& a, hipStream_t st) {
+hipError_t launch_gemm_wide(const LinArgs& a, hipStream_t st) { return gemm_wide_impl(a, st, nullptr); }
+static hipError_t gemm_wide_impl(const LinArgs& a, hipStream_t st, WidePartial* partial) {
     const bool rms = a.norm_w != nullptr;
     // (M <= 32 stays on k_gemv_wide: two column tiles do not pay for the second launch — 1.7B, B = 32: 6.17 vs 6.79 ms per frame)
     if (a.tiled != 1 || a.M < 33 || a.M > 64 || a.N % 128 != 0 || a.K % 128 != 0 || a.Kpad != a.K || a.ldx % 4 != 0 || a.ldy % 4 != 0 || !a.ws ||
@@ -298,9 +306,10 @@ hipError_t launch_gemm_wide(const LinArgs& a, hipStream_t st) {
     hipError_t e = rows == 128 ? (rms ? launch_gemm_t<true, 8>(w, st) : launch_gemm_t<false, 8>(w, st))
                                : (rms ? launch_gemm_t<true, 4>(w, st) : launch_gemm_t<false, 4>(w, st));
     if (e != hipSuccess) return e;
+    if (partial) { partial->part = w.part; partial->ssq = w.ssq; partial->S = w.S; return hipSuccess; }     // the consumer adds the slices
     WideEpiArgs p{};
     p.part = w.part; p.ssq = w.ssq; p.S = w.S; p.nmat = w.nmat; p.M = a.M; p.N = a.N; p.K = a.K; p.eps = a.eps;
-    p.bias = a.bias; p.resid = a.resid; p.ldr = a.ldr; p.y = a.y; p.ldy = a.ldy;
+    p.bias = a.bias; p.resid = a.resid; p.ldr = a.ldr; p.y = a.y; p.ldy = a.ldy; p.zero = a.zero; p.zero_n = a.zero_n;
     switch (a.epi) {
         case EPI_NONE: return launch_epi_t<EPI_NONE>(p, rms, st);
         case EPI_RESID: return launch_epi_t<EPI_RESID>(p, rms, st);
