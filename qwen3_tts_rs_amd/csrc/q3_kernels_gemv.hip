@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
 // The two halves meet in y through f32 atomic adds onto ZEROS (LinArgs::ksplit): two addends commute bit for bit, so the
 // result does not depend on arrival order — no ticket, no fence, no second pass. The k = 0 half adds bias + residual.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, int G, bool HALF>
+template <int EPI, int G, bool HALF, bool MB = false>       // MB: wide sessions, blockIdx.z = block of 16 activation rows
 __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     Q3_LIN_APPLY(a, a_in);
     constexpr int NWAVES = 8;
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kg = lane >> 4;
     const int half = blockIdx.y;
-    if (gridDim.z > 1) {                             // wide sessions: blockIdx.z = block of 16 activation rows (each block is its own two-addend sum)
+    if constexpr (MB) {                              // each row block is its own two-addend sum (a separate instantiation: the pointer
+                                                     // arithmetic on the preloaded arguments cost the M <= 16 kernel 0.4 us per launch)
         const int r0 = (int)blockIdx.z * 16;
         a.x += (size_t)r0 * a.ldx; a.y += (size_t)r0 * a.ldy;
         if (a.resid) a.resid += (size_t)r0 * a.ldr;
@@ -381,7 +382,8 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) acc0 = mfma3(g.wa[i], sp[i], acc0);
     }
     Q3T_W(2);
-    zero_job(a.zero, a.zero_n, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z, tid, NWAVES * 64);
+    if constexpr (MB) zero_job(a.zero, a.zero_n, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z, tid, NWAVES * 64);
+    else zero_job(a.zero, a.zero_n, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, NWAVES * 64);
     *reinterpret_cast<f32x4_t*>(&red[wave][m * 16 + kg * 4]) = acc0;
     Q3T(6);
     __syncthreads();
@@ -407,6 +409,11 @@ static hipError_t launch_gemv_sk2(const LinArgs& a, hipStream_t st) {
     const bool g6 = ((S / 2) % 48) == 0;             // a wave's slice is a multiple of 6 k-steps (K = 3072, 6144): no ragged group
     const bool half = a.M <= 8;
 #define Q3_SK2(E, GG, H) hipLaunchKernelGGL((k_gemv_sk2<E, GG, H>), grid, blk, 0, st, Q3_LIN_PASS(a))
+    if (a.M > 16) {                                  // row blocks: full 16-column tiles only
+        if (a.epi == EPI_RESID) { if (g6) hipLaunchKernelGGL((k_gemv_sk2<EPI_RESID, 6, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); else hipLaunchKernelGGL((k_gemv_sk2<EPI_RESID, 4, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); }
+        else { if (g6) hipLaunchKernelGGL((k_gemv_sk2<EPI_NONE, 6, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); else hipLaunchKernelGGL((k_gemv_sk2<EPI_NONE, 4, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); }
+        return hipGetLastError();
+    }
     if (a.epi == EPI_RESID) {
         if (g6) { if (half) Q3_SK2(EPI_RESID, 6, true); else Q3_SK2(EPI_RESID, 6, false); }
         else    { if (half) Q3_SK2(EPI_RESID, 4, true); else Q3_SK2(EPI_RESID, 4, false); }
