@@ -164,6 +164,9 @@ struct q3_model {
     // bf16x3-packed copies of the vocoder's conv / linear weights (launch_pack_conv_w), keyed by the f32 pointer
     std::unordered_map<const float*, const void*> wpk; void* wpk_arena = nullptr;
     const void* pk(const float* w) const { auto it = wpk.find(w); return it == wpk.end() ? nullptr : it->second; }
+    // frame-loop streams of freed sessions, reused by the next q3_session_create: creating a priority stream costs 1.6 ms and
+    // destroying one 1.1 ms — 8 % of a streaming session's time to first audio, more than its whole prefill
+    std::mutex stream_mu; std::vector<hipStream_t> idle_streams;
     const float* first_cb = nullptr; const float** rest_cbs_dev = nullptr; // device array of 15 pointers
     const uint16_t** cp_embs_dev = nullptr;                                // device array of 15 pointers
     // 1.7B: small_to_mtp_projection applied once to every row of the 15 acoustic embedding tables and of the talker's
@@ -431,6 +434,7 @@ extern "C" void q3_model_free(q3_model* m) {
     hipSetDevice(m->device);
     hipFree(m->arena); hipFree(m->rope_cos); hipFree(m->rope_sin); hipFree(m->derived); hipFree(m->wpk_arena);
     hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev); hipFree(m->proj_tabs); hipFree(m->qkv0_tabs);
+    for (hipStream_t st : m->idle_streams) (void)hipStreamDestroy(st);
     delete m;
 }
 
@@ -1636,9 +1640,15 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
         // that its workgroups are dispatched ahead of the vocoder segments running beside it (q3_session_run)
         if (borrow) { s->stream = borrow; s->owns_stream = false; }      // q3_session_replace: no second queue for a one-row prefill
         else {
-            int least = 0, greatest = 0;
-            HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIPC(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
+            {
+                std::lock_guard<std::mutex> g(m->stream_mu);
+                if (!m->idle_streams.empty()) { s->stream = m->idle_streams.back(); m->idle_streams.pop_back(); }
+            }
+            if (!s->stream) {
+                int least = 0, greatest = 0;
+                HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIPC(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
+            }
         }
     }
     const int B = batch, H = c.hidden, CH = c.cp_hidden;
@@ -1729,6 +1739,10 @@ q3_session::~q3_session() {
     if (pcm_all) dev_free(pcm_all);
     if (dec_ev) (void)hipEventDestroy(dec_ev);
     if (dec_stream) (void)hipStreamDestroy(dec_stream);
+    if (stream && owns_stream) {                   // synchronised above: idle, handed to the next session of this model
+        std::lock_guard<std::mutex> g(m->stream_mu);
+        if (m->idle_streams.size() < 16) { m->idle_streams.push_back(stream); stream = nullptr; }
+    }
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
 }
 
