@@ -82,6 +82,34 @@ int main(int argc, char** argv) {
     CHECK(q3_codes_write_bin(path, codes, nf, 16));
     printf("frames %d samples %zu prefill %.2f ms generation %.2f ms decode %.2f ms (gathered: %.2f ms, %.0f frames)\n", nf, n_samples,
            tm.prefill_ms, tm.generation_ms, tm.decode_ms, all[0], all[1]);
+    /* the same request and a second one through the native continuous batcher (two rows): the library's own serving loop;
+     * the first ticket must come back with exactly the codes of the session above */
+    q3_batcher* bat = NULL;
+    CHECK(q3_batcher_create(model, 2, frames, 0, &bat));
+    uint32_t text2[7];
+    for (int i = 0; i < 7; ++i) text2[i] = (uint32_t)(29 * i + 5) % 512;
+    q3_request req2 = req;
+    req2.text_ids = text2; req2.n_text = 7; req2.opts.seed = 7; req2.opts.max_length = frames > 2 ? frames - 2 : frames;
+    int64_t ta = 0, tb = 0;
+    CHECK(q3_batcher_submit(bat, &req, 0, &ta));
+    CHECK(q3_batcher_submit(bat, &req2, 1, &tb));
+    for (int guard = 0; guard < 1000; ++guard) {
+        int running = 0, queued = 0, fin = 0;
+        CHECK(q3_batcher_step(bat, 4, 1, &running, &queued, &fin));
+        if (running == 0 && queued == 0) break;
+    }
+    int st_a = 0, st_b = 0, nfa = 0, nfb = 0; size_t nsa = 0, nsb = 0;
+    CHECK(q3_batcher_poll(bat, ta, &st_a, &nfa, &nsa));
+    CHECK(q3_batcher_poll(bat, tb, &st_b, &nfb, &nsb));
+    if (st_a != Q3_TICKET_DONE || st_b != Q3_TICKET_DONE || nfa != nf || nsb != (size_t)nfb * 1920) { fprintf(stderr, "batcher: unexpected ticket state\n"); return 3; }
+    uint32_t* codes_a = (uint32_t*)malloc((size_t)nfa * 16 * 4);
+    float* pcm_b = (float*)malloc(nsb * sizeof(float));
+    CHECK(q3_batcher_fetch(bat, ta, codes_a, nfa, NULL, 0));
+    CHECK(q3_batcher_fetch(bat, tb, NULL, 0, pcm_b, nsb));
+    if (memcmp(codes_a, codes, (size_t)nf * 16 * 4) != 0) { fprintf(stderr, "batcher: codes differ from the session's\n"); return 3; }
+    printf("batcher: 2 requests through 2 rows, %d + %d frames, ticket 1 bit-equal to the session\n", nfa, nfb);
+    q3_batcher_free(bat); free(codes_a); free(pcm_b);
+
     q3_session_free(sess); q3_dp_free(comm); q3_model_free(model);
     free(pcm); free(codes);
     return 0;
