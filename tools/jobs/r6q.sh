@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 3, job 6q: GPU suite in other file orders and twice in one process order (stream cache / lazy zero-fill / atomic paths)
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_bench_config_parity.py tests/test_gpu_parity.py tests/test_speech_encoder.py tests/test_speaker_encoder.py tests/test_examples.py tests/test_cli.py tests/test_c_host.py tests/test_io_formats.py -m gpu -q 2>&1 | grep "passed\|failed\|Error" | tail -3
+timeout 1500 python -m pytest tests/test_speaker_encoder.py tests/test_speech_encoder.py tests/test_cli.py tests/test_gpu_parity.py tests/test_bench_config_parity.py -m gpu -q 2>&1 | grep "passed\|failed\|Error" | tail -3
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity.py -m gpu -q -k "not two_ranks" 2>&1 | grep "passed\|failed\|Error" | tail -3
+python -c "import __graft_entry__ as g; g.smoke()"
