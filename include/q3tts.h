@@ -222,7 +222,9 @@ q3_status q3_session_replace(q3_session* s, int b, const q3_request* req);
 typedef struct q3_batcher q3_batcher;
 enum { Q3_TICKET_QUEUED = 0, Q3_TICKET_RUNNING = 1, Q3_TICKET_DONE = 2, Q3_TICKET_FAILED = 3 };
 /* slots = rows of the session (1..64); frame_budget = largest max_length a request may ask for; prompt_budget = prefill
- * positions a row can hold (0: those of the first request) — see q3_session_create_reserved */
+ * positions a row can hold (at least 16, which covers CustomVoice and x-vector prompts — their text rides along as trailing
+ * text; VoiceDesign needs its instruct length + 16, ICL its reference frames + 16): see q3_session_create_reserved. The
+ * session is opened lazily, on idle rows, when the first request arrives. */
 q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget, int prompt_budget, q3_batcher** out);
 void      q3_batcher_free(q3_batcher* b);
 /* Queue a request (deep copy: the caller's arrays may go away). want_pcm != 0: the finished row is vocoded

@@ -340,6 +340,9 @@ class Batcher:
 
     def __init__(self, model: "Qwen3TTS", slots: int = 8, frame_budget: int = 2048, prompt_budget: int = 0,
                  options: Optional[SynthesisOptions] = None):
+        """slots: rows of the session; frame_budget: largest max_length a request may ask for; prompt_budget: prefill
+        positions a row can hold (at least 16 = CustomVoice / x-vector prompts; VoiceDesign: instruct length + 16; ICL:
+        reference frames + 16); options: defaults for utterances without their own."""
         self.model = model
         self.options = options or SynthesisOptions()
         h = ctypes.c_void_p()

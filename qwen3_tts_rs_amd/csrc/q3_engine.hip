@@ -2296,23 +2296,26 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
     if (!b) return set_err(Q3_INVALID_ARG, "q3_batcher_step: null batcher");
     if (n_frames < 1) return set_err(Q3_INVALID_ARG, "q3_batcher_step: n_frames must be >= 1");
     int finished = 0;
-    size_t qpos = 0;
-    // open the session on the first request that fits (it takes row 0; the other rows start idle): `slots` copies share one
-    // prefill shape by construction, whatever the queue holds
-    while (!b->s && qpos < b->queue.size()) {
-        const int64_t id = b->queue[qpos++];
-        BatTicket& t = *b->t[id];
-        b->chunk_frames = t.req.r.opts.chunk_frames;
-        std::vector<q3_request> reqs((size_t)b->slots, t.req.r);
+    // Open the session on `slots` idle rows: copies of a one-token CustomVoice prompt with a one-frame limit (ten prefill
+    // positions per row — opening on the first request itself would prefill, and size every row's KV extent for, `slots`
+    // copies of what may be a 4k-token prompt), frozen before the first frame. Every request, the first included, then enters
+    // through q3_session_replace, so prompt kinds mix freely.
+    if (!b->s && !b->queue.empty()) {
+        const q3_request& first = b->t[b->queue.front()]->req.r;
+        static const uint32_t one_tok[1] = {0};
+        q3_request d{};
+        d.mode = Q3_MODE_CUSTOM_VOICE; d.text_ids = one_tok; d.n_text = 1;
+        d.speaker_id = first.language_id; d.language_id = first.language_id;       // any valid codec token id
+        d.opts = first.opts; d.opts.max_length = 1; d.opts.has_seed = 1; d.opts.seed = 0;
+        b->chunk_frames = first.opts.chunk_frames;
+        std::vector<q3_request> reqs((size_t)b->slots, d);
         q3_session* s = nullptr;
-        q3_status st = q3_session_create_reserved(b->m, reqs.data(), b->slots, b->frame_budget, b->prompt_budget, &s);
+        q3_status st = q3_session_create_reserved(b->m, reqs.data(), b->slots, b->frame_budget, b->prompt_budget > 16 ? b->prompt_budget : 16, &s);
         if (st == Q3_OK) st = q3_session_prefill(s);
-        if (st != Q3_OK) { if (s) q3_session_free(s); bat_fail(t, st); finished++; continue; }
+        if (st != Q3_OK) { if (s) q3_session_free(s); return st; }
         b->s = s;
-        for (int r = 1; r < b->slots; ++r) Q3C(session_idle_row(s, r));
-        t.state = Q3_TICKET_RUNNING; t.row = 0; b->owner[0] = id;
+        for (int r = 0; r < b->slots; ++r) Q3C(session_idle_row(s, r));
     }
-    b->queue.erase(b->queue.begin(), b->queue.begin() + (long)qpos);
     if (!b->s) { if (n_running) *n_running = 0; if (n_queued) *n_queued = 0; if (n_finished) *n_finished = finished; return Q3_OK; }
     auto fill = [&]() -> q3_status {               // free rows <- waiting requests
         for (int r = 0; r < b->slots && !b->queue.empty(); ++r) {
