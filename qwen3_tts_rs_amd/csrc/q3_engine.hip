@@ -891,7 +891,10 @@ struct DevPool {
         if (m != hipSuccess) return m;
         return lazy ? hipSuccess : hipStreamSynchronize(nullptr);
     }
-    ~DevPool() { for (void* p : ptrs) dev_free(p); }
+    ~DevPool() {
+        if (lazy) (void)hipStreamSynchronize(nullptr);      // a creation that failed midway: no zero-fill may outlive its block's ownership
+        for (void* p : ptrs) dev_free(p);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
