@@ -135,7 +135,7 @@ def test_null_handles_return_status_not_crash():
     from qwen3_tts_rs_amd import _lib
     L = _lib.lib
     null = ctypes.c_void_p(None)
-    i = ctypes.c_int(); sz = ctypes.c_size_t(); d = ctypes.c_double()
+    i = ctypes.c_int(); sz = ctypes.c_size_t(); d = ctypes.c_double(); t64 = ctypes.c_int64()
     calls = [
         lambda: L.q3_model_create(None, 0, ctypes.byref(null)),
         lambda: L.q3_model_set_tensor(None, b"x", 0, None, 0),
@@ -150,6 +150,14 @@ def test_null_handles_return_status_not_crash():
         lambda: L.q3_session_run(None, 1, None, None, None, None),
         lambda: L.q3_session_next_chunk(None, None, 0, ctypes.byref(sz), ctypes.byref(i)),
         lambda: L.q3_session_set_stream_mode(None, 1),
+        lambda: L.q3_session_create_reserved(None, None, 1, 8, 16, ctypes.byref(null)),
+        lambda: L.q3_session_replace(None, 0, None),
+        lambda: L.q3_session_next_chunk_row(None, 0, None, 0, ctypes.byref(sz), ctypes.byref(i)),
+        lambda: L.q3_batcher_create(None, 8, 64, 0, ctypes.byref(null)),
+        lambda: L.q3_batcher_submit(None, None, 0, ctypes.byref(t64)),
+        lambda: L.q3_batcher_step(None, 8, 1, ctypes.byref(i), ctypes.byref(i), ctypes.byref(i)),
+        lambda: L.q3_batcher_poll(None, 1, ctypes.byref(i), ctypes.byref(i), ctypes.byref(sz)),
+        lambda: L.q3_batcher_fetch(None, 1, None, 0, None, 0),
         lambda: L.q3_decode_codes(None, None, 0, None, None),
         lambda: L.q3_spk_create(None, 0, ctypes.byref(null)),
         lambda: L.q3_spk_finalize(None),
@@ -166,4 +174,4 @@ def test_null_handles_return_status_not_crash():
         st = f()
         assert st != 0, k
         assert len(L.q3_last_error()) > 0, k
-    L.q3_model_free(None); L.q3_session_free(None); L.q3_spk_free(None); L.q3_dp_free(None)     # free(NULL) is a no-op
+    L.q3_model_free(None); L.q3_session_free(None); L.q3_spk_free(None); L.q3_dp_free(None); L.q3_batcher_free(None)     # free(NULL) is a no-op
