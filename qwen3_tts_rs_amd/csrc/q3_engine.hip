@@ -1297,7 +1297,8 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
     if (wp.part) { t.qkv_part = wp.part; t.qkv_ssq = wp.ssq; t.qkv_S = wp.S; t.qkv_K = d.H; t.qkv_eps = d.eps; }
-    // Split-K projections (LinArgs::ksplit, k_gemv_sk2): o-proj and down-proj with N <= 2048 and K >= 2048 at 3 .. 16 rows
+    // Split-K projections (LinArgs::ksplit, k_gemv_sk2): o-proj and down-proj with N <= 2048 and K >= 2048 at 3 .. 16 rows (wide
+    // sessions: blocks of 16 rows, see below)
     // run as two K halves that meet in the output through order-independent atomic adds. The output buffer must hold zeros:
     // SUM is cleared by this layer's attention launch (its last reader was the previous down-proj), X by the gate/up
     // launch (its last reader is this layer's o-proj, as the residual).

@@ -8,7 +8,9 @@
 // three exact bf16 terms ONCE (all 512 threads, into LDS in MFMA B-operand order), and its eight waves — one 16-row weight
 // tile each — run the bf16x3 products against the shared LDS image, no cross-wave reduction at all. The K slices of a row
 // group are summed by a second, tiny launch (k_wide_epilogue) in fixed slice order — deterministic — which also applies
-// 1/rms, bias, residual, SiLU / SwiGLU. Two launches per projection; both are captured in the frame graph.
+// 1/rms, bias, residual, SiLU / SwiGLU. Two launches per projection; both are captured in the frame graph. For q|k|v the
+// second launch is skipped (launch_gemm_wide_partial): the decode-attention kernels add the slices of the 3 x 128 values
+// they need themselves (AttnArgs::qkv_part); the o / down projections of a wide session run on k_gemv_sk2 row blocks.
 //   y[m][n] = epi( sum_s sum_{k in slice s} (x[m][k] * norm_w[k]) * W[n][k]  /  sqrt(mean_k x[m][k]^2 + eps) )
 // Numerics: the same exact bf16x3 arithmetic as the GEMV family; only the summation order differs.
 #include "q3_kernels.h"
