@@ -963,6 +963,8 @@ static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) 
     // ... and since round 3 also the 128-multiples (four waves x 32 co x 128 t instead of 2 x 2 waves x 64 x 64): k = 7
     // 808 -> 788 and 1023 -> 989 us, the 768 -> 384 transposed conv 791 -> 708 us. Q3_CONV_TM4=1: the round-2 choice
     static const int geo = [] { const char* e = getenv("Q3_CONV_TM4"); return e ? atoi(e) : 2; }();
+    // (192 co x 64 t in ONE 3-wave workgroup — x staged once instead of twice, but twice the weight-fragment traffic per MFMA —
+    // measured 1125-1137 us against 1064-1074 for two workgroups of 96 co x 128 t: rejected)
     if (geo && K >= 2 && a.L >= 4096 && (a.cout == 192 || a.cout == 96)) return launch_bf16x3_v<K, 1, 4, 3, 1>(a, phases, st);
     if (geo >= 2 && K >= 2 && a.L >= 4096 && a.cout % 128 == 0 && big_tiles >= 192) {      // experiment: 4 waves x (32 co x 128 / 256 t)
         if (geo == 2) return launch_bf16x3_v<K, 1, 4, 4, 1>(a, phases, st);
