@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU-baseline sample (~12 s of oracle time)")
-    ap.add_argument("--cpu-frames-single", type=int, default=3, help="frames of the single-thread CPU-baseline sample (~10 s)")
+    ap.add_argument("--cpu-frames-single", type=int, default=8, help="frames of the single-thread CPU-baseline sample (~8 s)")
     ap.add_argument("--profile-frames", type=int, default=6)
     ap.add_argument("--ttfa-reps", type=int, default=5)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE.json side configurations (greedy, x-vector, 4k-token VoiceDesign, 0.6B single utterance)")
