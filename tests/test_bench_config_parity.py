@@ -171,6 +171,19 @@ def test_b32_b64_session_1_7b(gm17, B):
     _dump(f"bench_parity_1_7b_b{B}.json", {"oracle_near_ties": bad, "hip_vs_hip_flips": flips})
 
 
+def test_wide_session_is_deterministic(gm17):
+    """The wide-session kernels reduce through f32 atomics (two addends per element onto zeros: order-independent) and through
+    slice sums added in slice order: two runs of one 64-row session must give the same codes bit for bit, graph or eager."""
+    opts = q.SynthesisOptions(max_length=12, eos_token_id=None, seed=42)
+    utts = [bench_utt(i) for i in range(64)]
+    runs = []
+    for use_graph in (True, True, False):
+        s = gm17.session(utts, opts); s.prefill(); s.generate(12, use_graph=use_graph)
+        runs.append(np.stack([s.codes(b) for b in range(64)])); s.close()
+    np.testing.assert_array_equal(runs[0], runs[1])
+    np.testing.assert_array_equal(runs[0], runs[2])
+
+
 def test_teacher_forced_m8(gm17):
     """talker step + code predictor at M = 8 rows, full width: RMS-fused / SwiGLU / residual epilogues, the split attention
     and its merge, compared logit by logit with the oracle's values for 8 DIFFERENT sequences."""
