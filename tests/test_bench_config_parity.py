@@ -171,6 +171,49 @@ def test_b32_b64_session_1_7b(gm17, B):
     _dump(f"bench_parity_1_7b_b{B}.json", {"oracle_near_ties": bad, "hip_vs_hip_flips": flips})
 
 
+def test_native_batcher_1_7b(gm17):
+    """The native serving loop at full width with prompt kinds mixed: six CustomVoice fixture sequences with their own frame
+    limits (default sampling) and the x-vector / ICL voice-clone fixtures (greedy, their own options) go through four rows of
+    one q3_batcher session — every request is prefilled on the side and swapped in — and each must come back with the
+    oracle's codes for it."""
+    from make_golden_bench import clone_utts
+    ref = np.load(os.path.join(G, "bench_1_7b_codes.npz"))["default_codes"]
+    fx = np.load(os.path.join(G, "bench_1_7b_clone.npz"))
+    limits = [8, 12, 6, 10, 7, 9]
+    utts = []
+    for i, L in enumerate(limits):
+        u = bench_utt(i); u.max_length = L
+        utts.append(u)
+    clones = clone_utts(gm17.config)
+    for name in ("xvector", "icl"):
+        u = clones[name]; u.options = q.SynthesisOptions(max_length=4, temperature=0.0, eos_token_id=None, seed=42)
+        utts.insert(3 if name == "xvector" else 5, u)                  # in the middle of the queue, between CustomVoice requests
+    b = q.Batcher(gm17, slots=4, frame_budget=32, prompt_budget=int(fx["icl_prefill_len"][0]) + 8,
+                  options=q.SynthesisOptions(max_length=N_FRAMES, eos_token_id=None, seed=42))
+    res = b.run_all(utts, want_pcm=False, poll_frames=5)
+    b.close()
+    bad = 0
+    for u, (codes, _) in zip(utts, res):
+        if u.xvector is not None:
+            name = "icl" if u.ref_codes is not None else "xvector"
+            want = fx[f"{name}_codes"]
+            assert codes.shape == want.shape, (name, codes.shape)
+            if not (codes == want).all():
+                f = next(i for i in range(len(want)) if not (codes[i] == want[i]).all())
+                g = int(np.nonzero(codes[f] != want[f])[0][0])
+                m = float(fx[f"{name}_talker_top2_margin"][f]) if g == 0 else float(fx[f"{name}_cp_top2_margin"][f][g - 1])
+                assert m < MARGIN_EPS, (name, f, g, m)
+                bad += 1
+        else:
+            i = u.seed - 42; L = u.max_length
+            assert codes.shape == (L, 16), (i, codes.shape)
+            if not (codes == ref[i][:L]).all():
+                ok, rep = _adjudicate("1.7b", u, q.SynthesisOptions(max_length=L, eos_token_id=None, seed=42), codes, f"1_7b_batcher_seq{i}")
+                assert ok, rep
+                bad += 1
+    assert bad <= 1, bad
+
+
 def test_wide_session_is_deterministic(gm17):
     """The wide-session kernels reduce through f32 atomics (two addends per element onto zeros: order-independent) and through
     slice sums added in slice order: two runs of one 64-row session must give the same codes bit for bit, graph or eager."""
