@@ -1282,7 +1282,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     WidePartial wp{nullptr, nullptr, 0};
     if (!skip_qkv) {       // skip: the caller already filled b.QKV (code predictor layer 0, table rows)
         bool fused = false;
-        if (qkv_fuse && B > 32 && rows_per_seq == 1 && !s->legacy_attn && !s->profile && !s->debug && s->wide_ws) {
+        if (qkv_fuse && B >= gemm_wide_min_rows() && rows_per_seq == 1 && !s->legacy_attn && !s->profile && !s->debug && s->wide_ws) {
             LinArgs a2 = a; a2.ws = s->wide_ws; a2.ws_bytes = s->wide_ws_bytes;
             const hipError_t e = launch_gemm_wide_partial(a2, s->stream, &wp);
             if (e == hipSuccess && wp.S <= 8) fused = true;

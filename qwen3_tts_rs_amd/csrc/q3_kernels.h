@@ -155,6 +155,7 @@ struct AttnArgs {
 // the GEMM of launch_gemm_wide WITHOUT its slice-sum launch (EPI_NONE with a fused input norm only): the consumer adds
 // the slices. hipErrorNotSupported: shape outside the family.
 struct WidePartial { const float* part; const float* ssq; int S; };
+int gemm_wide_min_rows();      // rows from which launch_gemm_wide takes a projection (17; Q3_WIDE_GEMM_MIN = 17 .. 64: A/B aid)
 hipError_t launch_gemm_wide_partial(const LinArgs& a, hipStream_t st, WidePartial* out);
 constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
 // planes of positions [0, n_pos) of every (sequence, kv head) pair, from the f32 cache launch_qknorm_rope_kv filled

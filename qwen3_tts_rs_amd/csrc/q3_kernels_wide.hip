@@ -16,6 +16,7 @@
 #include "q3_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace q3 {
 
@@ -284,6 +285,10 @@ size_t gemm_wide_ws_bytes(int M, int N, int K, int epi) {
     return ((size_t)S * nmat * M * N + (size_t)S * M) * sizeof(float);
 }
 
+int gemm_wide_min_rows() {
+    static const int v = [] { const char* e = getenv("Q3_WIDE_GEMM_MIN"); const int x = e ? atoi(e) : 17; return x < 17 ? 17 : (x > 64 ? 64 : x); }();
+    return v;
+}
 static hipError_t gemm_wide_impl(const LinArgs& a, hipStream_t st, WidePartial* partial);
 hipError_t launch_gemm_wide_partial(const LinArgs& a, hipStream_t st, WidePartial* out) {
     if (!out || a.epi != EPI_NONE || !a.norm_w || a.bias || a.zero) return hipErrorNotSupported;
@@ -293,8 +298,11 @@ hipError_t launch_gemm_wide_partial(const LinArgs& a, hipStream_t st, WidePartia
 hipError_t launch_gemm_wide(const LinArgs& a, hipStream_t st) { return gemm_wide_impl(a, st, nullptr); }
 static hipError_t gemm_wide_impl(const LinArgs& a, hipStream_t st, WidePartial* partial) {
     const bool rms = a.norm_w != nullptr;
-    // (M <= 32 stays on k_gemv_wide: two column tiles do not pay for the second launch — 1.7B, B = 32: 6.17 vs 6.79 ms per frame)
-    if (a.tiled != 1 || a.M < 33 || a.M > 64 || a.N % 128 != 0 || a.K % 128 != 0 || a.Kpad != a.K || a.ldx % 4 != 0 || a.ldy % 4 != 0 || !a.ws ||
+    // (until the q|k|v slice sums went to the attention kernels and o / down to the row-block split-K kernel, M <= 32 stayed on
+    // k_gemv_wide: two column tiles did not pay for the second launch — B = 32: 6.17 vs 6.79 ms per frame. With those launches
+    // gone the GEMM wins from 17 rows: B = 20 4.850 -> 4.644, B = 24 4.881 -> 4.727, B = 32 5.045 -> 4.981. Q3_WIDE_GEMM_MIN=33
+    // restores the old split)
+    if (a.tiled != 1 || a.M < gemm_wide_min_rows() || a.M > 64 || a.N % 128 != 0 || a.K % 128 != 0 || a.Kpad != a.K || a.ldx % 4 != 0 || a.ldy % 4 != 0 || !a.ws ||
         (a.epi == EPI_RESID && a.ldr % 4 != 0) || ((a.epi == EPI_RESID || a.epi == EPI_SILU) && rms) || a.ksplit != 1)
         return hipErrorNotSupported;
     WideArgs w{};
