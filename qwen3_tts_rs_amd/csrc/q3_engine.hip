@@ -826,7 +826,16 @@ struct DevCache {
     size_t cached = 0, cap = 0;
     DevCache() { const char* e = getenv("Q3_DEV_CACHE_MB"); cap = (size_t)(e ? atol(e) : 32768) << 20; }
     static uint64_t key(int dev, size_t bytes) { return ((uint64_t)dev << 48) | (uint64_t)bytes; }
+    // size classes: 16 per octave (<= 6.25 % slack), so that the side sessions of a continuous-batching server — one KV extent
+    // per prompt length — reuse each other's blocks instead of leaving one cached block per distinct length
+    static size_t size_class(size_t bytes) {
+        if (bytes <= 4096) return (bytes + 255) & ~(size_t)255;
+        size_t p2 = 1; while ((p2 << 1) <= bytes) p2 <<= 1;
+        const size_t step = p2 >> 4;
+        return (bytes + step - 1) / step * step;
+    }
     hipError_t get(void** p, size_t bytes) {
+        bytes = size_class(bytes);
         int dev = 0; (void)hipGetDevice(&dev);
         const uint64_t k = key(dev, bytes);
         {
