@@ -353,11 +353,11 @@ def main():
             for i, L in enumerate(lens):
                 u = make_utt(i); u.max_length = L
                 mix.append(u)
-            def batcher_run(reqs, poll):            # the native serving loop (q3_batcher): queue -> rows, refilled every `poll` frames
+            def batcher_run(reqs, poll, want_pcm=False):            # the native serving loop (q3_batcher): queue -> rows, refilled every `poll` frames
                 bt = q.Batcher(model, slots=B, frame_budget=args.frames, prompt_budget=0, options=opts)
                 try:
                     ta = time.perf_counter()
-                    tickets = [bt.submit(u, want_pcm=False) for u in reqs]
+                    tickets = [bt.submit(u, want_pcm=want_pcm) for u in reqs]
                     steady = None                    # (frames, seconds) at the moment the queue ran dry: every row busy until then
                     while True:
                         running, queued, _ = bt.step(poll, use_graph)
@@ -371,6 +371,7 @@ def main():
                     bt.close()
             batcher_run(mix[:B + 2], 8)              # warm (graph, side-session shapes)
             fr_c, wall_c, steady = batcher_run(mix, 8)
+            fr_p, wall_p, steady_p = batcher_run(mix, 8, want_pcm=True)      # every finished row vocoded before its row is refilled
             wall_l = 0.0; fr_l = 0
             for k in range(0, n_req, B):
                 sl = model.session(mix[k:k + B], opts)
@@ -378,8 +379,9 @@ def main():
                 fr_l += sum(sl.frames(b)[0] for b in range(len(mix[k:k + B]))); sl.close()
             eos_mix = {"requests": n_req, "rows": B, "lengths": f"uniform {min(100, args.frames)}..{args.frames} frames (seed 2026), mean {float(np.mean(lens)):.0f}",
                        "continuous_frames_per_s": fr_c / wall_c, "continuous_steady_frames_per_s": steady[0] / steady[1],
+                       "continuous_with_vocoder_frames_per_s": fr_p / wall_p, "continuous_with_vocoder_steady_frames_per_s": steady_p[0] / steady_p[1],
                        "lockstep_frames_per_s": fr_l / wall_l, "frames": fr_c,
-                       "what": "generation loop only (q3_batcher with 8-frame steps; session opening and the prefill of swapped-in requests included, no vocoder; `steady` = until the queue ran dry, i.e. without the drain of the last rows); lockstep = sessions of `rows` requests "
+                       "what": "generation loop only (q3_batcher with 8-frame steps; session opening and the prefill of swapped-in requests included, no vocoder except in the `with_vocoder` figures, where every finished row is decoded to PCM before it is refilled; `steady` = until the queue ran dry, i.e. without the drain of the last rows); lockstep = sessions of `rows` requests "
                                "each running until its longest row ends"}
         except Exception as e:
             eos_mix = {"error": str(e)}
