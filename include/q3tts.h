@@ -318,6 +318,11 @@ q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int
                           double* avg_us);
 /* raw stream handle (hipStream_t) the session launches on */
 q3_status q3_session_stream(q3_session* s, void** stream);
+/* How this session's captured frame is replayed: *path = 0 nothing captured yet / eager launches, 1 = hipGraphLaunch, 2 = the
+ * library's own AQL queue with HIP's packet headers (agent-scope fences at every kernel boundary), 3 = own AQL queue without
+ * boundary fences (the kernels exchange activations write-through); *nodes = dispatch packets per frame (0 on paths 0 / 1).
+ * The reference replays nothing — every op is an eager candle launch (src/lib.rs:580-652); new here (environment: Q3_AQL). */
+q3_status q3_session_submit_info(q3_session* s, int* path, int* nodes);
 /* Algorithmic HBM bytes of one frame for this session's batch at KV length L */
 q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes);
 

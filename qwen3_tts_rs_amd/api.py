@@ -326,6 +326,13 @@ class Session:
         check(lib.q3_session_profile_shapes(self._h, buf, n.value, ctypes.byref(n), 1 if reset else 0))
         return [tuple(buf[i * 8:(i + 1) * 8]) for i in range(n.value)]
 
+    def submit_info(self) -> Tuple[int, int]:
+        """(path, packets per frame): 0 nothing captured / eager, 1 hipGraphLaunch, 2 own AQL queue with HIP's fences, 3 own AQL
+        queue without boundary fences (include/q3tts.h: q3_session_submit_info; environment Q3_AQL)."""
+        p = ctypes.c_int(); n = ctypes.c_int()
+        check(lib.q3_session_submit_info(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
     def frame_bytes(self, kv_len: int) -> Tuple[float, float]:
         w = ctypes.c_double(); k = ctypes.c_double()
         check(lib.q3_session_frame_bytes(self._h, kv_len, ctypes.byref(w), ctypes.byref(k)))

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Builds libq3tts.so (gfx950) in-tree: qwen3_tts_rs_amd/libq3tts.so
+# Incremental: an object is rebuilt when its source, one of the headers it includes, or ITS COMMAND LINE changed (the
+# command is kept beside the object as <name>.cmd, so a flag change never reuses a stale object).
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 # A/B aids: Q3_BUILD_OUT / Q3_BUILD_DIR = another library / object directory, Q3_BUILD_EXTRA = extra hipcc flags,
@@ -10,22 +12,33 @@ mkdir -p "$BUILD"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 PRELOAD="-mllvm -amdgpu-kernarg-preload-count=14"
 [ -n "$Q3_NO_PRELOAD" ] && PRELOAD=""
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC $PRELOAD -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value $Q3_BUILD_EXTRA"
+DEV_FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC $PRELOAD -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value $Q3_BUILD_EXTRA"
+HOST_FLAGS="-O2 -std=c++17 -fPIC -Wall"
 pids=()
-for f in q3_kernels_lm q3_kernels_gemv q3_kernels_wide q3_kernels_codec q3_kernels_prefill q3_engine q3_speaker q3_mimi; do
-  if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/q3_kernels.h" -nt "$BUILD/$f.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/$f.o" ]; then
-    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
+objs=()
+# compile <source> <object> <flags> <dependency headers...>
+compile() {
+  local src="$1" obj="$2" flags="$3"; shift 3
+  local cmd="$HIPCC $flags -c $src -o $obj" stale=0
+  objs+=("$obj")
+  [ -f "$obj" ] && [ -f "$obj.cmd" ] && [ "$(cat "$obj.cmd")" = "$cmd" ] || stale=1
+  for dep in "$src" "$@"; do [ "$dep" -nt "$obj" ] && stale=1; done
+  if [ $stale = 1 ]; then
+    rm -f "$obj.cmd"
+    ( $cmd && echo "$cmd" > "$obj.cmd" ) &
     pids+=($!)
   fi
+}
+API="$HERE/../../include/q3tts.h"
+for f in q3_kernels_lm q3_kernels_gemv q3_kernels_wide q3_kernels_codec q3_kernels_prefill q3_speaker q3_mimi; do
+  compile "$HERE/$f.hip" "$BUILD/$f.o" "$DEV_FLAGS" "$HERE/q3_kernels.h" "$HERE/q3_internal.h" "$API"
 done
-if [ ! -f "$BUILD/q3_io.o" ] || [ "$HERE/q3_io.cpp" -nt "$BUILD/q3_io.o" ] || [ "$HERE/q3_internal.h" -nt "$BUILD/q3_io.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/q3_io.o" ]; then
-  $HIPCC -O2 -std=c++17 -fPIC -Wall -c "$HERE/q3_io.cpp" -o "$BUILD/q3_io.o" &
-  pids+=($!)
-fi
-if [ ! -f "$BUILD/q3_dp.o" ] || [ "$HERE/q3_dp.cpp" -nt "$BUILD/q3_dp.o" ] || [ "$HERE/q3_internal.h" -nt "$BUILD/q3_dp.o" ] || [ "$HERE/../../include/q3tts.h" -nt "$BUILD/q3_dp.o" ]; then
-  $HIPCC -O2 -std=c++17 -fPIC -Wall -c "$HERE/q3_dp.cpp" -o "$BUILD/q3_dp.o" &
-  pids+=($!)
-fi
-for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "$BUILD/q3_kernels_lm.o" "$BUILD/q3_kernels_gemv.o" "$BUILD/q3_kernels_wide.o" "$BUILD/q3_kernels_codec.o" "$BUILD/q3_kernels_prefill.o" "$BUILD/q3_engine.o" "$BUILD/q3_speaker.o" "$BUILD/q3_mimi.o" "$BUILD/q3_io.o" "$BUILD/q3_dp.o" -ldl
+compile "$HERE/q3_engine.hip" "$BUILD/q3_engine.o" "$DEV_FLAGS" "$HERE/q3_kernels.h" "$HERE/q3_internal.h" "$HERE/q3_aql.h" "$API"
+compile "$HERE/q3_io.cpp" "$BUILD/q3_io.o" "$HOST_FLAGS" "$HERE/q3_internal.h" "$API"
+compile "$HERE/q3_dp.cpp" "$BUILD/q3_dp.o" "$HOST_FLAGS" "$HERE/q3_internal.h" "$API"
+compile "$HERE/q3_aql.cpp" "$BUILD/q3_aql.o" "$HOST_FLAGS" "$HERE/q3_aql.h"
+fail=0
+for p in "${pids[@]}"; do wait $p || fail=1; done
+[ $fail = 0 ] || { echo "build failed" >&2; exit 1; }
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT" "${objs[@]}" -ldl
 echo "built $OUT"

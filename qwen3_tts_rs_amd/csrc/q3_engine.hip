@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "q3_internal.h"
+#include "q3_aql.h"
 using namespace q3;
 
 // ------------------------------------------------------------------------------------------------
@@ -1210,6 +1211,9 @@ struct q3_session {
     float* logits_hist = nullptr; float* cp_logits_hist = nullptr; bool debug = false;
     bool prefilled = false; int frames_run = 0;
     hipGraphExec_t graph_exec = nullptr; hipGraph_t graph = nullptr;
+    // the captured frame as a packet program on the library's own AQL queue (q3_aql.cpp); nullptr: frames replay through
+    // hipGraphLaunch.  aql_mode: 0 = off, 1 = HIP's header policy (agent-scope fences on every packet), 2 = no fences
+    q3::AqlProgram* aql = nullptr; int aql_mode = 0; bool aql_tried = false;
     CodecWS cws;
     // overlapped segment decode (q3_session_run): vocoder segments run on their own stream while the frame loop continues
     hipStream_t dec_stream = nullptr; hipEvent_t dec_ev = nullptr;
@@ -1743,6 +1747,7 @@ q3_session::~q3_session() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (dec_stream) (void)hipStreamSynchronize(dec_stream);
     for (auto st : par_streams) (void)hipStreamSynchronize(st);
+    if (aql) q3::aql_program_destroy(aql);               // waits for its outstanding replays
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
     for (auto& ev : prof_pool) (void)hipEventDestroy(ev);
@@ -2102,11 +2107,32 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "hipStreamEndCapture: %s", hipGetErrorString(e));
         HIPC(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
     }
+    // Q3_AQL=1 / 2: replay the frame as packets on the library's own AQL queue (q3_aql.cpp) instead of hipGraphLaunch;
+    // Q3_AQL=0 / unset: hipGraphLaunch. A graph the converter cannot take stays on hipGraphLaunch (reason: Q3_AQL_VERBOSE=1).
+    if (use_graph && !s->aql && !s->aql_tried) {
+        s->aql_tried = true;
+        const char* e = getenv("Q3_AQL");
+        const int mode = e ? atoi(e) : 0;
+        if (mode > 0) {
+            q3::AqlPolicy pol; pol.fence = mode >= 2 ? 0 : 1;
+            std::string why;
+            s->aql = q3::aql_program_create(s->graph, s->m->device, pol, &why);
+            if (s->aql) s->aql_mode = mode >= 2 ? 2 : 1;
+            else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
+        }
+    }
+    const bool on_aql = use_graph && s->aql;
+    if (on_aql) HIPC(hipStreamSynchronize(s->stream));     // the queue is not ordered with the HIP stream: prefill / swaps must have landed
     bool eos_on = false;
     for (const auto& q : s->seq) eos_on = eos_on || q.req.opts.eos_token_id >= 0;
     const int check_every = 32;
     while (todo > 0) {
         const int burst = eos_on ? (todo < check_every ? todo : check_every) : todo;
+        if (on_aql) {
+            std::string why;
+            if (!q3::aql_submit(s->aql, burst, &why) || !q3::aql_wait(s->aql, &why)) return set_err(Q3_HIP_ERROR, "AQL frame submission: %s", why.c_str());
+            s->frames_run += burst;
+        } else
         for (int i = 0; i < burst; ++i) {
             if (use_graph) HIPC(hipGraphLaunch(s->graph_exec, s->stream));
             else Q3C(frame_launch(s));
@@ -3010,6 +3036,13 @@ extern "C" q3_status q3_debug_trace_read(q3_session* s, unsigned long long* stam
     return Q3_OK;
 }
 #endif
+
+extern "C" q3_status q3_session_submit_info(q3_session* s, int* path, int* nodes) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (path) *path = s->aql ? 1 + s->aql_mode : s->graph_exec ? 1 : 0;
+    if (nodes) *nodes = s->aql ? q3::aql_program_nodes(s->aql) : 0;
+    return Q3_OK;
+}
 
 extern "C" q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
