@@ -12,8 +12,9 @@ count so the work is identical across engines, default sampling (temperature 0.9
 Weak scaling: every GPU gets `--batch` utterances (config[3] of BASELINE.json: 64 utterances over 8
 GPUs = 8 per GPU); value = frames of ALL ranks / max-over-ranks time.
 
-Extra objects: "roofline" (dominant kernel = the bf16 GEMV family: algorithmic weight bytes per
-launch ÷ launch duration measured with HIP events on the session stream) and "cpu_baseline" (the
+Extra objects: "roofline" (frac = the whole captured frame against the HBM roof, measured by this
+run; the GEMV family alone — isolated replay, and inside the graph from the committed rocprof table —
+in sub-objects that say which is which) and "cpu_baseline" (the
 C oracle = port of the reference's candle-CPU F32 path, timed on this host's cores on a bounded
 sample of the same workload; rank 0, N=1 only).
 """
@@ -28,11 +29,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def rocprof_in_situ(avg_bytes_per_launch):
-    """GEMV-family launches inside the captured frame graph, from the committed rocprofv3 --kernel-trace --stats table of this
-    same command (profiles/r3_rocprof_kernel_stats_bench_b8.txt: `kernel calls avg_us ms_per_run` rows): calls-weighted mean
-    duration of the k_gemv_* symbols, priced with this run's algorithmic bytes per launch."""
-    for name in ("r3_rocprof_kernel_stats_bench_b8.txt", "r2_rocprof_kernel_stats_bench_b8_final.txt"):
+def committed_rocprof_table(avg_bytes_per_launch, model, batch):
+    """GEMV-family launches INSIDE the captured frame graph, from a rocprofv3 --kernel-trace table COMMITTED under profiles/
+    (`kernel calls avg_us ...` rows of a B = 8-only run of this command). It is NOT measured by this run — PMC / kernel
+    traces cannot be taken from inside the process — and says so: `measured_in_this_run` is False and `source` names the
+    file; the figure this run measures itself is roofline.frac (whole frame, in graph). Returned only for the
+    configuration the table was taken on (1.7B, 8 rows)."""
+    if model != "1.7b" or batch != 8:
+        return None
+    for name in ("r4_rocprof_kernel_stats_bench_b8.txt",):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -46,8 +51,8 @@ def rocprof_in_situ(avg_bytes_per_launch):
                     pass
         if calls:
             avg = us / calls
-            return {"source": f"profiles/{name}", "launches": int(calls), "avg_launch_us": avg, "gbps": avg_bytes_per_launch / avg / 1e3,
-                    "frac": avg_bytes_per_launch / avg / 1e3 / 8000.0}
+            return {"measured_in_this_run": False, "source": f"profiles/{name}", "launches": int(calls), "avg_launch_us": avg,
+                    "gbps": avg_bytes_per_launch / avg / 1e3, "frac": avg_bytes_per_launch / avg / 1e3 / 8000.0}
     return None
 
 
@@ -145,13 +150,23 @@ def main():
     use_graph = not args.no_graph
 
     phase_ms = []       # (create, run, close) wall per step: the timed step is all three
+    # the samples of every utterance land in host memory inside the timed step, as `synthesize` returns them
+    # (lib.rs:718-784): one pinned buffer per row, reused step after step (allocated once, outside the timing, like a
+    # server's output ring)
+    pcm_cap = args.frames * cfg.samples_per_frame
+    pinned = {}
+    def pcm_bufs(n):
+        if n not in pinned:
+            pinned[n] = torch.empty((n, pcm_cap), dtype=torch.float32).pin_memory()
+        return [(pinned[n][i].data_ptr(), pcm_cap) for i in range(n)]
+    pcm_out = pcm_bufs(len(utts))
 
     def one_step():
         ta = time.perf_counter()
         s = model.session(utts, opts)
         tb = time.perf_counter()
         try:
-            return s.run_timing_only(use_graph=use_graph)
+            return s.run_timing_only(use_graph=use_graph, pcm_out=pcm_out)
         finally:
             tc = time.perf_counter()
             s.close()
@@ -253,21 +268,33 @@ def main():
             traffic = tsum / tcnt
         elif pmc:                                                       # older profile without dims: plain mean over its shapes
             traffic = float(np.mean([v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc.values()]))
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+    # Which number is which:
+    #   frac / achieved  = the WHOLE FRAME inside the captured graph, measured by this run: (weight bytes of every launch of a
+    #                      frame + the KV bytes its attention reads at the mean context) / (generation wall time / frames);
+    #   step_frac        = the same bytes over the whole timed step (prefill, vocoder, PCM copy-out, session open / close);
+    #   isolated         = the GEMV family with each shape replayed ALONE from a hipGraph (no neighbours: the ceiling of the
+    #                      kernels, not what the frame gets);
+    #   gemv_in_graph    = the GEMV family inside the frame, from the COMMITTED rocprofv3 table (not measured by this run).
+    frame_s = stage["generation_ms"] / 1000.0 / args.frames
+    frame_gbps = (wbytes + kvbytes) / frame_s / 1e9
+    step_gbps = (wbytes + kvbytes) * args.frames / (ms_per_step / 1000.0) / 1e9
+    roofline = {"bound": "hbm", "achieved": frame_gbps, "peak": 8000.0, "unit": "GB/s", "frac": frame_gbps / 8000.0,
+                "frame_frac": frame_gbps / 8000.0, "step_frac": step_gbps / 8000.0,
                 "traffic": traffic, "traffic_source": os.path.basename(pmc_path) if (traffic and pmc_path) else None,
-                "kernel": "k_gemv_mfma / k_gemv_sk2 / k_gemv_mfma4 / k_gemv_lds (bf16-weight MFMA GEMV family, M = batch)",
-                "timing": "launch inventory from the engine (profiled frames); each shape replayed from a hipGraph over HBM-resident "
-                          "weight copies, HIP events on the launch stream, mean of 5 replays x 200 launches",
-                "launches_per_frame": launches, "avg_launch_us": tot_us / launches, "avg_bytes_per_launch": tot_bytes / launches,
-                "gemv_us_per_frame": tot_us, "per_shape": per_shape,
-                "in_situ": {"what": "HIP event pairs around every GEMV launch of real frames (EAGER launches in a profiling session): inflated by the "
-                                    "event records and the host launch path — a lower bound on the in-graph rate, not the figure to trust; the in-graph "
-                                    "in-situ figure is rocprof_in_situ below",
-                            "launches_per_frame": insitu_n / pf, "avg_launch_us": insitu_ms * 1e3 / max(insitu_n, 1),
-                            "gbps": insitu_bytes / max(insitu_ms, 1e-9) / 1e6, "frac": insitu_bytes / max(insitu_ms, 1e-9) / 1e6 / 8000.0},
-                "rocprof_in_situ": rocprof_in_situ(tot_bytes / launches),
-                "frame_weight_bytes": wbytes, "frame_kv_bytes": kvbytes,
-                "frame_model_gbps": (wbytes + kvbytes) / (stage["generation_ms"] / 1000.0 / args.frames) / 1e9}
+                "kernel": "the captured frame (one hipGraph replay = talker step + 15 code-predictor passes + sampler); dominant family: "
+                          "k_gemv_mfma / k_gemv_sk2 / k_gemv_mfma4 / k_gemv_lds (bf16-weight MFMA GEMV, M = batch)",
+                "timing": "frac: generation wall time of the timed steps / frames (graph replays on the session stream, host clock around "
+                          "the stream-synchronised loop); traffic: per GEMV launch, committed PMC passes",
+                "frame_weight_bytes": wbytes, "frame_kv_bytes": kvbytes, "frame_ms": frame_s * 1e3,
+                "isolated": {"what": "GEMV family, each shape replayed alone from a hipGraph over HBM-resident weight copies (launch inventory from "
+                                     "the engine's profiled frames), HIP events on the launch stream, mean of 5 replays x 200 launches",
+                             "gbps": achieved, "frac": achieved / 8000.0, "launches_per_frame": launches, "avg_launch_us": tot_us / launches,
+                             "avg_bytes_per_launch": tot_bytes / launches, "gemv_us_per_frame": tot_us, "per_shape": per_shape},
+                "eager_in_situ": {"what": "HIP event pairs around every GEMV launch of real frames (EAGER launches in a profiling session): inflated by "
+                                          "the event records and the host launch path — a lower bound, not the figure to trust",
+                                  "launches_per_frame": insitu_n / pf, "avg_launch_us": insitu_ms * 1e3 / max(insitu_n, 1),
+                                  "gbps": insitu_bytes / max(insitu_ms, 1e-9) / 1e6, "frac": insitu_bytes / max(insitu_ms, 1e-9) / 1e6 / 8000.0},
+                "gemv_in_graph": committed_rocprof_table(tot_bytes / launches, args.model, B)}
 
     # ---- single-utterance latency + streaming TTFA (config[2]) ----
     lat = {}
@@ -299,7 +326,8 @@ def main():
         try:
             uw = [make_utt(i) for i in range(bb)]
             for rep in range(2):            # first pass warms the session-shape cache
-                sw = model.session(uw, opts); tw0 = time.perf_counter(); tw = sw.run_timing_only(use_graph=use_graph); tw1 = time.perf_counter(); sw.close()
+                pw = pcm_bufs(bb)
+                sw = model.session(uw, opts); tw0 = time.perf_counter(); tw = sw.run_timing_only(use_graph=use_graph, pcm_out=pw); tw1 = time.perf_counter(); sw.close()
             wide[str(bb)] = {"frames_per_s": tw.generation_frames / (tw1 - tw0), "ms_per_frame": tw.generation_ms / args.frames,
                              "stage_ms": {"prefill_ms": tw.prefill_ms, "generation_ms": tw.generation_ms, "decode_ms": tw.decode_ms}}
         except Exception as e:
@@ -310,9 +338,9 @@ def main():
     if world == 1 and not args.no_other_configs and args.workload == "customvoice" and args.sampling == "default":
         def timed(mdl, uu, oo, reps=1):
             sw = mdl.session(uu, oo); sw.run_timing_only(use_graph=use_graph); sw.close()           # warm (graph capture, session-shape cache)
-            best = None
+            best = None; po = pcm_bufs(len(uu))
             for _ in range(reps):
-                sw = mdl.session(uu, oo); ta = time.perf_counter(); tt = sw.run_timing_only(use_graph=use_graph); wall = time.perf_counter() - ta; sw.close()
+                sw = mdl.session(uu, oo); ta = time.perf_counter(); tt = sw.run_timing_only(use_graph=use_graph, pcm_out=po); wall = time.perf_counter() - ta; sw.close()
                 if best is None or wall < best[0]:
                     best = (wall, tt)
             wall, tt = best
@@ -443,7 +471,7 @@ def main():
                    "weights": "bf16", "activations_kv": "f32",
                    "kv": "f32, in place (2x the bytes of the reference GPU path's bf16 cache, kv_cache.rs:234-310: the parity contract is the CPU F32 path)",
                    "hip_graph": use_graph, "prefill": args.workload, "sampling": args.sampling,
-                   "pcm_copy_out": False},     # PCM stays in HBM inside the timed step (39 MB / step D2H at B = 8 would add < 0.5 %)
+                   "pcm_copy_out": True},      # every utterance's samples are copied to (pinned) host memory inside the timed step
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,
                                                         "gbps": (bcast_bytes / bcast_s / 1e9) if bcast_s > 0 else None},

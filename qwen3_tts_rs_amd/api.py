@@ -198,6 +198,8 @@ class Session:
         self.options = options
         self._keep = []
         self._ref_frames = [0 if u.ref_codes is None else int(np.asarray(u.ref_codes).reshape(-1, 16).shape[0]) for u in utts]
+        self._frame_budget = int(frame_budget)
+        self._row_limit = [self._limit_of(u) for u in utts]       # frames a row can reach: sizes the PCM buffers of run()
         reqs = (CRequest * self.B)()
         for i, u in enumerate(utts):
             self._fill(reqs[i], u)
@@ -213,6 +215,10 @@ class Session:
     def _fill(self, r, u: Utterance):
         fill_request(r, u, self.options, self._keep)
 
+    def _limit_of(self, u: Utterance) -> int:
+        lim = u.max_length if u.max_length is not None else (u.options or self.options).max_length
+        return max(int(lim), int(self.options.max_length), self._frame_budget)
+
     def close(self):
         if getattr(self, "_h", None):
             lib.q3_session_free(self._h); self._h = None
@@ -223,8 +229,12 @@ class Session:
         """Continuous batching (q3_session_replace): row b — normally a finished one whose codes / PCM have been fetched — starts
         over with `utt` at its frame 0 while the other rows keep going; they are bit-for-bit unaffected."""
         r = CRequest()
-        self._fill(r, utt)
+        keep = []                                   # the C side copies the request: nothing to keep beyond the call
+        fill_request(r, utt, self.options, keep)
         check(lib.q3_session_replace(self._h, int(b), ctypes.byref(r)))
+        del keep
+        if b < len(self._row_limit):
+            self._row_limit[b] = self._limit_of(utt)
         self._ref_frames[b] = 0 if utt.ref_codes is None else int(np.asarray(utt.ref_codes).reshape(-1, 16).shape[0])
 
     def next_chunk_row(self, b: int) -> Tuple[Optional[AudioBuffer], bool]:
@@ -266,20 +276,29 @@ class Session:
     def run(self, use_graph: bool = True) -> Tuple[List[AudioBuffer], SynthesisTiming]:
         """synthesize_with_timing (lib.rs:425-501) for the batch."""
         spf = self.model.config.samples_per_frame
-        cap = self.options.max_length * spf
-        bufs = [np.zeros(cap, dtype=np.float32) for _ in range(self.B)]
+        capl = [(self._row_limit[i] + self._ref_frames[i]) * spf for i in range(self.B)]      # a row's own limit may exceed the session's
+        bufs = [np.zeros(c, dtype=np.float32) for c in capl]
         ptrs = (ctypes.c_void_p * self.B)(*[b.ctypes.data_as(ctypes.c_void_p) for b in bufs])
-        caps = (ctypes.c_size_t * self.B)(*([cap] * self.B))
+        caps = (ctypes.c_size_t * self.B)(*capl)
         ns = (ctypes.c_size_t * self.B)()
         t = CTiming()
         check(lib.q3_session_run(self._h, 1 if use_graph else 0, ptrs, caps, ns, ctypes.byref(t)))
         audio = [AudioBuffer(bufs[i][:ns[i]].copy()) for i in range(self.B)]
         return audio, SynthesisTiming(t.prefill_ms, t.generation_ms, t.generation_frames, t.decode_ms)
 
-    def run_timing_only(self, use_graph: bool = True) -> SynthesisTiming:
+    def run_timing_only(self, use_graph: bool = True, pcm_out=None) -> SynthesisTiming:
+        """`run` without building AudioBuffers. pcm_out = None: the samples stay in HBM; pcm_out = [(address, capacity in
+        samples)] per row (e.g. rows of one pinned host tensor, reused step after step): every row's samples are copied to
+        the host inside the call, as `synthesize` hands them back (lib.rs:718-784)."""
         ns = (ctypes.c_size_t * self.B)()
         t = CTiming()
-        check(lib.q3_session_run(self._h, 1 if use_graph else 0, None, None, ns, ctypes.byref(t)))
+        ptrs = caps = None
+        if pcm_out is not None:
+            assert len(pcm_out) == self.B
+            ptrs = (ctypes.c_void_p * self.B)(*[int(a) for a, _ in pcm_out])
+            caps = (ctypes.c_size_t * self.B)(*[int(c) for _, c in pcm_out])
+        check(lib.q3_session_run(self._h, 1 if use_graph else 0, ptrs, caps, ns, ctypes.byref(t)))
+        self.last_samples = [int(x) for x in ns]
         return SynthesisTiming(t.prefill_ms, t.generation_ms, t.generation_frames, t.decode_ms)
 
     # ---- stage taps (parity tests) ----
@@ -627,7 +646,7 @@ class Qwen3TTS:
         Returns (AudioBuffer, codes)."""
         s = self.session([Utterance(text_ids, language=language, xvector=xvector, ref_codes=ref_codes, ref_text_ids=ref_text_ids)], options)
         try:
-            s.prefill(); s.generate(s.options.max_length)
+            s.prefill(); s.generate(max(s._row_limit))
             return AudioBuffer(s.decode(0)), s.codes(0)
         finally:
             s.close()

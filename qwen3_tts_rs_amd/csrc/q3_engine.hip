@@ -2220,6 +2220,7 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     nq.row_base = row0; nq.trail_base = hv[0]; nq.pad_row = hv[2];
     nq.start_run = s->frames_run; nq.limit = limit; nq.n_frames = 0; nq.done = false; nq.stream_pos = 0; nq.req.opts.max_length = limit;
     s->seq[b] = nq;
+    if (b == 0) s->stream_pos = 0;       // q3_session_next_chunk (the row-0 streaming call) starts over with the new utterance too
     s->codes_host_valid = false;
     lap("copies");
     side.reset();
@@ -2286,6 +2287,10 @@ extern "C" q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget,
     if (!m->finalized) return set_err(Q3_INVALID_ARG, "model not finalized");
     if (slots < 1 || slots > Q3_MAX_BATCH) return set_err(Q3_UNSUPPORTED, "q3_batcher_create: %d rows unsupported (1..%d)", slots, Q3_MAX_BATCH);
     if (frame_budget < 1 || prompt_budget < 0) return set_err(Q3_INVALID_ARG, "q3_batcher_create: frame_budget must be >= 1, prompt_budget >= 0");
+    {   // the session the first step opens: max_seq = max(prompt_budget, 16) + frame_budget + 1 positions of the RoPE table
+        const long need = (long)(prompt_budget > 16 ? prompt_budget : 16) + frame_budget + 1;
+        if (need > m->rope_len) return set_err(Q3_KV_OVERFLOW, "q3_batcher_create: prompt_budget + frame_budget = %ld positions exceed the RoPE table (%d)", need, m->rope_len);
+    }
     std::unique_ptr<q3_batcher> b(new q3_batcher());
     b->m = m; b->slots = slots; b->frame_budget = frame_budget; b->prompt_budget = prompt_budget;
     b->owner.assign(slots, -1);
@@ -2340,18 +2345,30 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
     // copies of what may be a 4k-token prompt), frozen before the first frame. Every request, the first included, then enters
     // through q3_session_replace, so prompt kinds mix freely.
     if (!b->s && !b->queue.empty()) {
+        // The idle rows are built from fixed, known-valid values — never from a queued request: a malformed first request must
+        // fail alone, at its own q3_session_replace below, not wedge the queue by failing the session every step.
         const q3_request& first = b->t[b->queue.front()]->req.r;
         static const uint32_t one_tok[1] = {0};
         q3_request d{};
         d.mode = Q3_MODE_CUSTOM_VOICE; d.text_ids = one_tok; d.n_text = 1;
-        d.speaker_id = first.language_id; d.language_id = first.language_id;       // any valid codec token id
-        d.opts = first.opts; d.opts.max_length = 1; d.opts.has_seed = 1; d.opts.seed = 0;
-        b->chunk_frames = first.opts.chunk_frames;
+        d.speaker_id = 0; d.language_id = 0;                                       // codec token 0: valid in every vocabulary
+        d.opts.temperature = 0.9; d.opts.top_p = 0.9; d.opts.repetition_penalty = 1.05; d.opts.top_k = 50;      // SynthesisOptions::default (lib.rs:1786-1836)
+        d.opts.eos_token_id = -1; d.opts.min_new_tokens = 2; d.opts.max_length = 1; d.opts.has_seed = 1; d.opts.seed = 0;
+        b->chunk_frames = first.opts.chunk_frames >= 1 ? first.opts.chunk_frames : 10;       // the one option a session shares
+        d.opts.chunk_frames = b->chunk_frames;
         std::vector<q3_request> reqs((size_t)b->slots, d);
         q3_session* s = nullptr;
         q3_status st = q3_session_create_reserved(b->m, reqs.data(), b->slots, b->frame_budget, b->prompt_budget > 16 ? b->prompt_budget : 16, &s);
         if (st == Q3_OK) st = q3_session_prefill(s);
-        if (st != Q3_OK) { if (s) q3_session_free(s); return st; }
+        if (st != Q3_OK) {
+            // nothing a request could have caused (the budgets were checked at q3_batcher_create): a device failure. The head
+            // ticket takes the error so that a serving loop sees it on a ticket and the queue moves on.
+            if (s) q3_session_free(s);
+            const int64_t id = b->queue.front(); b->queue.erase(b->queue.begin());
+            bat_fail(*b->t[id], st);
+            if (n_running) *n_running = 0; if (n_queued) *n_queued = (int)b->queue.size(); if (n_finished) *n_finished = 1;
+            return st;
+        }
         b->s = s;
         for (int r = 0; r < b->slots; ++r) Q3C(session_idle_row(s, r));
     }
@@ -2592,6 +2609,9 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
             }
             auto ws_of = [&](int k) -> CodecWS& { return k == 0 ? s->cws : s->par_ws[(size_t)k - 1]; };
             auto st_of = [&](int k) { return k == 0 ? s->stream : s->par_streams[(size_t)k - 1]; };
+            if (pcm_host)
+                for (int b = 0; b < s->B; ++b)
+                    if (pcm_host[b] && s->seq[b].n_frames && (!cap || cap[b] < (size_t)s->seq[b].n_frames * spf)) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
             for (int b0 = 0; b0 < s->B; b0 += conc) {
                 const int nb = (s->B - b0) < conc ? (s->B - b0) : conc;
                 for (int k = 0; k < nb; ++k) {
@@ -2602,15 +2622,12 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
                     Q3C(codec_reserve(s->m, ws_of(k), T));
                     HIPC(hipMemcpyAsync(ws_of(k).frames, s->codes + (size_t)b * s->max_frames * 16, (size_t)T * 16 * 4, hipMemcpyDeviceToDevice, st_of(k)));
                     Q3C(codec_decode_dev(s->m, ws_of(k), T, st_of(k), nullptr));
+                    // the samples leave for the host on the utterance's own stream, beside the other utterances' decodes
+                    // (synthesize returns host samples, lib.rs:718-784); pinned caller buffers make this a true async copy
+                    if (pcm_host && pcm_host[b])
+                        HIPC(hipMemcpyAsync(pcm_host[b], ws_of(k).pcm, (size_t)T * spf * 4, hipMemcpyDeviceToHost, st_of(k)));
                 }
-                for (int k = 0; k < nb; ++k) {
-                    const int b = b0 + k, T = s->seq[b].n_frames;
-                    HIPC(hipStreamSynchronize(st_of(k)));
-                    if (T && pcm_host && pcm_host[b]) {
-                        if (!cap || cap[b] < (size_t)T * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
-                        HIPC(hipMemcpy(pcm_host[b], ws_of(k).pcm, (size_t)T * spf * 4, hipMemcpyDeviceToHost));
-                    }
-                }
+                for (int k = 0; k < nb; ++k) HIPC(hipStreamSynchronize(st_of(k)));
             }
         } else
         for (int b = 0; b < s->B; ++b) {
