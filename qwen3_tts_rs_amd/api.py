@@ -606,6 +606,17 @@ class Qwen3TTS:
         m.finalize()
         return m
 
+    def kv_pool_limit(self, max_pages: int):
+        """Cap of the model's KV page pool (q3_model_kv_pool_limit; 0 = HBM is the limit). A session that needs a page beyond
+        it fails with Q3_KV_OVERFLOW — the reference's cache-overflow bail (kv_cache.rs:293-300)."""
+        check(lib.q3_model_kv_pool_limit(self._h, int(max_pages)))
+
+    def kv_pool_info(self) -> dict:
+        """Page geometry and occupancy of the model's KV pool (q3_model_kv_pool_info)."""
+        pp = ctypes.c_int(); pb = ctypes.c_size_t(); tot = ctypes.c_int(); use = ctypes.c_int(); peak = ctypes.c_int()
+        check(lib.q3_model_kv_pool_info(self._h, ctypes.byref(pp), ctypes.byref(pb), ctypes.byref(tot), ctypes.byref(use), ctypes.byref(peak)))
+        return {"page_positions": pp.value, "page_bytes": pb.value, "pages_total": tot.value, "pages_in_use": use.value, "pages_peak": peak.value}
+
     def arena(self) -> Tuple[int, int]:
         p = ctypes.c_void_p(); n = ctypes.c_size_t()
         check(lib.q3_model_arena(self._h, ctypes.byref(p), ctypes.byref(n)))

@@ -375,9 +375,9 @@ AqlProgram* aql_program_create(hipGraph_t graph, int device, const AqlPolicy& po
             else { *why = std::string(nm) + " uses " + k + " (not provided by this submission path)"; return nullptr; }
         }
         hsa_kernel_dispatch_packet_t pk; memset(&pk, 0, sizeof pk);
-        const int fence = pol.fence ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
+        const int acq = pol.acquire ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, rel = pol.release ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
         pk.header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                               (fence << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (fence << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+                               (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         pk.setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
         pk.workgroup_size_x = (uint16_t)kp.blockDim.x; pk.workgroup_size_y = (uint16_t)kp.blockDim.y; pk.workgroup_size_z = (uint16_t)kp.blockDim.z;
         pk.grid_size_x = kp.gridDim.x * kp.blockDim.x; pk.grid_size_y = kp.gridDim.y * kp.blockDim.y; pk.grid_size_z = kp.gridDim.z * kp.blockDim.z;

@@ -11,7 +11,7 @@ struct AqlProgram;
 // Per-node policy of a program, chosen by the engine when it converts a captured frame:
 //   fence: 1 = agent-scope acquire / release at the kernel boundary (what HIP writes), 0 = none — legal only between nodes
 //          whose cross-kernel traffic is write-through (sc1) on the producer and L1-bypassing (sc1) on the consumer.
-struct AqlPolicy { int fence = 1; };
+struct AqlPolicy { int fence = 1; int acquire = 1, release = 1; };      // acquire / release: the two halves of `fence`, set separately by probes
 
 // Converts a captured, purely linear kernel graph into a packet program for `device`. Returns nullptr and fills *why when
 // the graph holds anything the converter does not handle (the caller then stays on hipGraphLaunch).

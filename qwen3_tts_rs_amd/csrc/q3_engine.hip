@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -152,9 +153,64 @@ struct ResUnitW { const float *a1, *ib1, *c1w, *c1b, *a2, *ib2, *c2w, *c2b; };
 struct DecBlockW { const float *a, *ib, *tw, *tb; ResUnitW res[3]; int cin, cout, rate; };
 struct UpW { const float *tw, *tb, *dww, *dwb, *nw, *nb, *p1w, *p1b, *p2w, *p2b, *gamma; int ratio; };
 
+// ------------------------------------------------------------------------------------------------
+// Paged talker KV (north_star: "in-place paged KV in 288 GB HBM3E"; replaces the per-call preallocated cache of
+// kv_cache.rs:234-310 and its overflow bail :293-300). One pool per model: pages of KV_PAGE_POS positions x every layer
+// and KV head (q3_kernels.h), carved from slabs that are hipMalloc'ed on demand and kept for the model's lifetime. Sessions
+// take pages as their rows cross page boundaries and hand them back when a row is replaced or the session ends, so a
+// 4k-position prompt and a ten-position prompt draw on the same memory, and a continuous-batching swap RELINKS the
+// prefilled pages of the side session into the row instead of copying extents. Pages are never cleared: the attention
+// kernels read a position only after it was written.
+// ------------------------------------------------------------------------------------------------
+struct KvPool {
+    std::mutex mu;
+    size_t page_floats = 0;               // 2 * n_layers * nkv * KV_PAGE_POS * HEAD_DIM
+    std::vector<void*> slabs; std::vector<float*> free_pages;
+    int total = 0, in_use = 0, peak = 0, limit = 0;       // pages; limit 0 = bounded by HBM only
+    size_t page_bytes() const { return page_floats * sizeof(float); }
+    // n pages or none: hipErrorOutOfMemory when the limit (q3_model_kv_pool_limit) or the device says no
+    hipError_t take(int n, std::vector<float*>& out) {
+        std::lock_guard<std::mutex> g(mu);
+        if (n <= 0) return hipSuccess;
+        if (limit > 0 && in_use + n > limit) return hipErrorOutOfMemory;
+        if ((int)free_pages.size() < n) {
+            int grow = n - (int)free_pages.size();
+            const int slab_min = (int)(((size_t)1 << 30) / page_bytes()) + 1;      // ~1 GiB per slab: few hipMallocs, none in steady state
+            if (grow < slab_min) grow = slab_min;
+            if (limit > 0 && total + grow > limit) grow = limit - total;
+            if (grow < n - (int)free_pages.size()) return hipErrorOutOfMemory;
+            void* slab = nullptr;
+            hipError_t e = hipMalloc(&slab, (size_t)grow * page_bytes());
+            if (e != hipSuccess && grow > n - (int)free_pages.size()) {            // a full slab does not fit any more: just what is needed
+                (void)hipGetLastError();
+                grow = n - (int)free_pages.size();
+                e = hipMalloc(&slab, (size_t)grow * page_bytes());
+            }
+            if (e != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+            slabs.push_back(slab);
+            for (int i = grow - 1; i >= 0; --i) free_pages.push_back((float*)slab + (size_t)i * page_floats);
+            total += grow;
+        }
+        for (int i = 0; i < n; ++i) { out.push_back(free_pages.back()); free_pages.pop_back(); }
+        in_use += n; if (in_use > peak) peak = in_use;
+        return hipSuccess;
+    }
+    void give(std::vector<float*>& pages) {
+        std::lock_guard<std::mutex> g(mu);
+        for (float* p : pages) free_pages.push_back(p);
+        in_use -= (int)pages.size();
+        pages.clear();
+    }
+    ~KvPool() { for (void* s : slabs) (void)hipFree(s); }
+};
+
 struct q3_model {
     q3_config cfg{};
     int device = 0;
+    KvPool kv_pool;
+    // sessions hold pages, streams and weights of their model: q3_model_free with sessions still alive only marks the model,
+    // the last q3_session_free destroys it (a host that tears down in the wrong order must not crash)
+    std::atomic<int> live_sessions{0}; std::atomic<bool> zombie{false};
     std::vector<Slot> slots;
     std::unordered_map<std::string, int> index;
     char* arena = nullptr; size_t arena_bytes = 0;
@@ -421,6 +477,7 @@ extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model*
     if (device < 0 || device >= ndev) return set_err(Q3_INVALID_ARG, "device %d not available (%d visible)", device, ndev);
     HIPC(hipSetDevice(device));
     std::unique_ptr<q3_model> m(new q3_model());
+    m->kv_pool.page_floats = (size_t)2 * cfg->n_layers * cfg->n_kv_heads * KV_PAGE_POS * HEAD_DIM;
     m->cfg = *cfg; m->device = device;
     build_manifest(m.get());
     HIPC(hipMalloc((void**)&m->arena, m->arena_bytes));
@@ -429,14 +486,40 @@ extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model*
     return Q3_OK;
 }
 
+static void model_destroy(q3_model* m);
 extern "C" void q3_model_free(q3_model* m) {
     if (!m) return;
+    if (m->live_sessions.load() > 0) { m->zombie.store(true); return; }
+    model_destroy(m);
+}
+static void model_destroy(q3_model* m) {
     if (m->device < 0) { delete m; return; }
     hipSetDevice(m->device);
     hipFree(m->arena); hipFree(m->rope_cos); hipFree(m->rope_sin); hipFree(m->derived); hipFree(m->wpk_arena);
     hipFree((void*)m->rest_cbs_dev); hipFree((void*)m->cp_embs_dev); hipFree(m->proj_tabs); hipFree(m->qkv0_tabs);
     for (hipStream_t st : m->idle_streams) (void)hipStreamDestroy(st);
     delete m;
+}
+
+// Paged KV pool of the model (KvPool above). limit: the most pages the pool may ever hold (0 = HBM is the limit); a session
+// that needs a page beyond it fails with Q3_KV_OVERFLOW — the reference's KV-overflow bail (kv_cache.rs:293-300).
+extern "C" q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages) {
+    if (!m || m->device < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: no device model");
+    if (max_pages < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: negative limit");
+    std::lock_guard<std::mutex> g(m->kv_pool.mu);
+    if (max_pages > 0 && max_pages < m->kv_pool.total) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: the pool already holds %d pages", m->kv_pool.total);
+    m->kv_pool.limit = max_pages;
+    return Q3_OK;
+}
+extern "C" q3_status q3_model_kv_pool_info(q3_model* m, int* page_positions, size_t* page_bytes, int* pages_total, int* pages_in_use, int* pages_peak) {
+    if (!m || m->device < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_info: no device model");
+    std::lock_guard<std::mutex> g(m->kv_pool.mu);
+    if (page_positions) *page_positions = KV_PAGE_POS;
+    if (page_bytes) *page_bytes = m->kv_pool.page_bytes();
+    if (pages_total) *pages_total = m->kv_pool.total;
+    if (pages_in_use) *pages_in_use = m->kv_pool.in_use;
+    if (pages_peak) *pages_peak = m->kv_pool.peak;
+    return Q3_OK;
 }
 
 extern "C" q3_status q3_model_config(const q3_model* m, q3_config* out) {
@@ -901,10 +984,12 @@ struct DevPool {
         if (m != hipSuccess) return m;
         return lazy ? hipSuccess : hipStreamSynchronize(nullptr);
     }
-    ~DevPool() {
+    void release_all() {
         if (lazy) (void)hipStreamSynchronize(nullptr);      // a creation that failed midway: no zero-fill may outlive its block's ownership
         for (void* p : ptrs) dev_free(p);
+        ptrs.clear(); lazy = false;
     }
+    ~DevPool() { release_all(); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1201,6 +1286,9 @@ struct q3_session {
     float* wide_ws = nullptr; size_t wide_ws_bytes = 0;       // slice sums of the wide-session GEMM (B > 16; q3_kernels_wide.hip)
     float *kcache = nullptr, *vcache = nullptr, *ckcache = nullptr, *cvcache = nullptr;
     size_t kv_layer_stride = 0, ckv_layer_stride = 0;
+    // paged talker KV (the default; Q3_KV_CONTIGUOUS=1 keeps one extent per row: A/B aid): kv_table[b][KV_MAX_PAGES] page
+    // pointers on the device (what the attention kernels read), kv_rows[b] = the pages row b holds, in position order
+    bool paged = false; unsigned long long* kv_table = nullptr; std::vector<std::vector<float*>> kv_rows;
     float *rows = nullptr, *embeds = nullptr, *xvec = nullptr; int n_rows_total = 0;
     // prefill scratch, session-lifetime (no hipMalloc / hipFree and no extra stream syncs on the time-to-first-audio path)
     uint32_t* ids_dev = nullptr; int *tr_dev = nullptr, *ci_dev = nullptr; float *proj_e = nullptr, *proj_h = nullptr;
@@ -1277,10 +1365,45 @@ static hipError_t run_linear(q3_session* s, const LinArgs& a_in) {
     return e != hipSuccess ? e : e2;
 }
 
+// Paged KV bookkeeping (KvPool): row b gets the pages for positions [0, n_pos) it does not hold yet; the new table entries
+// are queued on the session's stream ahead of the kernels that read them (hipMemcpyAsync stages pageable sources before it
+// returns; kv_rows[b] never reallocates: reserved to KV_MAX_PAGES at creation).
+static q3_status kv_reserve_row(q3_session* s, int b, int n_pos) {
+    if (!s->paged) return Q3_OK;
+    if (n_pos > KV_MAX_PAGES * KV_PAGE_POS) return set_err(Q3_KV_OVERFLOW, "%d positions exceed a row's page table (%d)", n_pos, KV_MAX_PAGES * KV_PAGE_POS);
+    std::vector<float*>& row = s->kv_rows[(size_t)b];
+    const int need = (n_pos + KV_PAGE_POS - 1) / KV_PAGE_POS, have = (int)row.size();
+    if (need <= have) return Q3_OK;
+    KvPool& pool = s->m->kv_pool;
+    if (pool.take(need - have, row) != hipSuccess)
+        return set_err(Q3_KV_OVERFLOW, "KV page pool exhausted: row %d needs %d more page(s) of %d positions (pool: %d of %d in use, limit %d)",
+                       b, need - have, KV_PAGE_POS, pool.in_use, pool.total, pool.limit);
+    static_assert(sizeof(float*) == sizeof(unsigned long long), "page table entries are 64-bit pointers");
+    HIPC(hipMemcpyAsync(s->kv_table + (size_t)b * KV_MAX_PAGES + have, row.data() + have, (size_t)(need - have) * 8, hipMemcpyHostToDevice, s->stream));
+    return Q3_OK;
+}
+// pages for what the next `frames` frames of every row can touch: frame f of a row writes position prefill_len + f, a row
+// that reached its limit keeps rewriting position prefill_len + limit (k_sample freezes its counters)
+static q3_status kv_reserve_frames(q3_session* s, int frames) {
+    if (!s->paged) return Q3_OK;
+    for (int b = 0; b < s->B; ++b) {
+        const SeqInfo& q = s->seq[(size_t)b];
+        int upto = s->frames_run - q.start_run + frames;
+        if (upto > q.limit) upto = q.limit;
+        if (upto < 0) upto = 0;
+        Q3C(kv_reserve_row(s, b, q.prefill_len + upto + 1));
+    }
+    return Q3_OK;
+}
+static void kv_release_row(q3_session* s, int b) {        // the caller has drained every stream that may still touch the row
+    if (s->paged && !s->kv_rows[(size_t)b].empty()) s->m->kv_pool.give(s->kv_rows[(size_t)b]);
+}
+
 // one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
 static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf& b, float* kc, float* vc, int max_seq,
                           const int* pos_dev, int pos_static, int n_splits, int rows_per_seq = 1, bool skip_qkv = false,
-                          const CpGatherArgs* fold = nullptr) {     // fold: this layer's attention does the pass's gather
+                          const CpGatherArgs* fold = nullptr,       // fold: this layer's attention does the pass's gather
+                          int paged_layer = -1) {                   // >= 0: the talker's paged cache, this layer's index (kc / vc / max_seq unused)
     const q3_model* m = s->m;
     // B = number of activation ROWS of this step: one per sequence, or rows_per_seq consecutive positions per
     // sequence (chunked prefill, the code predictor's 2-token first pass)
@@ -1309,13 +1432,17 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = pos_dev; t.pos_static = pos_static;
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
+    if (paged_layer >= 0) {
+        t.kv_pages = s->kv_table; t.kv_layer_off = (size_t)paged_layer * d.nkv * KV_PAGE_POS * HEAD_DIM;
+        t.kv_vdelta = (size_t)d.layers * d.nkv * KV_PAGE_POS * HEAD_DIM;
+    }
     if (wp.part) { t.qkv_part = wp.part; t.qkv_ssq = wp.ssq; t.qkv_S = wp.S; t.qkv_K = d.H; t.qkv_eps = d.eps; }
     // Split-K projections (LinArgs::ksplit, k_gemv_sk2): o-proj and down-proj with N <= 2048 and K >= 2048 at 3 .. 16 rows (wide
     // sessions: blocks of 16 rows, see below)
     // run as two K halves that meet in the output through order-independent atomic adds. The output buffer must hold zeros:
     // SUM is cleared by this layer's attention launch (its last reader was the previous down-proj), X by the gate/up
     // launch (its last reader is this layer's o-proj, as the residual).
-    const bool first2 = !s->legacy_attn && rows_per_seq == 2 && !pos_dev && pos_static == 0;
+    const bool first2 = !s->legacy_attn && rows_per_seq == 2 && !pos_dev && pos_static == 0 && paged_layer < 0;
     const bool attn3 = !first2 && (s->legacy_attn || rows_per_seq > 1);
     // Wide sessions (B > 16, round 3): the same kernel over blocks of 16 rows (grid plane z) — one launch instead of the
     // split-K GEMM + slice-sum pair for exactly the narrow outputs where the second launch hurt most (B = 64, code
@@ -1390,8 +1517,9 @@ static q3_status talker_step(q3_session* s, const int* pos_dev, int pos_static, 
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     const LmDims d = talker_dims(c);
     for (int i = 0; i < c.n_layers; ++i)
-        Q3C(lm_layer(s, d, m->tl[i], s->tb, s->kcache + (size_t)i * s->kv_layer_stride, s->vcache + (size_t)i * s->kv_layer_stride,
-                     s->max_seq, pos_dev, pos_static, s->n_splits, rows_per_seq));
+        Q3C(lm_layer(s, d, m->tl[i], s->tb, s->paged ? nullptr : s->kcache + (size_t)i * s->kv_layer_stride,
+                     s->paged ? nullptr : s->vcache + (size_t)i * s->kv_layer_stride,
+                     s->max_seq, pos_dev, pos_static, s->n_splits, rows_per_seq, false, nullptr, s->paged ? i : -1));
     if (with_head) {
         // final norm of each sequence's LAST row of the step
         HIPC(launch_rmsnorm(s->tb.X + (size_t)(rows_per_seq - 1) * c.hidden, rows_per_seq * c.hidden, m->norm, s->LASTH, c.hidden, s->B,
@@ -1573,6 +1701,7 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
     const q3_config& c = m->cfg;
     std::unique_ptr<q3_session> s(new q3_session());
     s->m = m; s->B = batch; s->opts = reqs[0].opts;
+    m->live_sessions.fetch_add(1);
     if (s->opts.max_length < 1) return set_err(Q3_INVALID_ARG, "max_length must be >= 1");
     s->seq.resize(batch);
     int rows = 0;
@@ -1637,6 +1766,7 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
     }
     s->opts.max_length = s->max_frames;
     if (s->row_cap < 1024) s->row_cap = 1024;      // replacement slots hold any text up to ~1000 tokens (8 MB per row at H = 2048), longer if the batch had one
+    if (prompt_budget > 0 && s->row_cap < prompt_budget + 1024) s->row_cap = prompt_budget + 1024;      // ... or the caller announced longer prompts (instruct / reference text rows are projected rows too)
     s->repl_base = rows;
     // KV sized for what the path needs (prefill + frames), not the reference's max_new_tokens+256 (lib.rs:450)
     s->max_seq = (prompt_budget > s->prefill_len ? prompt_budget : s->prefill_len) + s->max_frames + 1;   // prompt_budget: later rows with longer prompts
@@ -1698,8 +1828,19 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
     HIPC(s->pool.alloc(&s->CP_IN, (size_t)(B > 16 ? up16(B) : 16) * H));
     HIPC(s->pool.alloc(&s->CP_LOGITS, (size_t)15 * B * c.cp_vocab));
     s->kv_layer_stride = (size_t)B * c.n_kv_heads * s->max_seq * HEAD_DIM;
-    HIPC(s->pool.alloc(&s->kcache, s->kv_layer_stride * c.n_layers));
-    HIPC(s->pool.alloc(&s->vcache, s->kv_layer_stride * c.n_layers));
+    {   // talker KV: pages from the model's pool as the rows grow (default), or one extent per row sized for the worst case
+        const char* e = getenv("Q3_KV_CONTIGUOUS");          // read per session: the paged-vs-contiguous test flips it
+        s->paged = !(e && atoi(e) != 0);
+        if (s->paged) {
+            if (s->max_seq > KV_MAX_PAGES * KV_PAGE_POS) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds a row's page table (%d)", s->max_seq, KV_MAX_PAGES * KV_PAGE_POS);
+            HIPC(s->pool.alloc(&s->kv_table, (size_t)B * KV_MAX_PAGES));
+            s->kv_rows.resize((size_t)B);
+            for (auto& r : s->kv_rows) r.reserve(KV_MAX_PAGES);
+        } else {
+            HIPC(s->pool.alloc(&s->kcache, s->kv_layer_stride * c.n_layers));
+            HIPC(s->pool.alloc(&s->vcache, s->kv_layer_stride * c.n_layers));
+        }
+    }
     s->ckv_layer_stride = (size_t)B * c.cp_kv_heads * (c.n_groups + 1) * HEAD_DIM;
     HIPC(s->pool.alloc(&s->ckcache, s->ckv_layer_stride * c.cp_layers));
     HIPC(s->pool.alloc(&s->cvcache, s->ckv_layer_stride * c.cp_layers));
@@ -1748,6 +1889,7 @@ q3_session::~q3_session() {
     if (dec_stream) (void)hipStreamSynchronize(dec_stream);
     for (auto st : par_streams) (void)hipStreamSynchronize(st);
     if (aql) q3::aql_program_destroy(aql);               // waits for its outstanding replays
+    for (int b = 0; b < (int)kv_rows.size(); ++b) kv_release_row(this, b);      // every stream that touched them is idle
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
     for (auto& ev : prof_pool) (void)hipEventDestroy(ev);
@@ -1762,6 +1904,8 @@ q3_session::~q3_session() {
         if (m->idle_streams.size() < 16) { m->idle_streams.push_back(stream); stream = nullptr; }
     }
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
+    pool.release_all();                                          // the model's device must still be current for these
+    if (m->live_sessions.fetch_sub(1) == 1 && m->zombie.load()) model_destroy(m);
 }
 
 extern "C" void q3_session_free(q3_session* s) { delete s; }
@@ -1894,12 +2038,14 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
             AttnArgs t{};
             t.qkv = QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
             t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = nullptr; t.pos_static = t0;
-            t.kcache = s->kcache + (size_t)i * s->kv_layer_stride; t.vcache = s->vcache + (size_t)i * s->kv_layer_stride;
+            if (s->paged) {
+                t.kv_pages = s->kv_table; t.kv_layer_off = (size_t)i * d.nkv * KV_PAGE_POS * HEAD_DIM; t.kv_vdelta = (size_t)d.layers * d.nkv * KV_PAGE_POS * HEAD_DIM;
+            } else { t.kcache = s->kcache + (size_t)i * s->kv_layer_stride; t.vcache = s->vcache + (size_t)i * s->kv_layer_stride; }
             t.max_seq = s->max_seq; t.qbuf = Qb; t.part = nullptr; t.out = ATT; t.ld_out = QD;
             t.B = rows; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = 1; t.rows_per_seq = ch;
             HIPC(launch_qknorm_rope_kv(t, s->stream));
             if (attn_x3) {
-                HIPC(launch_kv_planes(t.kcache, t.vcache, s->max_seq, B * d.nkv, t0 + ch, kvp_tiles, KVP, s->stream));
+                HIPC(launch_kv_planes(t, B * d.nkv, t0 + ch, kvp_tiles, KVP, s->stream));
                 t.kvp = KVP; t.kvp_tiles = kvp_tiles;
             }
             if (kv_split) { t.part = PART; t.n_splits = 2; }
@@ -1937,6 +2083,7 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     HIPC(hipSetDevice(m->device));
     const int B = s->B, H = c.hidden, S = s->prefill_len;
+    for (int b = 0; b < B; ++b) Q3C(kv_reserve_row(s, b, S + 1));      // paged KV: the prompt's positions and the first frame's
     // 1. ids to project, per sequence: [instruct…, IM_START, ASSISTANT, NEWLINE, TTS_PAD, TTS_BOS, text…, TTS_EOS]
     std::vector<uint32_t> ids; ids.reserve(s->n_rows_total);
     std::vector<int> text_row((size_t)B * S, -1), codec_id((size_t)B * S, -1);
@@ -2098,6 +2245,7 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
     int todo = n_frames;
     { const int left = session_remaining(s); if (todo > left) todo = left; }
     if (todo <= 0) return Q3_OK;
+    Q3C(kv_reserve_frames(s, todo));        // paged KV: every page these frames can reach, before the first of them is queued
     if (use_graph && !s->graph_exec) {
         HIPC(hipStreamSynchronize(s->stream));
         HIPC(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -2115,6 +2263,9 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         const int mode = e ? atoi(e) : 0;
         if (mode > 0) {
             q3::AqlPolicy pol; pol.fence = mode >= 2 ? 0 : 1;
+            pol.acquire = pol.release = pol.fence;
+            if (const char* a = getenv("Q3_AQL_ACQ")) pol.acquire = atoi(a);        // probes: the two fences of a boundary priced separately
+            if (const char* r = getenv("Q3_AQL_REL")) pol.release = atoi(r);
             std::string why;
             s->aql = q3::aql_program_create(s->graph, s->m->device, pol, &why);
             if (s->aql) s->aql_mode = mode >= 2 ? 2 : 1;
@@ -2186,12 +2337,24 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     if (side->opts.chunk_frames != s->opts.chunk_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: chunk_frames is a property of the session");
     const int limit = limit_req < sq.limit ? limit_req : sq.limit;
     if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
-    if (side->prefill_len + limit + 1 > s->max_seq) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", side->prefill_len, limit, s->max_seq);
+    if (s->paged != side->paged) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the sessions disagree on KV paging");
+    // paged rows grow page by page: only the RoPE table bounds a row (prompt_budget is not needed); contiguous extents were sized at creation
+    const int kv_cap = s->paged ? (m->rope_len < KV_MAX_PAGES * KV_PAGE_POS ? m->rope_len : KV_MAX_PAGES * KV_PAGE_POS) : s->max_seq;
+    if (side->prefill_len + limit + 1 > kv_cap) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", side->prefill_len, limit, kv_cap);
     Q3C(q3_session_prefill(side.get()));               // ends with a synchronisation of the side stream
     lap("prefill");
     HIPC(hipStreamSynchronize(s->stream));             // no frame of the host session in flight while its row changes
     const int H = c.hidden, S = side->prefill_len, nkv = c.n_kv_heads;
     const size_t row_bytes = (size_t)HEAD_DIM * 4;
+    if (s->paged) {
+        // the prompt's K/V is not copied: the side session's pages become the row's (its old ones go back to the pool — both
+        // streams are idle), and the row's table entries are rewritten
+        kv_release_row(s, b);
+        std::vector<float*>& row = s->kv_rows[(size_t)b];
+        row.assign(side->kv_rows[0].begin(), side->kv_rows[0].end());
+        side->kv_rows[0].clear();
+        HIPC(hipMemcpyAsync(s->kv_table + (size_t)b * KV_MAX_PAGES, row.data(), row.size() * 8, hipMemcpyHostToDevice, s->stream));
+    } else
     for (int l = 0; l < c.n_layers; ++l) {
         const size_t so = (size_t)l * side->kv_layer_stride, dof = (size_t)l * s->kv_layer_stride + (size_t)b * nkv * s->max_seq * HEAD_DIM;
         HIPC(hipMemcpy2DAsync(s->kcache + dof, s->max_seq * row_bytes, side->kcache + so, side->max_seq * row_bytes, S * row_bytes, nkv, hipMemcpyDeviceToDevice, s->stream));
@@ -2754,6 +2917,7 @@ extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_
     }
     const bool first = s->stream_pos == 0;
     auto launch_ahead = [&]() -> q3_status {
+        Q3C(kv_reserve_frames(s, ahead));
         for (int i = 0; i < ahead; ++i) HIPC(hipGraphLaunch(s->graph_exec, s->stream));
         s->frames_run += ahead;
         s->codes_host_valid = false;                            // the next call re-reads codes / EOS state after a sync
@@ -2853,6 +3017,7 @@ extern "C" q3_status q3_talker_step(q3_session* s, const float* embeds_host, flo
     HIPC(hipStreamSynchronize(s->stream));
     HIPC(hipMemcpy(posv.data(), s->pos, s->B * 4, hipMemcpyDeviceToHost));
     for (int p : posv) if (p >= s->max_seq) return set_err(Q3_KV_OVERFLOW, "KV cache full (%d)", s->max_seq);
+    for (int b = 0; b < s->B; ++b) Q3C(kv_reserve_row(s, b, posv[(size_t)b] + 1));       // paged KV: the slot this step writes
     HIPC(hipMemcpyAsync(s->tb.X, embeds_host, (size_t)s->B * c.hidden * 4, hipMemcpyHostToDevice, s->stream));
     Q3C(talker_step(s, s->pos, 0, true));
     // advance positions by one (host-driven teacher forcing)

@@ -10,6 +10,12 @@ namespace q3 {
 constexpr int HEAD_DIM = 128;        // talker / code-predictor head dim (kernels are specialised)
 constexpr int MAX_SPLITS = 64;       // KV splits of the decode attention (16 unless the context is long, see q3_session_create)
 constexpr int PART_STRIDE = HEAD_DIM + 2;   // partial record: acc[128], m, l
+// Paged talker KV (replaces the reference's preallocated per-call cache, kv_cache.rs:234-310): a PAGE holds KV_PAGE_POS
+// consecutive positions of ONE sequence for every layer and KV head, K half then V half —
+//   page[2][n_layers][nkv][KV_PAGE_POS][HEAD_DIM] f32 (29.4 MB at 28 layers x 8 KV heads; a (layer, head) run is 64 KB).
+// A sequence owns a row of KV_MAX_PAGES page pointers in device memory (64 x 128 = 8192 positions = the RoPE table);
+// position p of (layer l, head h) lives at pages[p / 128] + l * nkv * 16384 + h * 16384 + (p % 128) * 128.
+constexpr int KV_PAGE_POS = 128, KV_PAGE_SHIFT = 7, KV_MAX_PAGES = 64;
 
 // ---- Q3_TRACE (development builds only: tools/trace_build.sh -> libq3tts_trace.so; never defined in the product) ----
 // Per-node timeline of the captured frame graph at 10 ns resolution: every instrumented kernel gets, per launch, its own
@@ -123,6 +129,10 @@ struct AttnArgs {
     const int* pos_dev; int pos_static;     // position of the new token: pos_dev[b] if non-null
     float* kcache; float* vcache;           // [B][nkv][max_seq][128]
     int max_seq;
+    // paged form (the talker): kv_pages != nullptr -> kcache / vcache / max_seq are unused; kv_pages[seq * KV_MAX_PAGES + p / 128]
+    // is the page of position p, kv_layer_off = layer * nkv * KV_PAGE_POS * HEAD_DIM floats into it, kv_vdelta = floats from
+    // a K row to its V row (n_layers * nkv * KV_PAGE_POS * HEAD_DIM)
+    const unsigned long long* kv_pages = nullptr; size_t kv_layer_off = 0, kv_vdelta = 0;
     float* qbuf;                            // [B][nh][128] normed+roped q
     float* part;                            // [B][nh][n_splits][PART_STRIDE]
     float* out; int ld_out;                 // [B][nh*128]
@@ -152,6 +162,18 @@ struct AttnArgs {
     const float* qkv_part = nullptr; const float* qkv_ssq = nullptr; int qkv_S = 0, qkv_K = 0; float qkv_eps = 0.0f;
     Q3_TRACE_FIELD
 };
+#if defined(__HIPCC__)
+// K row of (sequence, kv head, position) — contiguous extent or page (one table fetch: the cold paths; k_attn_fused keeps the
+// sequence's table row in registers instead). The V row is `+ kv_vd(a)` floats further.
+__device__ __forceinline__ float* kv_krow(const AttnArgs& a, int seq, int kvh, int p) {
+    if (a.kv_pages) {
+        float* pg = reinterpret_cast<float*>(a.kv_pages[(size_t)seq * KV_MAX_PAGES + (p >> KV_PAGE_SHIFT)]);
+        return pg + a.kv_layer_off + ((size_t)kvh * KV_PAGE_POS + (p & (KV_PAGE_POS - 1))) * HEAD_DIM;
+    }
+    return a.kcache + (((size_t)seq * a.nkv + kvh) * a.max_seq + p) * HEAD_DIM;
+}
+__device__ __forceinline__ ptrdiff_t kv_vd(const AttnArgs& a) { return a.kv_pages ? (ptrdiff_t)a.kv_vdelta : a.vcache - a.kcache; }
+#endif
 // the GEMM of launch_gemm_wide WITHOUT its slice-sum launch (EPI_NONE with a fused input norm only): the consumer adds
 // the slices. hipErrorNotSupported: shape outside the family.
 struct WidePartial { const float* part; const float* ssq; int S; };
@@ -159,7 +181,7 @@ int gemm_wide_min_rows();      // rows from which launch_gemm_wide takes a proje
 hipError_t launch_gemm_wide_partial(const LinArgs& a, hipStream_t st, WidePartial* out);
 constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
 // planes of positions [0, n_pos) of every (sequence, kv head) pair, from the f32 cache launch_qknorm_rope_kv filled
-hipError_t launch_kv_planes(const float* kcache, const float* vcache, int max_seq, int n_pairs, int n_pos, int tiles_alloc,
+hipError_t launch_kv_planes(const AttnArgs& kv, int n_pairs, int n_pos, int tiles_alloc,
                             unsigned char* kvp, hipStream_t st);
 hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);

@@ -359,10 +359,10 @@ __global__ __launch_bounds__(64) void k_qknorm_rope_kv(AttnArgs a) {
         q[lane] = o1; q[lane + 64] = o2;
     } else {
         const int kvh = h - a.nh;
-        const size_t slot = (((size_t)seq * a.nkv + kvh) * a.max_seq + pos) * HEAD_DIM;
-        a.kcache[slot + lane] = o1; a.kcache[slot + lane + 64] = o2;
+        float* kr = kv_krow(a, seq, kvh, pos); float* vr = kr + kv_vd(a);
+        kr[lane] = o1; kr[lane + 64] = o2;
         const float* vs = a.qkv + (size_t)b * a.ld_qkv + QD + KD + kvh * HEAD_DIM;
-        a.vcache[slot + lane] = vs[lane]; a.vcache[slot + lane + 64] = vs[lane + 64];
+        vr[lane] = vs[lane]; vr[lane + 64] = vs[lane + 64];
     }
 }
 
@@ -401,10 +401,11 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
 
-    const size_t base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM + li * 4;
+    const ptrdiff_t vd = kv_vd(a);
     for (int p = start + grp; p < end; p += 8) {
-        const float4 kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
-        const float4 vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
+        const float* kr = kv_krow(a, seq, kvh, p) + li * 4;
+        const float4 kk = *reinterpret_cast<const float4*>(kr);
+        const float4 vv = *reinterpret_cast<const float4*>(kr + vd);
 #pragma unroll
         for (int r = 0; r < NREP; ++r) {
             float s = q[r].x * kk.x + q[r].y * kk.y + q[r].z * kk.z + q[r].w * kk.w;
@@ -461,12 +462,27 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
 // takes position `pos` from LDS, never from the just-written global memory.
 // Leading scalars: the 14 dwords the first requests depend on, preloaded into SGPRs (see k_attn_cp): position array, caches,
 // q|k|v rows, norm weights, max_seq and n_splits | nkv << 8 | nh << 16.
-template <int NREP>
+// PAGED (the talker's cache, KV_PAGE_POS positions per page): the preloaded scalars carry the page table (p_kc), the
+// layer's offset inside a page in floats (p_vc, an integer in a pointer's clothes) and the K -> V distance (p_max_seq).
+// Every wave asks for the sequence's table row first — one entry per lane, beside the position load — and a row address
+// then costs two ds_bpermute (page pointer of p / 128) instead of a dependent trip to memory: the first K/V requests
+// leave as early as with one contiguous extent per sequence.
+template <int NREP, bool PAGED>
 __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const float* p_kc, const float* p_vc, const float* p_qkv, const float* p_qw,
                                                     const float* p_kw, int p_max_seq, int p_pk, AttnArgs a_in) {
     AttnArgs a = a_in;
-    a.pos_dev = p_pos; a.kcache = const_cast<float*>(p_kc); a.vcache = const_cast<float*>(p_vc); a.qkv = p_qkv; a.q_norm_w = p_qw; a.k_norm_w = p_kw;
-    a.max_seq = p_max_seq; a.n_splits = p_pk & 255; a.nkv = (p_pk >> 8) & 255; a.nh = (p_pk >> 16) & 255;
+    a.pos_dev = p_pos; a.qkv = p_qkv; a.q_norm_w = p_qw; a.k_norm_w = p_kw;
+    a.n_splits = p_pk & 255; a.nkv = (p_pk >> 8) & 255; a.nh = (p_pk >> 16) & 255;
+    uint32_t tab_lo = 0, tab_hi = 0;
+    size_t pg_off = 0, pg_vd = 0;
+    if constexpr (PAGED) {
+        const unsigned long long e = reinterpret_cast<const unsigned long long*>(p_kc)[(size_t)blockIdx.z * KV_MAX_PAGES + (threadIdx.x & 63)];
+        tab_lo = (uint32_t)e; tab_hi = (uint32_t)(e >> 32);
+        pg_off = reinterpret_cast<size_t>(p_vc) + (size_t)blockIdx.y * KV_PAGE_POS * HEAD_DIM;
+        pg_vd = (size_t)p_max_seq;
+    } else {
+        a.kcache = const_cast<float*>(p_kc); a.vcache = const_cast<float*>(p_vc); a.max_seq = p_max_seq;
+    }
     __shared__ __attribute__((aligned(16))) float s_q[NREP][HEAD_DIM];
     __shared__ __attribute__((aligned(16))) float s_k[HEAD_DIM], s_v[HEAD_DIM];
     __shared__ float sm_m[NREP][8], sm_l[NREP][8];
@@ -481,7 +497,13 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     const int start = split * chunk;
     const int end = (start + chunk) < len ? (start + chunk) : len;
     const float scale = 0.08838834764831845f;
-    const size_t cache_base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    const size_t cache_base = PAGED ? 0 : ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    // K row of position p (p may differ between lanes; every lane of the wave must be active: ds_bpermute)
+    auto krow_paged = [&](int p) -> float* {
+        const int idx = (p >> KV_PAGE_SHIFT) << 2;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)tab_lo), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)tab_hi);
+        return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo) + pg_off + (size_t)(p & (KV_PAGE_POS - 1)) * HEAD_DIM;
+    };
 
     // The first two cached K/V rows of this group are requested NOW, before the q/k-norm + RoPE prologue: they depend
     // on nothing but `pos`, and their round trip then runs under the prologue instead of after its barrier (the new
@@ -493,8 +515,14 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     const size_t base = cache_base + li * 4;
     auto request = [&](int p, float4& ko, float4& vo) {
         const int ps = (p < end && p != pos) ? p : 0;               // row 0 always exists
-        ko = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)ps * HEAD_DIM);
-        vo = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)ps * HEAD_DIM);
+        if constexpr (PAGED) {
+            const float* kr = krow_paged(ps) + li * 4;
+            ko = *reinterpret_cast<const float4*>(kr);
+            vo = *reinterpret_cast<const float4*>(kr + pg_vd);
+        } else {
+            ko = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)ps * HEAD_DIM);
+            vo = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)ps * HEAD_DIM);
+        }
     };
     float4 kA, vA, kB, vB, kC, vC;
     const int p0 = start + grp;
@@ -543,8 +571,9 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             else { v1 = vs[lane]; v2 = vs[lane + 64]; }
             s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
             if (split == pos / chunk) {
-                float* kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM;
-                float* vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM;
+                float* kc; float* vc;
+                if constexpr (PAGED) { kc = krow_paged(pos); vc = kc + pg_vd; }          // (wave-uniform branch: all 64 lanes are here)
+                else { kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM; vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM; }
                 kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
             }
         }
@@ -627,10 +656,18 @@ hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
     if (a.n_splits > 255 || a.nh > 255 || a.nkv > 255) return hipErrorInvalidValue;
     dim3 grid(a.n_splits, a.nkv, a.B);
     const int pk = a.n_splits | (a.nkv << 8) | (a.nh << 16);
-#define Q3_AF(R) hipLaunchKernelGGL(k_attn_fused<R>, grid, dim3(256), 0, st, a.pos_dev, (const float*)a.kcache, (const float*)a.vcache, a.qkv, a.q_norm_w, a.k_norm_w, a.max_seq, pk, a)
+#define Q3_AF(R) hipLaunchKernelGGL((k_attn_fused<R, false>), grid, dim3(256), 0, st, a.pos_dev, (const float*)a.kcache, (const float*)a.vcache, a.qkv, a.q_norm_w, a.k_norm_w, a.max_seq, pk, a)
+#define Q3_AFP(R) hipLaunchKernelGGL((k_attn_fused<R, true>), grid, dim3(256), 0, st, a.pos_dev, reinterpret_cast<const float*>(a.kv_pages), reinterpret_cast<const float*>(a.kv_layer_off), \
+                                     a.qkv, a.q_norm_w, a.k_norm_w, (int)a.kv_vdelta, pk, a)
+    if (a.kv_pages) {
+        if (a.kv_vdelta > 0x7fffffffu) return hipErrorInvalidValue;
+        if (nrep == 1) Q3_AFP(1); else if (nrep == 2) Q3_AFP(2); else if (nrep == 4) Q3_AFP(4);
+        else return hipErrorInvalidValue;
+    } else
     if (nrep == 1) Q3_AF(1); else if (nrep == 2) Q3_AF(2); else if (nrep == 4) Q3_AF(4);
     else return hipErrorInvalidValue;
 #undef Q3_AF
+#undef Q3_AFP
     return hipGetLastError();
 }
 
@@ -699,7 +736,7 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
 
 hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
     const int nrep = a.nh / a.nkv;
-    if (a.rows_per_seq != 2 || a.B % 2) return hipErrorInvalidValue;
+    if (a.rows_per_seq != 2 || a.B % 2 || a.kv_pages) return hipErrorInvalidValue;      // the code predictor's 17-position cache is never paged
     dim3 grid(a.nkv, a.B / 2);
     if (nrep == 1) hipLaunchKernelGGL(k_attn_first2<1>, grid, dim3(256), 0, st, a);
     else if (nrep == 2) hipLaunchKernelGGL(k_attn_first2<2>, grid, dim3(256), 0, st, a);
@@ -915,7 +952,7 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
 // single-row passes of a cache that never exceeds 16 positions, position known at launch (the code predictor)
 bool attn_cp_ok(const AttnArgs& a) {
     const ptrdiff_t vd = a.vcache - a.kcache;
-    return !a.pos_dev && a.rows_per_seq <= 1 && a.n_splits == 1 && a.pos_static >= 0 && a.pos_static < 16 && a.pos_static < a.max_seq &&
+    return !a.kv_pages && !a.pos_dev && a.rows_per_seq <= 1 && a.n_splits == 1 && a.pos_static >= 0 && a.pos_static < 16 && a.pos_static < a.max_seq &&
            a.max_seq < 256 && a.nkv > 0 && a.nh < 256 && a.nh % a.nkv == 0 && a.ld_qkv == (a.nh + 2 * a.nkv) * HEAD_DIM && a.ld_out % 2 == 0 &&
            vd > -(ptrdiff_t)0x7fffffff && vd < (ptrdiff_t)0x7fffffff && (!a.g_logits || (a.g_proj_dim % 4 == 0 && a.g_ldx % 4 == 0));
 }

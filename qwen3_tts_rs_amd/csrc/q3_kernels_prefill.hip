@@ -775,10 +775,11 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < NQ; ++j) { m[j] = -INFINITY; l[j] = 0.0f; acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
 
-    const size_t base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM + li * 4;
+    const ptrdiff_t vd = kv_vd(a);
     for (int p = grp; p <= last_pos; p += 8) {
-        const float4 kk = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)p * HEAD_DIM);
-        const float4 vv = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)p * HEAD_DIM);
+        const float* kr = kv_krow(a, seq, kvh, p) + li * 4;
+        const float4 kk = *reinterpret_cast<const float4*>(kr);
+        const float4 vv = *reinterpret_cast<const float4*>(kr + vd);
 #pragma unroll
         for (int i = 0; i < RQ; ++i) {
             if (i < nrows && p <= base_pos + i0 + i) {         // causal: key position <= query position
@@ -886,15 +887,15 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.0f; }
     const int my_first_pos = base_pos + r0, my_last_pos = base_pos + r0 + 31;   // (rows past the chunk end are discarded)
 
-    const size_t cache_base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    const ptrdiff_t vd = kv_vd(a);
     const int skey = tid >> 3, sc = (tid & 7) * 16;            // staging role: key row, 16-float column chunk
     for (int tile = 0; tile < n_tiles; ++tile) {
         __syncthreads();
         {
             const int p = tile * 32 + skey;
             const bool ok = p <= wg_last_pos;
-            const float* kp = a.kcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
-            const float* vp = a.vcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
+            const float* kp = kv_krow(a, seq, kvh, ok ? p : 0) + sc;
+            const float* vp = kp + vd;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float4 kf = ok ? *reinterpret_cast<const float4*>(kp + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1032,14 +1033,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_prefill_t(AttnArgs a) {      //
     const int qpos = base_pos + r0 + li;                       // this lane's query position
     const int my_first_pos = base_pos + r0, my_last_pos = base_pos + r0 + 31;
 
-    const size_t cache_base = ((size_t)seq * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    const ptrdiff_t vd = kv_vd(a);
     const int skey = tid >> 3, sc = (tid & 7) * 16;            // staging role: key row, 16-float column chunk
     float4 kst[4], vst[4];
     auto fetch = [&](int tile) {
         const int p = tile * 32 + skey;
         const bool ok = p <= wg_last_pos;
-        const float* kp = a.kcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
-        const float* vp = a.vcache + cache_base + (size_t)(ok ? p : 0) * HEAD_DIM + sc;
+        const float* kp = kv_krow(a, seq, kvh, ok ? p : 0) + sc;
+        const float* vp = kp + vd;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             kst[t] = ok ? *reinterpret_cast<const float4*>(kp + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1152,20 +1153,20 @@ constexpr int X3_PLANE = 32 * HEAD_DIM * 2;          // bytes of one plane of on
 constexpr int X3_TILE = 6 * X3_PLANE;                // K h, m, l, Vᵀ h, m, l
 typedef __attribute__((ext_vector_type(16))) float pf32x16b_t;
 
-__global__ __launch_bounds__(256) void k_kv_planes(const float* __restrict__ kcache, const float* __restrict__ vcache, int max_seq,
-                                                   int n_pos, int tiles_alloc, unsigned char* __restrict__ kvp) {
+__global__ __launch_bounds__(256) void k_kv_planes(AttnArgs a, int n_pos, int tiles_alloc, unsigned char* __restrict__ kvp) {
     __shared__ float sV[32 * 129];
     const int tile = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x;
-    const size_t cache_base = (size_t)pair * max_seq * HEAD_DIM;
     unsigned char* dst = kvp + ((size_t)pair * tiles_alloc + tile) * X3_TILE;
     const int key = tid >> 3, dc = (tid & 7) * 16;
     const int p = tile * 32 + key;
     const bool ok = p < n_pos;                                   // positions past the prompt: zeros (masked by causality anyway)
+    const float* krow = kv_krow(a, pair / a.nkv, pair % a.nkv, ok ? p : 0) + dc;      // pair = sequence * nkv + kv head
+    const float* vrow = krow + kv_vd(a);
     float kv[16], vv[16];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const float4 kf = ok ? *reinterpret_cast<const float4*>(kcache + cache_base + (size_t)p * HEAD_DIM + dc + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 vf = ok ? *reinterpret_cast<const float4*>(vcache + cache_base + (size_t)p * HEAD_DIM + dc + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 kf = ok ? *reinterpret_cast<const float4*>(krow + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vf = ok ? *reinterpret_cast<const float4*>(vrow + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
         kv[4 * t] = kf.x; kv[4 * t + 1] = kf.y; kv[4 * t + 2] = kf.z; kv[4 * t + 3] = kf.w;
         vv[4 * t] = vf.x; vv[4 * t + 1] = vf.y; vv[4 * t + 2] = vf.z; vv[4 * t + 3] = vf.w;
     }
@@ -1201,11 +1202,12 @@ __global__ __launch_bounds__(256) void k_kv_planes(const float* __restrict__ kca
         *reinterpret_cast<pu32x4_t*>(o + 2 * X3_PLANE) = l;
     }
 }
-hipError_t launch_kv_planes(const float* kcache, const float* vcache, int max_seq, int n_pairs, int n_pos, int tiles_alloc,
+hipError_t launch_kv_planes(const AttnArgs& kv, int n_pairs, int n_pos, int tiles_alloc,
                             unsigned char* kvp, hipStream_t st) {
     const int tiles = (n_pos + 31) / 32;
-    if (tiles < 1 || tiles > tiles_alloc || n_pos > max_seq) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_kv_planes, dim3(tiles, n_pairs), dim3(256), 0, st, kcache, vcache, max_seq, n_pos, tiles_alloc, kvp);
+    const int cap = kv.kv_pages ? KV_MAX_PAGES * KV_PAGE_POS : kv.max_seq;
+    if (tiles < 1 || tiles > tiles_alloc || n_pos > cap || kv.nkv < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_kv_planes, dim3(tiles, n_pairs), dim3(256), 0, st, kv, n_pos, tiles_alloc, kvp);
     return hipGetLastError();
 }
 

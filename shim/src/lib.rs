@@ -41,6 +41,8 @@ pub mod ffi {
         pub fn q3_model_tensor_info(m: *const c_void, i: i32, name: *mut *const c_char, n: *mut i64, stored_dtype: *mut i32) -> i32;
         pub fn q3_model_set_tensor(m: *mut c_void, name: *const c_char, dtype: i32, data: *const c_void, n: i64) -> i32;
         pub fn q3_model_finalize(m: *mut c_void) -> i32;
+        pub fn q3_model_kv_pool_limit(m: *mut c_void, max_pages: i32) -> i32;
+        pub fn q3_model_kv_pool_info(m: *mut c_void, page_positions: *mut i32, page_bytes: *mut usize, pages_total: *mut i32, pages_in_use: *mut i32, pages_peak: *mut i32) -> i32;
         pub fn q3_codes_to_tensor(frames: *const u32, n_frames: i32, out: *mut i64);
         pub fn q3_session_create(m: *mut c_void, reqs: *const Q3Request, batch: i32, out: *mut *mut c_void) -> i32;
         pub fn q3_session_prefill(s: *mut c_void) -> i32;

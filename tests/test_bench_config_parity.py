@@ -467,3 +467,37 @@ def test_clone_prefill_1_7b(gm17, flavour):
         m = float(fx[f"{flavour}_talker_top2_margin"][f]) if g == 0 else float(fx[f"{flavour}_cp_top2_margin"][f][g - 1])
         assert m < MARGIN_EPS, (f, g, m)
     s.close()
+
+
+@pytest.mark.gpu
+def test_icl_2k_reference_1_7b(gm17):
+    """config[4] thickened: ONE 1.7B ICL voice-clone request whose reference block makes the prefill 2110
+    positions (2100 reference frames, 600 reference-text tokens, talker.rs:646-710): the GEMM prefill over an ICL prompt
+    (paged KV: 17 pages), last hidden state and first logits, four greedy hipGraph frames, and the prepend-and-cut decode of
+    lib.rs:1022-1041 over 2104 frames (PCM of the generated share, RMS <= 1e-3) against the oracle fixture."""
+    from make_golden_bench import icl2k_utt
+    fx = np.load(os.path.join(G, "bench_1_7b_icl2k.npz"))
+    cfg = gm17.config
+    utt = icl2k_utt(cfg)
+    opts = q.SynthesisOptions(max_length=4, temperature=0.0, eos_token_id=None, seed=42)
+    s = gm17.session([utt], opts); s.prefill()
+    assert s.prefill_len(0)[0] == int(fx["prefill_len"][0]) == 2110
+    hid = s.get(1, (cfg.hidden,)); lg = s.get(2, (cfg.codec_vocab,))
+    eh = float(np.abs(hid - fx["hidden"]).max()); el = float(np.abs(lg - fx["logits"]).max())
+    assert eh <= 5e-4 and el <= 5e-3, (eh, el)              # the 600-position thresholds of test_long_context_b8
+    s.generate(4, use_graph=True)
+    codes = s.codes(0); ref = fx["codes"]
+    exact = bool((codes == ref).all())
+    if not exact:
+        f = next(i for i in range(4) if not (codes[i] == ref[i]).all())
+        g = int(np.nonzero(codes[f] != ref[f])[0][0])
+        m = float(fx["talker_top2_margin"][f]) if g == 0 else float(fx["cp_top2_margin"][f][g - 1])
+        assert m < MARGIN_EPS, (f, g, m)
+    pcm = s.decode(0)
+    s.close()
+    assert pcm.shape == fx["pcm"].shape == (4 * 1920,)
+    rms = float(np.sqrt(np.mean((pcm.astype(np.float64) - fx["pcm"].astype(np.float64)) ** 2)))
+    _dump("bench_icl2k.json", {"hidden_max_abs_err": eh, "logits_max_abs_err": el, "codes_exact": exact, "pcm_rms_err": rms,
+                               "pcm_ref_rms": float(np.sqrt(np.mean(fx["pcm"].astype(np.float64) ** 2)))})
+    if exact:
+        assert rms <= 1e-3, rms

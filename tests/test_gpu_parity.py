@@ -919,6 +919,62 @@ def test_bench_two_ranks_same_gpu():
     assert out["config"]["utterances_per_gpu"] == 2 and out["weight_broadcast"]["bytes"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_eight_ranks_same_gpu():
+    """8-rank rehearsal of the driver's SCALE run: `bench.py --gpus 8` spawns eight ranks itself, all on
+    cuda:0 over gloo (Q3_DP_TEST_SAME_GPU=1; RCCL refuses several ranks per device), tiny model. Arena broadcast to seven
+    non-root ranks, their finalize, barriers, max-over-ranks timing, sum of frames over ranks, eight entries in
+    rccl.ranks_seen, every rank leaves with exit code 0."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["Q3_DP_TEST_SAME_GPU"] = "1"; env["MASTER_ADDR"] = "127.0.0.1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--model", "tiny", "--steps", "2", "--warmup", "1", "--frames", "12",
+                        "--batch", "2", "--also-batches", "", "--no-cpu-baseline", "--no-other-configs", "--ttfa-reps", "1", "--prompt-tokens", "16"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["rccl"]["world"] == 8 and sorted(x[0] for x in out["rccl"]["ranks_seen"]) == list(range(8)) and out["rccl"]["same_gpu_test_mode"] is True
+    assert out["config"]["utterances_per_gpu"] == 2 and out["weight_broadcast"]["bytes"] > 0
+    # weak scaling bookkeeping: 8 ranks x 2 utterances x 12 frames x 2 steps over the max-over-ranks time
+    assert abs(out["value"] * out["ms_per_step"] / 1000.0 - 8 * 2 * 12) < 1e-6 * 8 * 2 * 12
+    _dump("bench_eight_ranks_same_gpu.json", {k: out[k] for k in ("n_gpus", "value", "ms_per_step", "rccl", "weight_broadcast")})
+
+
+@pytest.mark.gpu
+def test_native_rccl_world2_same_gpu(tmp_path):
+    """q3_dp_* at world 2 on a one-GPU box: two processes, both on device 0, id shipped through a file. RCCL
+    is expected to refuse the duplicate device; the outcome is RECORDED (gpurun_out/native_rccl_world2_same_gpu.json), and the
+    requirement is that it is clean either way — both ranks report within the timeout, as `ok` with matching codes or as a
+    status + message, never a hang or a crash."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "rccl_w2")
+    env = dict(os.environ)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_native_world2_check.py"), str(r), path], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, _ = p.communicate(); o = (o or "") + "\n[killed after 240 s]"
+        outs.append((p.returncode, o))
+    lines = [[l for l in o.splitlines() if l.startswith("rank ")] for _, o in outs]
+    _dump("native_rccl_world2_same_gpu.json", {"returncodes": [rc for rc, _ in outs], "lines": lines, "tails": [o[-600:] for _, o in outs]})
+    for rc, o in outs:
+        assert rc == 0, o[-2000:]
+    assert all(len(l) == 1 for l in lines), outs
+    kinds = [l[0].split()[2] for l in lines]
+    assert all(k in ("ok", "refused", "error") for k in kinds)
+    if all(k == "ok" for k in kinds):
+        assert all("match" in l[0] for l in lines)
+
+
 # ---------------------------------------------------------------- continuous batching (q3_session_replace, per-row limits, per-row streaming)
 @pytest.mark.gpu
 def test_rows_end_at_their_own_limit(pair):

@@ -12,7 +12,8 @@ from common import synthetic_prompt
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="1.7b"); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--frames", type=int, default=200)
-ap.add_argument("--modes", default="0,1,2,0,1,2"); ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--modes", default="0,1,2,0,1,2", help="Q3_AQL values; `1:a:r` = mode 1 with Q3_AQL_ACQ=a Q3_AQL_REL=r (fence halves priced separately; results invalid when a fence is off)")
+ap.add_argument("--reps", type=int, default=2)
 a = ap.parse_args()
 cfg = {"1.7b": q.qwen3_tts_1_7b, "0.6b": q.qwen3_tts_0_6b, "tiny": q.tiny}[a.model]()
 model = q.Qwen3TTS.from_synthetic(cfg, device=0, seed=synth.DEFAULT_SEED)
@@ -20,8 +21,12 @@ utts = [q.Utterance(synthetic_prompt(512, i), q.Speaker.Ryan, q.Language.English
 opts = q.SynthesisOptions(max_length=a.frames, eos_token_id=None, seed=42)
 os.environ["Q3_AQL_VERBOSE"] = "1"
 ref = None
-for mode in [int(x) for x in a.modes.split(",")]:
+for spec in a.modes.split(","):
+    parts = spec.split(":"); mode = int(parts[0])
     os.environ["Q3_AQL"] = str(mode)
+    os.environ.pop("Q3_AQL_ACQ", None); os.environ.pop("Q3_AQL_REL", None)
+    if len(parts) == 3:
+        os.environ["Q3_AQL_ACQ"], os.environ["Q3_AQL_REL"] = parts[1], parts[2]
     best = 1e9
     for r in range(a.reps):
         s = model.session(utts, opts)
@@ -33,4 +38,4 @@ for mode in [int(x) for x in a.modes.split(",")]:
         best = min(best, dt)
     if ref is None: ref = codes
     same = codes.shape == ref.shape and bool((codes == ref).all())
-    print(f"Q3_AQL={mode}: path {path} ({nodes} packets/frame)  {best * 1e3 / a.frames:.3f} ms/frame  codes {'identical' if same else 'DIFFER'}", flush=True)
+    print(f"Q3_AQL={spec}: path {path} ({nodes} packets/frame)  {best * 1e3 / a.frames:.3f} ms/frame  codes {'identical' if same else 'DIFFER'}", flush=True)

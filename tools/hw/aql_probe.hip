@@ -245,7 +245,7 @@ static int get_kernel(hsa_executable_t ex, const char* name, KSym* k) {
 
 // writes n dispatch packets — stage i into queue i % nq — and rings each doorbell once; waits for the last packet of every queue
 static int run_chain(hsa_queue_t** qs, int nq, hsa_signal_t* dones, const KSym& k, const char* kargs_dev, int n, int wgs, bool barrier, int fence, double* us,
-                     uint32_t lds_pad = 0) {
+                     uint32_t lds_pad = 0, int acq_fence = -1) {      // acq_fence >= 0: acquire scope set apart from the release scope (`fence`)
     uint64_t base[4], cnt[4] = {0, 0, 0, 0};
     for (int j = 0; j < nq; ++j) {
         const uint64_t mine = (uint64_t)((n - j + nq - 1) / nq);
@@ -259,7 +259,7 @@ static int run_chain(hsa_queue_t** qs, int nq, hsa_signal_t* dones, const KSym& 
         hsa_kernel_dispatch_packet_t pk; memset(&pk, 0, sizeof pk);
         const bool first = i < nq, last = i >= n - nq;
         // the first packet acquires at system scope (the host's memsets), the last releases at system scope (the host reads)
-        const int acq = first ? HSA_FENCE_SCOPE_SYSTEM : fence, rel = last ? HSA_FENCE_SCOPE_SYSTEM : fence;
+        const int acq = first ? HSA_FENCE_SCOPE_SYSTEM : (acq_fence >= 0 ? acq_fence : fence), rel = last ? HSA_FENCE_SCOPE_SYSTEM : fence;
         pk.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
         pk.workgroup_size_x = 512; pk.workgroup_size_y = 1; pk.workgroup_size_z = 1;
         pk.grid_size_x = (uint32_t)wgs * 512; pk.grid_size_y = 1; pk.grid_size_z = 1;
@@ -435,9 +435,14 @@ int main(int argc, char** argv) {
             (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
             for (int j = 0; j < 3; ++j) { (void)hipStreamDestroy(sb[j]); (void)hipEventDestroy(ej[j]); }
         }
-        struct V { const char* name; const char* kernel; int kind, ns; bool barrier; int fence; uint32_t lds; int nq; };
+        struct V { const char* name; const char* kernel; int kind, ns; bool barrier; int fence; uint32_t lds; int nq; int acq = -1; };
         const V vs[] = {
             {"Q1  AQL, barrier, fences AGENT, plain ld/st            ", "k_plain", 0, 0, true, HSA_FENCE_SCOPE_AGENT},
+            // the two halves of the boundary priced apart, PLAIN loads and stores: every workgroup of every stage reads the whole x
+            // ring slot (so every XCD's L2 and every CU's L1 holds it) and two stages later other workgroups have rewritten it — a
+            // stale hit anywhere changes the final value and the verification reports it
+            {"Q1b AQL, barrier, acquire NONE + release AGENT, plain   ", "k_plain", 0, 0, true, HSA_FENCE_SCOPE_AGENT, 0, 0, HSA_FENCE_SCOPE_NONE},
+            {"Q1c AQL, barrier, acquire AGENT + release NONE, plain   ", "k_plain", 0, 0, true, HSA_FENCE_SCOPE_NONE, 0, 0, HSA_FENCE_SCOPE_AGENT},
             {"Q2  AQL, barrier, fences NONE, sc1 ld/st               ", "k_sc1", 0, 0, true, HSA_FENCE_SCOPE_NONE},
             {"Q2a AQL, barrier, fences AGENT, sc1 ld/st              ", "k_sc1", 0, 0, true, HSA_FENCE_SCOPE_AGENT},
             {"Q3  AQL, NO barrier, one counter, poll + arrive        ", "k_poll", 0, 0, false, HSA_FENCE_SCOPE_NONE},
@@ -458,11 +463,11 @@ int main(int argc, char** argv) {
             if (build(v.kind, v.ns)) return 1;
             double us = 0, sum = 0, best = 1e30;
             if (reset()) return 1;
-            int rc = run_chain(qs, v.nq ? v.nq : 1, dones, k, kargs, STAGES, WGS, v.barrier, v.fence, &us, v.lds); if (rc) return rc;
+            int rc = run_chain(qs, v.nq ? v.nq : 1, dones, k, kargs, STAGES, WGS, v.barrier, v.fence, &us, v.lds, v.acq); if (rc) return rc;
             verify("warmup", v.kind == 5);
             for (int r = 0; r < REPS; ++r) {
                 if (reset()) return 1;
-                rc = run_chain(qs, v.nq ? v.nq : 1, dones, k, kargs, STAGES, WGS, v.barrier, v.fence, &us, v.lds); if (rc) return rc;
+                rc = run_chain(qs, v.nq ? v.nq : 1, dones, k, kargs, STAGES, WGS, v.barrier, v.fence, &us, v.lds, v.acq); if (rc) return rc;
                 sum += us; if (us < best) best = us;
             }
             verify(v.name, v.kind == 5);
