@@ -42,11 +42,11 @@ def committed_rocprof_table(avg_bytes_per_launch, model, batch):
         if not os.path.exists(path):
             continue
         calls = us = 0.0
-        for line in open(path):
+        for line in open(path):      # rows of tools/prof_analyze.py: kernel  WGs thr calls /frame avg_us gap_us ms/frame %busy
             f = line.split()
-            if len(f) >= 4 and "k_gemv" in f[0]:
+            if len(f) >= 9 and f[0].startswith("k_gemv"):
                 try:
-                    calls += float(f[-3]); us += float(f[-3]) * float(f[-2])
+                    calls += float(f[-6]); us += float(f[-6]) * float(f[-4])
                 except ValueError:
                     pass
         if calls:
@@ -76,8 +76,12 @@ def main():
     ap.add_argument("--cpu-frames-single", type=int, default=8, help="frames of the single-thread CPU-baseline sample (~8 s)")
     ap.add_argument("--profile-frames", type=int, default=6)
     ap.add_argument("--ttfa-reps", type=int, default=5)
+    ap.add_argument("--headline-only", action="store_true", help="only the timed steps: no roofline replays, latency / TTFA, other batches, other configurations, "
+                    "EOS mix or CPU baseline (the command the committed rocprofv3 kernel table is taken from)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE.json side configurations (greedy, x-vector, 4k-token VoiceDesign, 0.6B single utterance)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = True; args.no_other_configs = True; args.also_batches = ""; args.ttfa_reps = 0
 
     import numpy as np
     import torch
@@ -227,12 +231,14 @@ def main():
     from qwen3_tts_rs_amd.api import bench_linear
     pf = max(2, args.profile_frames)
     sp = model.session(utts, q.SynthesisOptions(max_length=pf + 2, eos_token_id=None, seed=42, **samp))
-    sp.prefill(); sp.generate(1, use_graph=False)             # first frame outside the inventory (lazy initialisation)
-    sp.set_profile(True); sp.profile_shapes(reset=True); sp.profile_read(reset=True)
-    sp.generate(pf, use_graph=False)
-    insitu_ms, insitu_bytes, insitu_n = sp.profile_read(reset=True)
-    shapes = sp.profile_shapes(reset=True)
     wbytes, kvbytes = sp.frame_bytes((10 if args.workload != "voicedesign4k" else 4105) + args.frames // 2)
+    insitu_ms = insitu_bytes = 0.0; insitu_n = 0; shapes = []
+    if not args.headline_only:
+        sp.prefill(); sp.generate(1, use_graph=False)             # first frame outside the inventory (lazy initialisation)
+        sp.set_profile(True); sp.profile_shapes(reset=True); sp.profile_read(reset=True)
+        sp.generate(pf, use_graph=False)
+        insitu_ms, insitu_bytes, insitu_n = sp.profile_read(reset=True)
+        shapes = sp.profile_shapes(reset=True)
     sp.close()
     tot_bytes = tot_us = 0.0; launches = 0; per_shape = {}
     EPI = {0: "none", 1: "resid", 2: "silu", 3: "swiglu"}
@@ -299,6 +305,8 @@ def main():
     # ---- single-utterance latency + streaming TTFA (config[2]) ----
     lat = {}
     try:
+        if args.headline_only:
+            raise RuntimeError("skipped (--headline-only)")
         u1 = [q.Utterance(synthetic_prompt(args.prompt_tokens, 0), seed=42)]
         f1 = min(args.frames, 160)
         s1 = model.session(u1, q.SynthesisOptions(max_length=f1, eos_token_id=None, seed=42))
@@ -372,7 +380,7 @@ def main():
     # 8-frame step (q3_session_replace) — and (b) as lockstep sessions of B, each running until its longest row is done. Useful frames / wall of the generation
     # loop (prefills of the swapped-in requests included; no vocoder on either side). ----
     eos_mix = None
-    if world == 1 and not args.no_other_configs and args.workload == "customvoice":
+    if world == 1 and not args.no_other_configs and not args.headline_only and args.workload == "customvoice":
         try:
             rng = np.random.default_rng(2026)
             n_req = 4 * B

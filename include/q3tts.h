@@ -154,8 +154,8 @@ q3_status q3_model_mark_loaded(q3_model* m);
  * (128 positions x every layer and KV head, K and V) from one pool per model as its rows grow, and returns them when a
  * row is replaced or the session ends: a 4k-position prompt and a ten-position prompt share the memory, and
  * q3_session_replace relinks the prefilled pages into the row instead of copying them.
- * q3_model_kv_pool_limit: the most pages the pool may ever hold (0 = no limit but HBM); a session that needs a page
- * beyond it fails with Q3_KV_OVERFLOW before it runs (the reference's overflow bail). q3_model_kv_pool_info: page
+ * q3_model_kv_pool_limit: the most pages the model's sessions may hold at once (0 = no limit but HBM); a session that
+ * needs a page beyond it fails with Q3_KV_OVERFLOW before it runs (the reference's overflow bail). q3_model_kv_pool_info: page
  * geometry and occupancy (any pointer may be NULL). */
 q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages);
 q3_status q3_model_kv_pool_info(q3_model* m, int* page_positions, size_t* page_bytes, int* pages_total, int* pages_in_use, int* pages_peak);

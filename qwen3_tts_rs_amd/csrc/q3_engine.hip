@@ -156,40 +156,38 @@ struct UpW { const float *tw, *tb, *dww, *dwb, *nw, *nb, *p1w, *p1b, *p2w, *p2b,
 // ------------------------------------------------------------------------------------------------
 // Paged talker KV (north_star: "in-place paged KV in 288 GB HBM3E"; replaces the per-call preallocated cache of
 // kv_cache.rs:234-310 and its overflow bail :293-300). One pool per model: pages of KV_PAGE_POS positions x every layer
-// and KV head (q3_kernels.h), carved from slabs that are hipMalloc'ed on demand and kept for the model's lifetime. Sessions
+// and KV head (q3_kernels.h), carved from 32-page slabs that are hipMalloc'ed on demand and kept for the model's lifetime. Sessions
 // take pages as their rows cross page boundaries and hand them back when a row is replaced or the session ends, so a
 // 4k-position prompt and a ten-position prompt draw on the same memory, and a continuous-batching swap RELINKS the
 // prefilled pages of the side session into the row instead of copying extents. Pages are never cleared: the attention
 // kernels read a position only after it was written.
 // ------------------------------------------------------------------------------------------------
 struct KvPool {
+    // Slab layout (layer-major, so that ONE layer's K/V of every page of a slab sits in one contiguous run — the attention
+    // launch of a layer touches SLAB_SLOTS x 512 KB = 16 MB runs instead of one 64 KB run per (page, head) spread 29 MB
+    // apart, which cost ~1 us of address translation per launch at B = 8: the frame was 0.9 % slower than with contiguous
+    // extents):   slab[n_layers][2 (K, V)][SLAB_SLOTS][nkv][KV_PAGE_POS][HEAD_DIM] f32.
+    // A page = one slot of a slab, named by the address of its layer-0 K run; layer l is `l * layer_stride()` floats further,
+    // V `v_delta()` floats behind K.
+    static constexpr int SLAB_SLOTS = 32;
     std::mutex mu;
-    size_t page_floats = 0;               // 2 * n_layers * nkv * KV_PAGE_POS * HEAD_DIM
+    size_t run_floats = 0; int n_layers = 0;       // run = nkv * KV_PAGE_POS * HEAD_DIM (one layer's K of one page)
     std::vector<void*> slabs; std::vector<float*> free_pages;
     int total = 0, in_use = 0, peak = 0, limit = 0;       // pages; limit 0 = bounded by HBM only
-    size_t page_bytes() const { return page_floats * sizeof(float); }
+    size_t page_bytes() const { return (size_t)2 * n_layers * run_floats * sizeof(float); }
+    size_t layer_stride() const { return (size_t)2 * SLAB_SLOTS * run_floats; }
+    size_t v_delta() const { return (size_t)SLAB_SLOTS * run_floats; }
     // n pages or none: hipErrorOutOfMemory when the limit (q3_model_kv_pool_limit) or the device says no
     hipError_t take(int n, std::vector<float*>& out) {
         std::lock_guard<std::mutex> g(mu);
         if (n <= 0) return hipSuccess;
         if (limit > 0 && in_use + n > limit) return hipErrorOutOfMemory;
-        if ((int)free_pages.size() < n) {
-            int grow = n - (int)free_pages.size();
-            const int slab_min = (int)(((size_t)1 << 30) / page_bytes()) + 1;      // ~1 GiB per slab: few hipMallocs, none in steady state
-            if (grow < slab_min) grow = slab_min;
-            if (limit > 0 && total + grow > limit) grow = limit - total;
-            if (grow < n - (int)free_pages.size()) return hipErrorOutOfMemory;
+        while ((int)free_pages.size() < n) {          // whole slabs (~1 GB at 28 layers x 8 KV heads), kept for the model's lifetime: no hipMalloc in steady state
             void* slab = nullptr;
-            hipError_t e = hipMalloc(&slab, (size_t)grow * page_bytes());
-            if (e != hipSuccess && grow > n - (int)free_pages.size()) {            // a full slab does not fit any more: just what is needed
-                (void)hipGetLastError();
-                grow = n - (int)free_pages.size();
-                e = hipMalloc(&slab, (size_t)grow * page_bytes());
-            }
-            if (e != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+            if (hipMalloc(&slab, (size_t)SLAB_SLOTS * page_bytes()) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
             slabs.push_back(slab);
-            for (int i = grow - 1; i >= 0; --i) free_pages.push_back((float*)slab + (size_t)i * page_floats);
-            total += grow;
+            for (int i = SLAB_SLOTS - 1; i >= 0; --i) free_pages.push_back((float*)slab + (size_t)i * run_floats);
+            total += SLAB_SLOTS;
         }
         for (int i = 0; i < n; ++i) { out.push_back(free_pages.back()); free_pages.pop_back(); }
         in_use += n; if (in_use > peak) peak = in_use;
@@ -477,7 +475,7 @@ extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model*
     if (device < 0 || device >= ndev) return set_err(Q3_INVALID_ARG, "device %d not available (%d visible)", device, ndev);
     HIPC(hipSetDevice(device));
     std::unique_ptr<q3_model> m(new q3_model());
-    m->kv_pool.page_floats = (size_t)2 * cfg->n_layers * cfg->n_kv_heads * KV_PAGE_POS * HEAD_DIM;
+    m->kv_pool.run_floats = (size_t)cfg->n_kv_heads * KV_PAGE_POS * HEAD_DIM; m->kv_pool.n_layers = cfg->n_layers;
     m->cfg = *cfg; m->device = device;
     build_manifest(m.get());
     HIPC(hipMalloc((void**)&m->arena, m->arena_bytes));
@@ -501,13 +499,13 @@ static void model_destroy(q3_model* m) {
     delete m;
 }
 
-// Paged KV pool of the model (KvPool above). limit: the most pages the pool may ever hold (0 = HBM is the limit); a session
+// Paged KV pool of the model (KvPool above). limit: the most pages sessions may hold at once (0 = HBM is the limit); a session
 // that needs a page beyond it fails with Q3_KV_OVERFLOW — the reference's KV-overflow bail (kv_cache.rs:293-300).
 extern "C" q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages) {
     if (!m || m->device < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: no device model");
     if (max_pages < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: negative limit");
     std::lock_guard<std::mutex> g(m->kv_pool.mu);
-    if (max_pages > 0 && max_pages < m->kv_pool.total) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: the pool already holds %d pages", m->kv_pool.total);
+    if (max_pages > 0 && max_pages < m->kv_pool.in_use) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: %d pages are in use", m->kv_pool.in_use);
     m->kv_pool.limit = max_pages;
     return Q3_OK;
 }
@@ -1433,8 +1431,9 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     t.kcache = kc; t.vcache = vc; t.max_seq = max_seq; t.qbuf = b.Q; t.part = b.PART; t.out = b.ATT; t.ld_out = QD;
     t.B = B; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = n_splits; t.rows_per_seq = rows_per_seq;
     if (paged_layer >= 0) {
-        t.kv_pages = s->kv_table; t.kv_layer_off = (size_t)paged_layer * d.nkv * KV_PAGE_POS * HEAD_DIM;
-        t.kv_vdelta = (size_t)d.layers * d.nkv * KV_PAGE_POS * HEAD_DIM;
+        t.kv_pages = s->kv_table; t.kv_layer_off = (size_t)paged_layer * s->m->kv_pool.layer_stride();
+        t.kv_vdelta = s->m->kv_pool.v_delta();
+        t.kv_row_pages = (max_seq + KV_PAGE_POS - 1) / KV_PAGE_POS;
     }
     if (wp.part) { t.qkv_part = wp.part; t.qkv_ssq = wp.ssq; t.qkv_S = wp.S; t.qkv_K = d.H; t.qkv_eps = d.eps; }
     // Split-K projections (LinArgs::ksplit, k_gemv_sk2): o-proj and down-proj with N <= 2048 and K >= 2048 at 3 .. 16 rows (wide
@@ -2039,7 +2038,7 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
             t.qkv = QKV; t.ld_qkv = QD + 2 * KD; t.q_norm_w = w.q_norm; t.k_norm_w = w.k_norm; t.eps = d.eps;
             t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.pos_dev = nullptr; t.pos_static = t0;
             if (s->paged) {
-                t.kv_pages = s->kv_table; t.kv_layer_off = (size_t)i * d.nkv * KV_PAGE_POS * HEAD_DIM; t.kv_vdelta = (size_t)d.layers * d.nkv * KV_PAGE_POS * HEAD_DIM;
+                t.kv_pages = s->kv_table; t.kv_layer_off = (size_t)i * m->kv_pool.layer_stride(); t.kv_vdelta = m->kv_pool.v_delta();
             } else { t.kcache = s->kcache + (size_t)i * s->kv_layer_stride; t.vcache = s->vcache + (size_t)i * s->kv_layer_stride; }
             t.max_seq = s->max_seq; t.qbuf = Qb; t.part = nullptr; t.out = ATT; t.ld_out = QD;
             t.B = rows; t.nh = d.nh; t.nkv = d.nkv; t.n_splits = 1; t.rows_per_seq = ch;
@@ -2262,13 +2261,13 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         const char* e = getenv("Q3_AQL");
         const int mode = e ? atoi(e) : 0;
         if (mode > 0) {
-            q3::AqlPolicy pol; pol.fence = mode >= 2 ? 0 : 1;
+            q3::AqlPolicy pol; pol.fence = mode == 2 ? 0 : 1;
             pol.acquire = pol.release = pol.fence;
             if (const char* a = getenv("Q3_AQL_ACQ")) pol.acquire = atoi(a);        // probes: the two fences of a boundary priced separately
             if (const char* r = getenv("Q3_AQL_REL")) pol.release = atoi(r);
             std::string why;
             s->aql = q3::aql_program_create(s->graph, s->m->device, pol, &why);
-            if (s->aql) s->aql_mode = mode >= 2 ? 2 : 1;
+            if (s->aql) s->aql_mode = mode == 2 ? 2 : 1;
             else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
         }
     }
@@ -2338,8 +2337,9 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     const int limit = limit_req < sq.limit ? limit_req : sq.limit;
     if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
     if (s->paged != side->paged) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the sessions disagree on KV paging");
-    // paged rows grow page by page: only the RoPE table bounds a row (prompt_budget is not needed); contiguous extents were sized at creation
-    const int kv_cap = s->paged ? (m->rope_len < KV_MAX_PAGES * KV_PAGE_POS ? m->rope_len : KV_MAX_PAGES * KV_PAGE_POS) : s->max_seq;
+    // max_seq bounds a row in both layouts: the captured frame was specialised for it (key splits, the page-table form of the
+    // attention kernel); with pages it reserves nothing — only the pages a row really reaches are taken from the pool
+    const int kv_cap = s->max_seq;
     if (side->prefill_len + limit + 1 > kv_cap) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", side->prefill_len, limit, kv_cap);
     Q3C(q3_session_prefill(side.get()));               // ends with a synchronisation of the side stream
     lap("prefill");

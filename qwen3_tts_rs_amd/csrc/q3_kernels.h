@@ -11,10 +11,11 @@ constexpr int HEAD_DIM = 128;        // talker / code-predictor head dim (kernel
 constexpr int MAX_SPLITS = 64;       // KV splits of the decode attention (16 unless the context is long, see q3_session_create)
 constexpr int PART_STRIDE = HEAD_DIM + 2;   // partial record: acc[128], m, l
 // Paged talker KV (replaces the reference's preallocated per-call cache, kv_cache.rs:234-310): a PAGE holds KV_PAGE_POS
-// consecutive positions of ONE sequence for every layer and KV head, K half then V half —
-//   page[2][n_layers][nkv][KV_PAGE_POS][HEAD_DIM] f32 (29.4 MB at 28 layers x 8 KV heads; a (layer, head) run is 64 KB).
-// A sequence owns a row of KV_MAX_PAGES page pointers in device memory (64 x 128 = 8192 positions = the RoPE table);
-// position p of (layer l, head h) lives at pages[p / 128] + l * nkv * 16384 + h * 16384 + (p % 128) * 128.
+// consecutive positions of ONE sequence for every layer and KV head, K and V (29.4 MB at 28 layers x 8 KV heads; a
+// (layer, head) run is 64 KB). Pages are slots of layer-major slabs (KvPool, q3_engine.hip); a page is named by the
+// address of its layer-0 K run. A sequence owns a row of KV_MAX_PAGES page pointers in device memory (64 x 128 = 8192
+// positions = the RoPE table); the K row of position p of (layer l, head h) lives at
+//   pages[p / 128] + l * layer_stride + h * 16384 + (p % 128) * 128 floats, its V row kv_vdelta floats further.
 constexpr int KV_PAGE_POS = 128, KV_PAGE_SHIFT = 7, KV_MAX_PAGES = 64;
 
 // ---- Q3_TRACE (development builds only: tools/trace_build.sh -> libq3tts_trace.so; never defined in the product) ----
@@ -130,9 +131,10 @@ struct AttnArgs {
     float* kcache; float* vcache;           // [B][nkv][max_seq][128]
     int max_seq;
     // paged form (the talker): kv_pages != nullptr -> kcache / vcache / max_seq are unused; kv_pages[seq * KV_MAX_PAGES + p / 128]
-    // is the page of position p, kv_layer_off = layer * nkv * KV_PAGE_POS * HEAD_DIM floats into it, kv_vdelta = floats from
-    // a K row to its V row (n_layers * nkv * KV_PAGE_POS * HEAD_DIM)
+    // is the page of position p, kv_layer_off = floats from the page's layer-0 K run to this layer's, kv_vdelta = floats from
+    // a K row to its V row (both constants of the pool's slab layout)
     const unsigned long long* kv_pages = nullptr; size_t kv_layer_off = 0, kv_vdelta = 0;
+    int kv_row_pages = 0;                   // most pages a row of this session can ever hold (0 = unknown: up to KV_MAX_PAGES)
     float* qbuf;                            // [B][nh][128] normed+roped q
     float* part;                            // [B][nh][n_splits][PART_STRIDE]
     float* out; int ld_out;                 // [B][nh*128]
@@ -165,10 +167,19 @@ struct AttnArgs {
 #if defined(__HIPCC__)
 // K row of (sequence, kv head, position) — contiguous extent or page (one table fetch: the cold paths; k_attn_fused keeps the
 // sequence's table row in registers instead). The V row is `+ kv_vd(a)` floats further.
+// Row rotation inside a (page, head) run: position p sits in row (p + kv_rot) % 128. Every run starts on a 64 KB boundary, and
+// the workgroups of a decode-attention launch all read the same position range of their sequences at the same time — without
+// the rotation the 64 (sequence, head) streams of a B = 8 launch walk addresses that are equal modulo 64 KB (the contiguous
+// layout staggers them by max_seq * 512 B) and crowd the same memory channels.
+__device__ __forceinline__ int kv_rot(unsigned long long page, int kvh) {
+    const unsigned h = (unsigned)(page >> 19);            // slot number of the page within its slab region (512 KB apart at 8 KV heads)
+    return (int)((kvh * 16 + (h & 15) * 8 + ((h >> 4) & 7)) & (KV_PAGE_POS - 1));
+}
 __device__ __forceinline__ float* kv_krow(const AttnArgs& a, int seq, int kvh, int p) {
     if (a.kv_pages) {
-        float* pg = reinterpret_cast<float*>(a.kv_pages[(size_t)seq * KV_MAX_PAGES + (p >> KV_PAGE_SHIFT)]);
-        return pg + a.kv_layer_off + ((size_t)kvh * KV_PAGE_POS + (p & (KV_PAGE_POS - 1))) * HEAD_DIM;
+        const unsigned long long page = a.kv_pages[(size_t)seq * KV_MAX_PAGES + (p >> KV_PAGE_SHIFT)];
+        float* pg = reinterpret_cast<float*>(page);
+        return pg + a.kv_layer_off + ((size_t)kvh * KV_PAGE_POS + ((p + kv_rot(page, kvh)) & (KV_PAGE_POS - 1))) * HEAD_DIM;
     }
     return a.kcache + (((size_t)seq * a.nkv + kvh) * a.max_seq + p) * HEAD_DIM;
 }

@@ -467,7 +467,11 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
 // Every wave asks for the sequence's table row first — one entry per lane, beside the position load — and a row address
 // then costs two ds_bpermute (page pointer of p / 128) instead of a dependent trip to memory: the first K/V requests
 // leave as early as with one contiguous extent per sequence.
-template <int NREP, bool PAGED>
+// PAGED = 1: rows of at most 8 pages (1024 positions: every bench session) — the table row is ONE scalar load (the address
+// is uniform: 64 bytes through the scalar cache, which the workgroups of a CU share) spread over lanes 0..7; PAGED = 2: up to
+// KV_MAX_PAGES pages, one entry per lane from a vector load (2048 waves asking the same 4 KB of table cost ~1 us per launch
+// at B = 8 — measured: the frame 1.0 % slower than with contiguous extents — hence the scalar form where it fits).
+template <int NREP, int PAGED>
 __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const float* p_kc, const float* p_vc, const float* p_qkv, const float* p_qw,
                                                     const float* p_kw, int p_max_seq, int p_pk, AttnArgs a_in) {
     AttnArgs a = a_in;
@@ -475,9 +479,18 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     a.n_splits = p_pk & 255; a.nkv = (p_pk >> 8) & 255; a.nh = (p_pk >> 16) & 255;
     uint32_t tab_lo = 0, tab_hi = 0;
     size_t pg_off = 0, pg_vd = 0;
-    if constexpr (PAGED) {
-        const unsigned long long e = reinterpret_cast<const unsigned long long*>(p_kc)[(size_t)blockIdx.z * KV_MAX_PAGES + (threadIdx.x & 63)];
-        tab_lo = (uint32_t)e; tab_hi = (uint32_t)(e >> 32);
+    if constexpr (PAGED != 0) {
+        const unsigned long long* trow = reinterpret_cast<const unsigned long long*>(p_kc) + (size_t)blockIdx.z * KV_MAX_PAGES;
+        if constexpr (PAGED == 1) {
+            unsigned long long e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = trow[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if ((int)(threadIdx.x & 63) == i) { tab_lo = (uint32_t)e[i]; tab_hi = (uint32_t)(e[i] >> 32); }
+        } else {
+            const unsigned long long e = trow[threadIdx.x & 63];
+            tab_lo = (uint32_t)e; tab_hi = (uint32_t)(e >> 32);
+        }
         pg_off = reinterpret_cast<size_t>(p_vc) + (size_t)blockIdx.y * KV_PAGE_POS * HEAD_DIM;
         pg_vd = (size_t)p_max_seq;
     } else {
@@ -497,12 +510,25 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     const int start = split * chunk;
     const int end = (start + chunk) < len ? (start + chunk) : len;
     const float scale = 0.08838834764831845f;
-    const size_t cache_base = PAGED ? 0 : ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM;
-    // K row of position p (p may differ between lanes; every lane of the wave must be active: ds_bpermute)
-    auto krow_paged = [&](int p) -> float* {
-        const int idx = (p >> KV_PAGE_SHIFT) << 2;
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)tab_lo), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)tab_hi);
-        return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo) + pg_off + (size_t)(p & (KV_PAGE_POS - 1)) * HEAD_DIM;
+    const size_t cache_base = PAGED != 0 ? 0 : ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM;
+    // K row of position p <= pos. The two 32-lane groups of a wave ask for neighbouring positions (pe = the even group's, pe + 1),
+    // so a wave needs at most TWO pages per request: page i = min(pe, pos) / 128 — wave-uniform, read from the table lanes with
+    // v_readlane, no LDS and nothing to wait for — and page i + 1; a lane picks by its own position. A lane with nothing to
+    // fetch (ok = false) reads row 0 of page 0, as the contiguous form does: ONE row per sequence and head, always cached.
+    // (Measured on the B = 8 frame against contiguous extents: ds_bpermute per lane +0.9 %; readlane with min(p, pos) as the
+    // dummy row +1.4 % — every dummy became a distinct row of another split's range, 40 % more K/V traffic.)
+    const int pos_page = pos >> KV_PAGE_SHIFT;
+    unsigned long long pg_zero = 0;
+    if constexpr (PAGED != 0)
+        pg_zero = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)tab_hi, 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)tab_lo, 0);
+    auto krow_paged = [&](int p, int pe, bool ok) -> float* {
+        int ib = pe >> KV_PAGE_SHIFT; ib = ib < pos_page ? ib : pos_page;
+        ib = __builtin_amdgcn_readfirstlane(ib);
+        const int ib1 = ib + 1 < KV_MAX_PAGES ? ib + 1 : ib;
+        const unsigned long long p0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)tab_hi, ib) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)tab_lo, ib);
+        const unsigned long long p1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)tab_hi, ib1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)tab_lo, ib1);
+        const unsigned long long pg = ok ? ((p >> KV_PAGE_SHIFT) == ib ? p0 : p1) : pg_zero;
+        return reinterpret_cast<float*>(pg) + pg_off + (size_t)(((ok ? p : 0) + kv_rot(pg, (int)blockIdx.y)) & (KV_PAGE_POS - 1)) * HEAD_DIM;
     };
 
     // The first two cached K/V rows of this group are requested NOW, before the q/k-norm + RoPE prologue: they depend
@@ -515,8 +541,8 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     const size_t base = cache_base + li * 4;
     auto request = [&](int p, float4& ko, float4& vo) {
         const int ps = (p < end && p != pos) ? p : 0;               // row 0 always exists
-        if constexpr (PAGED) {
-            const float* kr = krow_paged(ps) + li * 4;
+        if constexpr (PAGED != 0) {
+            const float* kr = krow_paged(p, p - (grp & 1), p < end && p != pos) + li * 4;
             ko = *reinterpret_cast<const float4*>(kr);
             vo = *reinterpret_cast<const float4*>(kr + pg_vd);
         } else {
@@ -572,7 +598,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
             if (split == pos / chunk) {
                 float* kc; float* vc;
-                if constexpr (PAGED) { kc = krow_paged(pos); vc = kc + pg_vd; }          // (wave-uniform branch: all 64 lanes are here)
+                if constexpr (PAGED != 0) { kc = krow_paged(pos, pos, true); vc = kc + pg_vd; }
                 else { kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM; vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM; }
                 kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
             }
@@ -656,12 +682,15 @@ hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
     if (a.n_splits > 255 || a.nh > 255 || a.nkv > 255) return hipErrorInvalidValue;
     dim3 grid(a.n_splits, a.nkv, a.B);
     const int pk = a.n_splits | (a.nkv << 8) | (a.nh << 16);
-#define Q3_AF(R) hipLaunchKernelGGL((k_attn_fused<R, false>), grid, dim3(256), 0, st, a.pos_dev, (const float*)a.kcache, (const float*)a.vcache, a.qkv, a.q_norm_w, a.k_norm_w, a.max_seq, pk, a)
-#define Q3_AFP(R) hipLaunchKernelGGL((k_attn_fused<R, true>), grid, dim3(256), 0, st, a.pos_dev, reinterpret_cast<const float*>(a.kv_pages), reinterpret_cast<const float*>(a.kv_layer_off), \
-                                     a.qkv, a.q_norm_w, a.k_norm_w, (int)a.kv_vdelta, pk, a)
+#define Q3_AF(R) hipLaunchKernelGGL((k_attn_fused<R, 0>), grid, dim3(256), 0, st, a.pos_dev, (const float*)a.kcache, (const float*)a.vcache, a.qkv, a.q_norm_w, a.k_norm_w, a.max_seq, pk, a)
+#define Q3_AFP(R, P) hipLaunchKernelGGL((k_attn_fused<R, P>), grid, dim3(256), 0, st, a.pos_dev, reinterpret_cast<const float*>(a.kv_pages), reinterpret_cast<const float*>(a.kv_layer_off), \
+                                        a.qkv, a.q_norm_w, a.k_norm_w, (int)a.kv_vdelta, pk, a)
     if (a.kv_pages) {
         if (a.kv_vdelta > 0x7fffffffu) return hipErrorInvalidValue;
-        if (nrep == 1) Q3_AFP(1); else if (nrep == 2) Q3_AFP(2); else if (nrep == 4) Q3_AFP(4);
+        const bool few = a.kv_row_pages > 0 && a.kv_row_pages <= 8;        // the session's rows never hold more than 8 pages
+        if (nrep == 1) { if (few) Q3_AFP(1, 1); else Q3_AFP(1, 2); }
+        else if (nrep == 2) { if (few) Q3_AFP(2, 1); else Q3_AFP(2, 2); }
+        else if (nrep == 4) { if (few) Q3_AFP(4, 1); else Q3_AFP(4, 2); }
         else return hipErrorInvalidValue;
     } else
     if (nrep == 1) Q3_AF(1); else if (nrep == 2) Q3_AF(2); else if (nrep == 4) Q3_AF(4);

@@ -1242,3 +1242,35 @@ def test_native_batcher(pair):
     s1 = gm.session([utts[2]], utts[2].options); s1.prefill(); s1.generate(100, use_graph=False)
     np.testing.assert_array_equal(codes, s1.codes(0)); s1.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_batcher_bad_first_request_fails_alone(pair):
+    """the batcher opens its session on idle rows built from fixed valid values, never from the first queued
+    request — a malformed FIRST request (repetition_penalty <= 0, NaN temperature) fails alone at its own swap and the queue
+    moves on; budgets beyond the RoPE table are refused at q3_batcher_create."""
+    cfg, gm, om = pair
+    opts = q.SynthesisOptions(max_length=6, seed=1, eos_token_id=None)
+    with pytest.raises(_lib.Q3Error, match="RoPE table"):
+        q.Batcher(gm, slots=2, frame_budget=8000, prompt_budget=4000, options=opts)
+    b = q.Batcher(gm, slots=2, frame_budget=6, prompt_budget=0, options=opts)
+    try:
+        bad = _utts("custom", 5, index=1, hidden=cfg.hidden)
+        bad.options = q.SynthesisOptions(max_length=6, seed=1, eos_token_id=None, repetition_penalty=0.0)
+        bad2 = _utts("custom", 5, index=2, hidden=cfg.hidden)
+        bad2.options = q.SynthesisOptions(max_length=6, seed=1, eos_token_id=None, temperature=float("nan"))
+        good = [_utts("custom", 4 + i, index=3 + i, hidden=cfg.hidden) for i in range(3)]
+        t_bad = b.submit(bad, want_pcm=False); t_bad2 = b.submit(bad2, want_pcm=False)
+        t_good = [b.submit(u, want_pcm=False) for u in good]
+        for _ in range(30):
+            running, queued, _ = b.step(4)
+            if running == 0 and queued == 0:
+                break
+        assert b.poll(t_bad)[0] == q.Batcher.FAILED and b.poll(t_bad2)[0] == q.Batcher.FAILED
+        for u, t in zip(good, t_good):
+            assert b.poll(t)[0] == q.Batcher.DONE
+            codes, _ = b.fetch(t)
+            s1 = gm.session([u], opts); s1.prefill(); s1.generate(6, use_graph=False)
+            np.testing.assert_array_equal(codes, s1.codes(0)); s1.close()
+    finally:
+        b.close()

@@ -37,11 +37,12 @@ def _run(model, utts, frames, graph, monkeypatch, contiguous):
     return out, pcm
 
 
-@pytest.mark.parametrize("kind,B,frames", [("custom", 3, 300), ("custom", 1, 140), ("design200", 2, 150), ("design600", 1, 40)])
+@pytest.mark.parametrize("kind,B,frames", [("custom", 3, 300), ("custom", 1, 140), ("design200", 2, 150), ("design600", 1, 40), ("design1100", 1, 30)])
 def test_paged_equals_contiguous_bit_for_bit(gm, kind, B, frames, monkeypatch):
     """Same sessions with paged and with contiguous KV: identical codes. 300 frames cross two page boundaries inside the
     captured frame; a 200-token instruct prompt fills page 0 and 1 in the chunked prefill, 600 tokens go through the GEMM
-    prefill (bf16x3 planes built from pages) and end in page 4."""
+    prefill (bf16x3 planes built from pages) and end in page 4; 1100 tokens make the row longer than 8 pages (the vector-loaded
+    form of the page-table row; shorter sessions use the scalar-loaded one)."""
     def utt(i):
         if kind == "custom":
             return q.Utterance(synthetic_prompt(12, i), q.Speaker.Ryan, q.Language.English, seed=40 + i)

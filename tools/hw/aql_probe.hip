@@ -18,7 +18,7 @@
 // Every spin is bounded; every chain is verified (x carries the stage index, so ONE stale 16-byte read anywhere changes the
 // final value).
 // Build: hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-kernarg-preload-count=15 aql_probe.hip -o aql_probe -lhsa-runtime64
-//        hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-kernarg-preload-count=15 --genco aql_probe.hip -o aql_probe.hsaco
+//        hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-kernarg-preload-count=15 --cuda-device-only --no-gpu-bundle-output -c aql_probe.hip -o aql_probe.hsaco
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
