@@ -166,7 +166,7 @@ struct KvPool {
     // Slab layout (layer-major, so that ONE layer's K/V of every page of a slab sits in one contiguous run — the attention
     // launch of a layer touches SLAB_SLOTS x 512 KB = 16 MB runs instead of one 64 KB run per (page, head) spread 29 MB
     // apart, which cost ~1 us of address translation per launch at B = 8: the frame was 0.9 % slower than with contiguous
-    // extents):   slab[n_layers][2 (K, V)][SLAB_SLOTS][nkv][KV_PAGE_POS][HEAD_DIM] f32.
+    // extents):   slab[n_layers][2 (K, V)][SLAB_SLOTS][nkv][KV_PAGE_POS][HEAD_DIM] f32 (+ padding, below).
     // A page = one slot of a slab, named by the address of its layer-0 K run; layer l is `l * layer_stride()` floats further,
     // V `v_delta()` floats behind K.
     static constexpr int SLAB_SLOTS = 32;
@@ -174,9 +174,14 @@ struct KvPool {
     size_t run_floats = 0; int n_layers = 0;       // run = nkv * KV_PAGE_POS * HEAD_DIM (one layer's K of one page)
     std::vector<void*> slabs; std::vector<float*> free_pages;
     int total = 0, in_use = 0, peak = 0, limit = 0;       // pages; limit 0 = bounded by HBM only
+    // K -> V and layer -> layer distances are kept OFF powers of two (17 KB of padding behind every region): a lane asks for
+    // the K row and the V row of a position together, and at exactly 16 MB apart the two requests meet in the same memory
+    // channel (k_attn_fused 7.6 vs 6.9 us per launch at B = 8 against the contiguous caches, whose distance is arbitrary)
+    static constexpr size_t PAD_FLOATS = 17 * 256;
     size_t page_bytes() const { return (size_t)2 * n_layers * run_floats * sizeof(float); }
-    size_t layer_stride() const { return (size_t)2 * SLAB_SLOTS * run_floats; }
-    size_t v_delta() const { return (size_t)SLAB_SLOTS * run_floats; }
+    size_t v_delta() const { return (size_t)SLAB_SLOTS * run_floats + PAD_FLOATS; }
+    size_t layer_stride() const { return 2 * v_delta(); }
+    size_t slab_bytes() const { return (size_t)n_layers * layer_stride() * sizeof(float); }
     // n pages or none: hipErrorOutOfMemory when the limit (q3_model_kv_pool_limit) or the device says no
     hipError_t take(int n, std::vector<float*>& out) {
         std::lock_guard<std::mutex> g(mu);
@@ -184,7 +189,7 @@ struct KvPool {
         if (limit > 0 && in_use + n > limit) return hipErrorOutOfMemory;
         while ((int)free_pages.size() < n) {          // whole slabs (~1 GB at 28 layers x 8 KV heads), kept for the model's lifetime: no hipMalloc in steady state
             void* slab = nullptr;
-            if (hipMalloc(&slab, (size_t)SLAB_SLOTS * page_bytes()) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+            if (hipMalloc(&slab, slab_bytes()) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
             slabs.push_back(slab);
             for (int i = SLAB_SLOTS - 1; i >= 0; --i) free_pages.push_back((float*)slab + (size_t)i * run_floats);
             total += SLAB_SLOTS;
@@ -1841,8 +1846,11 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
         }
     }
     s->ckv_layer_stride = (size_t)B * c.cp_kv_heads * (c.n_groups + 1) * HEAD_DIM;
-    HIPC(s->pool.alloc(&s->ckcache, s->ckv_layer_stride * c.cp_layers));
-    HIPC(s->pool.alloc(&s->cvcache, s->ckv_layer_stride * c.cp_layers));
+    // K and V of the code predictor in ONE block: k_attn_cp takes their distance as a 32-bit float count, and two blocks of the
+    // size-class cache can lie further apart than that (the launch then silently fell back to k_attn_fused: 70 nodes per
+    // frame 1.1 us slower each — seen in a profiling run of round 4)
+    HIPC(s->pool.alloc(&s->ckcache, 2 * s->ckv_layer_stride * c.cp_layers + 64));
+    s->cvcache = s->ckcache + s->ckv_layer_stride * c.cp_layers + 64;
     HIPC(s->pool.alloc(&s->rows, ((size_t)rows + (size_t)B * s->row_cap) * H));      // + one replacement slot per row (q3_session_replace)
     HIPC(s->pool.alloc(&s->limit, B));
     HIPC(s->pool.alloc(&s->sample_rows, B));

@@ -178,7 +178,11 @@ __device__ __forceinline__ int kv_rot(unsigned long long page, int kvh) {
 __device__ __forceinline__ float* kv_krow(const AttnArgs& a, int seq, int kvh, int p) {
     if (a.kv_pages) {
         const unsigned long long page = a.kv_pages[(size_t)seq * KV_MAX_PAGES + (p >> KV_PAGE_SHIFT)];
-        float* pg = reinterpret_cast<float*>(page);
+        // the page address as an OFFSET from a pointer the compiler knows to be global (a kernel argument): a pointer made from
+        // an integer is generic, and its loads become flat_load — which also count on lgkmcnt, so every LDS / scalar wait
+        // then waits for the K/V stream (k_attn_fused: +1 us per launch until its page pointers were formed this way)
+        float* pg = reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<unsigned long long*>(a.kv_pages)) +
+                                             (ptrdiff_t)(page - reinterpret_cast<unsigned long long>(a.kv_pages)));
         return pg + a.kv_layer_off + ((size_t)kvh * KV_PAGE_POS + ((p + kv_rot(page, kvh)) & (KV_PAGE_POS - 1))) * HEAD_DIM;
     }
     return a.kcache + (((size_t)seq * a.nkv + kvh) * a.max_seq + p) * HEAD_DIM;

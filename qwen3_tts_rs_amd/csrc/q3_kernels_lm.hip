@@ -528,7 +528,12 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
         const unsigned long long p0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)tab_hi, ib) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)tab_lo, ib);
         const unsigned long long p1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)tab_hi, ib1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)tab_lo, ib1);
         const unsigned long long pg = ok ? ((p >> KV_PAGE_SHIFT) == ib ? p0 : p1) : pg_zero;
-        return reinterpret_cast<float*>(pg) + pg_off + (size_t)(((ok ? p : 0) + kv_rot(pg, (int)blockIdx.y)) & (KV_PAGE_POS - 1)) * HEAD_DIM;
+        // (the address is formed as an offset from the table pointer — a kernel argument, known to be global — not cast from
+        // the integer: a generic pointer's loads are flat_load, which count on lgkmcnt as well and made every LDS / scalar
+        // wait of the loop wait for the K/V stream: +1 us per launch)
+        const char* gbase = reinterpret_cast<const char*>(p_kc);
+        float* page = reinterpret_cast<float*>(const_cast<char*>(gbase) + (ptrdiff_t)(pg - reinterpret_cast<unsigned long long>(gbase)));
+        return page + pg_off + (size_t)(((ok ? p : 0) + kv_rot(pg, (int)blockIdx.y)) & (KV_PAGE_POS - 1)) * HEAD_DIM;
     };
 
     // The first two cached K/V rows of this group are requested NOW, before the q/k-norm + RoPE prologue: they depend

@@ -11,6 +11,7 @@ for f in q3_kernels_lm q3_kernels_gemv q3_kernels_wide q3_kernels_codec q3_kerne
 done
 $HIPCC -O2 -std=c++17 -fPIC -c "$SRC/q3_io.cpp" -o "$B/q3_io.o" & pids+=($!)
 $HIPCC -O2 -std=c++17 -fPIC -c "$SRC/q3_dp.cpp" -o "$B/q3_dp.o" & pids+=($!)
+$HIPCC -O2 -std=c++17 -fPIC -c "$SRC/q3_aql.cpp" -o "$B/q3_aql.o" & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$ROOT/qwen3_tts_rs_amd/libq3tts_trace.so" "$B"/*.o -ldl
 echo "built $ROOT/qwen3_tts_rs_amd/libq3tts_trace.so"
