@@ -135,8 +135,7 @@ def main():
     load_s = time.time() - t_load
 
     # ---- workload ----
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from common import synthetic_prompt
+    from qwen3_tts_rs_amd.synth import synthetic_prompt
     B = args.batch
     n_total = B * world
     my_idx = dp.shard_indices(n_total, rank, world)
@@ -426,6 +425,7 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))      # the oracle wrapper is test infrastructure: only this baseline leg touches it
             import oracle as O
             from common import oracle_model
             t_o = time.time()

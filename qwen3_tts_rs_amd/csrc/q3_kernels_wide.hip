@@ -63,13 +63,20 @@ struct WideArgs {
     const float* x; int ldx; const float* norm_w;
     int M, N, K, kst;                            // kst = k-steps of 32 per tile row of the image (Kpad / 32)
     int S, Ks, nmat, rgm;                        // K slices, k per slice (multiple of 128), matrices, 128-row groups per matrix
+    unsigned w_bytes, x_bytes;                   // extents of one weight image / of x: the buffer descriptors' num_records
     float* part;                                 // [S][nmat][M][N] slice sums
     float* ssq;                                  // [S][M] sum of x^2 per row and slice (fused RMSNorm)
 };
 
 // One workgroup = NWV waves x one 16-row weight tile (128 or 64 weight rows) x one K slice, all M <= 16*MT rows of x.
-// The K slice is walked in 128-column chunks; the requests of chunk c+1 (x, norm weight, weight tiles) are issued before
-// the MFMAs of chunk c, into a second register set — two sets used alternately, no copies.
+// The K slice is walked in 128-column chunks through a RING OF FOUR register sets (round 4): the requests of chunk c + 3
+// (x, norm weight, weight tiles) are issued before the MFMAs of chunk c. With two sets (round 3) a chunk was requested one
+// MFMA phase (~0.4 us) before its staging needed it and every chunk paid the rest of a memory round trip: 8 chunks of the
+// talker's gate/up slice took 32 us against ~4 us of matrix time. The workgroup is alone on its CU (512 threads), so the
+// 256-VGPR budget of two waves per SIMD is there to be used. Every request is UNCONDITIONAL — `s_waitcnt vmcnt` counts in
+// issue order and a load behind a branch makes hipcc wait for everything in flight — and goes through buffer descriptors:
+// the requests past the slice's last chunk get an offset beyond num_records, which the hardware answers with zeros
+// without touching memory.
 template <bool RMS, int MT, int NWV>
 __global__ __launch_bounds__(NWV * 64) void k_wide_gemm(WideArgs a) {
     __shared__ __attribute__((aligned(16))) u32x4_t xs[3][MT][4][64];       // [plane][column tile][k-step of the chunk][lane]: 12 KB x MT
@@ -79,7 +86,11 @@ __global__ __launch_bounds__(NWV * 64) void k_wide_gemm(WideArgs a) {
     const int mat = rg / a.rgm, rgi = rg - mat * a.rgm;
     const int tile = rgi * NWV + wave;
     const bool tile_ok = tile * 16 < a.N;
-    const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(mat ? a.W2 : a.W) + (size_t)(tile_ok ? tile : 0) * a.kst * 64 + lane;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(mat ? a.W2 : a.W), 0, (int)a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RMS ? a.norm_w : a.x), 0, RMS ? a.K * 4 : 0, 0x00020000);
+    const unsigned w_lane = ((unsigned)(tile_ok ? tile : 0) * (unsigned)a.kst * 64u + (unsigned)lane) * 16u;      // byte offset of this lane in its tile row (image < 4 GB)
+    constexpr unsigned OOB = 0x80000000u;            // beyond any num_records: the load returns zeros, no memory access
     const int k_begin = s * a.Ks, k_end = (k_begin + a.Ks) < a.K ? (k_begin + a.Ks) : a.K;
     constexpr int NIT = (MT * 4 + NWV - 1) / NWV;     // staging items (column tile, k-step) per wave and chunk
     f32x4_t acc[MT];
@@ -92,19 +103,24 @@ __global__ __launch_bounds__(NWV * 64) void k_wide_gemm(WideArgs a) {
     struct Set { float4 xa[NIT], xb[NIT], na[NIT], nb[NIT]; u32x4_t wa[4]; };
     // requests of a chunk: this wave's share of x (and of the norm weight) first — they come back first and feed the staging —
     // then its four weight tiles
+    auto ld4 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    };
     auto request = [&](Set& r, int k0) {
+        const bool live = k0 < k_end;                  // wave-uniform; a dead chunk's requests all go out of range
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             const int it = wave + NWV * j, t = it >> 2, ks = it & 3;
             const int m = 16 * t + m16, kk = k0 + (4 * ks + kg) * 8;
-            const bool ok = it < MT * 4 && m < a.M;
-            const float* px = a.x + (size_t)(ok ? m : 0) * a.ldx + kk;
-            r.xa[j] = ok ? *reinterpret_cast<const float4*>(px) : float4{0.f, 0.f, 0.f, 0.f};
-            r.xb[j] = ok ? *reinterpret_cast<const float4*>(px + 4) : float4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (RMS) { r.na[j] = *reinterpret_cast<const float4*>(a.norm_w + kk); r.nb[j] = *reinterpret_cast<const float4*>(a.norm_w + kk + 4); }
+            const bool ok = live && it < MT * 4 && m < a.M;
+            const unsigned xo = ok ? ((unsigned)m * (unsigned)a.ldx + (unsigned)kk) * 4u : OOB;
+            r.xa[j] = ld4(xrs, xo);
+            r.xb[j] = ld4(xrs, xo + 16u);
+            if constexpr (RMS) { const unsigned no = live ? (unsigned)kk * 4u : OOB; r.na[j] = ld4(nrs, no); r.nb[j] = ld4(nrs, no + 16u); }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r.wa[i] = __builtin_nontemporal_load(wp + (size_t)((k0 >> 5) + i) * 64);
+        for (int i = 0; i < 4; ++i)
+            r.wa[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(live ? w_lane + (unsigned)((k0 >> 5) + i) * 1024u : OOB), 0, 2));    // nt: streamed once
     };
     // staging: split once, park the B operands of the whole workgroup in LDS (lane-linear fragments: conflict-free b128)
     auto stage = [&](const Set& r) {
@@ -136,20 +152,34 @@ __global__ __launch_bounds__(NWV * 64) void k_wide_gemm(WideArgs a) {
                 }
         }
     };
-    Set A, B;
-    request(A, k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += 256) {
-        stage(A);
+    // one chunk: stage it, request the chunk AHEAD chunks later into the set that came free a step ago, multiply
+    auto step = [&](Set& cur, Set& nxt, int k0, int ahead) {
+        stage(cur);
         __syncthreads();
-        if (k0 + 128 < k_end) request(B, k0 + 128);          // in flight under this chunk's MFMAs
-        multiply(A);
+        __builtin_amdgcn_sched_barrier(0); request(nxt, k0 + ahead * 128); __builtin_amdgcn_sched_barrier(0);      // pinned ahead of the MFMAs
+        multiply(cur);
         __syncthreads();                                     // the next staging overwrites xs
-        if (k0 + 128 >= k_end) break;
-        stage(B);
-        __syncthreads();
-        if (k0 + 256 < k_end) request(A, k0 + 256);
-        multiply(B);
-        __syncthreads();
+    };
+    if constexpr (NWV == 8) {                                // 512 threads, one workgroup per CU: four sets fit the 256-VGPR budget
+        Set R0, R1, R2, R3;
+        request(R0, k_begin); request(R1, k_begin + 128); request(R2, k_begin + 256);
+        for (int k0 = k_begin; k0 < k_end; k0 += 512) {
+            step(R0, R3, k0, 3);
+            if (k0 + 128 >= k_end) break;
+            step(R1, R0, k0 + 128, 3);
+            if (k0 + 256 >= k_end) break;
+            step(R2, R1, k0 + 256, 3);
+            if (k0 + 384 >= k_end) break;
+            step(R3, R2, k0 + 384, 3);
+        }
+    } else {                                                 // 256-thread geometry: twice the staging items per wave — four sets would leave one wave per
+        Set A, B;                                            // SIMD (measured: 9.4 -> 11.9 us); two sets, three workgroups per CU cover for each other
+        request(A, k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += 256) {
+            step(A, B, k0, 1);
+            if (k0 + 128 >= k_end) break;
+            step(B, A, k0 + 128, 1);
+        }
     }
     // slice sums: lane (column m16 of tile t, row group kg) holds rows kg*4 .. kg*4+3 — 16 bytes contiguous in n
     if (tile_ok) {
@@ -263,7 +293,8 @@ static void wide_plan(int N, int nmat, int K, int& rows, int& S, int& Ks) {
     const int chunks = K / 128;
     auto plan = [&](int r, int min_chunks, int& s_out, int& ks_out) {
         const int groups = (N / r) * nmat;
-        int want = 256 / groups;                       // never more workgroups than CUs: the RMS / four-column-tile variants hold one
+        static const int cap = [] { const char* e = getenv("Q3_WIDE_WG_CAP"); const int v = e ? atoi(e) : 256; return v < 64 ? 64 : v; }();      // A/B aid
+        int want = (r == 64 ? cap : 256) / groups;     // never more workgroups than CUs: the RMS / four-column-tile variants hold one
                                                        // workgroup per CU (134 VGPRs), so 288 workgroups are two rounds (gate/up: 28.8 -> 38.5 us)
         int max_s = chunks / min_chunks; if (max_s < 1) max_s = 1;
         if (want > max_s) want = max_s;
@@ -272,10 +303,11 @@ static void wide_plan(int N, int nmat, int K, int& rows, int& S, int& Ks) {
         ks_out = per * 128; s_out = (chunks + per - 1) / per;
         return groups * s_out;
     };
+    static const int minc = [] { const char* e = getenv("Q3_WIDE_MIN_CHUNKS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();      // A/B aid
     int s128, k128, s64, k64;
-    const int wg128 = plan(128, 2, s128, k128);
+    const int wg128 = plan(128, minc, s128, k128);
     if (wg128 >= 192 || N % 64 != 0) { rows = 128; S = s128; Ks = k128; return; }
-    const int wg64 = plan(64, 2, s64, k64);
+    const int wg64 = plan(64, minc, s64, k64);
     if (wg64 > wg128) { rows = 64; S = s64; Ks = k64; } else { rows = 128; S = s128; Ks = k128; }
 }
 
@@ -310,6 +342,11 @@ static hipError_t gemm_wide_impl(const LinArgs& a, hipStream_t st, WidePartial* 
     w.nmat = a.epi == EPI_SWIGLU ? 2 : 1;
     int rows; wide_plan(a.N, w.nmat, a.K, rows, w.S, w.Ks);
     w.rgm = a.N / rows;
+    {
+        const size_t wb = (size_t)a.N * a.Kpad * 2, xb = ((size_t)(a.M - 1) * a.ldx + a.K) * 4;
+        if (wb >= 0x7fffffffu || xb >= 0x7fffffffu) return hipErrorNotSupported;
+        w.w_bytes = (unsigned)wb; w.x_bytes = (unsigned)xb;
+    }
     const size_t part_floats = (size_t)w.S * w.nmat * a.M * a.N;
     if ((part_floats + (size_t)w.S * a.M) * sizeof(float) > a.ws_bytes) return hipErrorNotSupported;
     w.part = a.ws; w.ssq = a.ws + part_floats;

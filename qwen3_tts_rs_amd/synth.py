@@ -144,3 +144,17 @@ def synthetic_checkpoint(cfg: Q3Config, model_handle, seed: int = DEFAULT_SEED) 
     for name, n, stored in manifest(model_handle):
         arr, dt = synth_tensor(cfg, seed, name, n, stored)
         yield name, arr, dt
+
+
+def synthetic_prompt(n: int, index: int = 0, vocab: int = 151643) -> np.ndarray:
+    """n text ids uniform in [0, vocab) from the PCG stream of seed 1000 + index (SURVEY.md §8d: the benchmark's prompts;
+    host-side only — q3_rng_* are plain C)."""
+    import ctypes
+    from . import _lib
+    st = ctypes.c_uint64()
+    _lib.lib.q3_rng_seed(1000 + index, ctypes.byref(st))
+    out = np.zeros(n, dtype=np.uint32)
+    for i in range(n):
+        u = _lib.lib.q3_rng_next(ctypes.byref(st))
+        out[i] = min(int(u * vocab), vocab - 1)
+    return out

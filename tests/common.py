@@ -38,15 +38,7 @@ def model_pair(cfg, seed=synth.DEFAULT_SEED, device=0):
     return gm, om
 
 
-def synthetic_prompt(n, index=0, vocab=151643):
-    """n text ids uniform in [0, vocab) from PCG seed 1000+index."""
-    st = ctypes.c_uint64()
-    _lib.lib.q3_rng_seed(1000 + index, ctypes.byref(st))
-    out = np.zeros(n, dtype=np.uint32)
-    for i in range(n):
-        u = _lib.lib.q3_rng_next(ctypes.byref(st))
-        out[i] = min(int(u * vocab), vocab - 1)
-    return out
+from qwen3_tts_rs_amd.synth import synthetic_prompt      # noqa: E402,F401 — the benchmark's prompt generator lives in the package (bench.py uses it)
 
 
 def top2_margin(logits):
