@@ -269,6 +269,185 @@ __global__ __launch_bounds__(256) void k_wide_epilogue(WideEpiArgs e) {
     *reinterpret_cast<float4*>(e.y + (size_t)m * e.ldy + n) = v;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the SwiGLU pair of a wide session WITHOUT split-K (k_wide2_swiglu) — one launch that writes y, fed by a small
+// launch that splits x ONCE for the whole chip (k_wide2_split).
+//
+// Why. k_wide_gemm stages and splits x per workgroup, so a workgroup can only afford a slice of K; the slices are summed by a
+// second launch, and for the code predictor's gate/up that second pass moves as many bytes as the weights themselves (6.3 MB
+// of slice sums written and re-read for 12.6 MB of weights: 11.8 + 5.2 us per projection at 64 rows, 80 times per frame).
+// Here x is split into its three exact bf16 terms ONCE, by 16-32 workgroups, straight into MFMA B-operand order in global
+// memory (384 KB at K = 1024: L2-resident) — with the RMSNorm weight folded in and the rows' sum(x^2) reported per K slab —
+// and the GEMM workgroup owns 16 output columns of BOTH matrices over ALL of K: its four waves take a quarter of K each,
+// read their B operands as plain 16-byte loads (no VALU, no LDS, no barrier in the loop), keep four k-steps of operands in
+// flight in a register ring, meet once in LDS (quarters added in order: deterministic) and apply 1/rms, SiLU and the product
+// themselves. Same arithmetic as the GEMV family (exact bf16x3 products, f32 accumulation); only the summation order differs.
+//   xp[k-step][column tile t][plane][lane] (16 bytes each): lane (kg, m16) = the 8 values x[16 t + m16][32 ks + 8 kg ..] * norm_w
+struct Wide2Args {
+    const uint16_t* W; const uint16_t* W2;      // mode-1 tiled images (gate, up)
+    const float* x; int ldx; const float* norm_w;
+    int M, N, K, kst;                            // kst = k-steps per tile row of the image (Kpad / 32)
+    unsigned char* xp; float* ssq; int nslab;    // planes; sum(x^2) per (K slab of 256, row): ssq[slab][M]
+    float eps; float* y; int ldy;
+    float* zero; int zero_n;                     // side job (LinArgs::zero)
+    unsigned w_bytes;
+};
+
+// grid (column tiles, K slabs of 256): 4 waves x 2 k-steps each
+template <bool RMS>
+__global__ __launch_bounds__(256) void k_wide2_split(Wide2Args a) {
+    __shared__ float ssq_s[4][2][4][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m16 = lane & 15, kg = lane >> 4;
+    const int t = blockIdx.x, slab = blockIdx.y, MT = gridDim.x;
+    const int m = 16 * t + m16;
+    const bool ok = m < a.M;
+    float ss[2] = {0.f, 0.f};
+    float4 xa[2], xb[2], na[2], nb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ks = slab * 8 + wave * 2 + j, kk = ks * 32 + kg * 8;
+        const bool kok = kk < a.K;
+        const float* px = a.x + (size_t)(ok ? m : 0) * a.ldx + (kok ? kk : 0);
+        xa[j] = *reinterpret_cast<const float4*>(px); xb[j] = *reinterpret_cast<const float4*>(px + 4);
+        if constexpr (RMS) { na[j] = *reinterpret_cast<const float4*>(a.norm_w + (kok ? kk : 0)); nb[j] = *reinterpret_cast<const float4*>(a.norm_w + (kok ? kk : 0) + 4); }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ks = slab * 8 + wave * 2 + j, kk = ks * 32 + kg * 8;
+        const bool live = ok && kk < a.K;
+        float xv[8] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w, xb[j].x, xb[j].y, xb[j].z, xb[j].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = live ? xv[e] : 0.0f;
+        if constexpr (RMS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss[j] = fmaf(xv[e], xv[e], ss[j]);
+            xv[0] *= na[j].x; xv[1] *= na[j].y; xv[2] *= na[j].z; xv[3] *= na[j].w;
+            xv[4] *= nb[j].x; xv[5] *= nb[j].y; xv[6] *= nb[j].z; xv[7] *= nb[j].w;
+        }
+        const Split3 sp = split3(xv);
+        if (kk < a.K || kg * 8 + (ks * 32) < ((a.K + 31) & ~31)) {      // every k-step of the (32-padded) image is written, zeros past K
+            u32x4_t* dst = reinterpret_cast<u32x4_t*>(a.xp) + ((size_t)(ks * MT + t) * 3) * 64 + lane;
+            dst[0] = sp.hi; dst[64] = sp.mid; dst[128] = sp.lo;
+        }
+        if constexpr (RMS) ssq_s[wave][j][kg][m16] = ss[j];
+    }
+    if constexpr (RMS) {
+        __syncthreads();
+        if (tid < 16) {                               // fixed order: waves, k-steps, k-groups
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) tot += ssq_s[w][j][g][tid];
+            if (16 * t + tid < a.M) a.ssq[(size_t)slab * a.M + 16 * t + tid] = tot;
+        }
+    }
+}
+
+// grid (N / 16): workgroup = 16 output columns of gate AND up over all of K; 4 waves = K quarters.
+// (The same loop over two tiles of ONE matrix, for q|k|v, was built and measured: 6.94 vs 6.75 ms per frame at 64 rows — the
+// K-slice sums handed straight to the attention kernel stay the better q|k|v.)
+template <int MT, int NT>            // NT = 16-column tiles of each matrix per workgroup (2 for the talker's 6144-row pair: one round of 192 workgroups)
+__global__ __launch_bounds__(256) void k_wide2_swiglu(Wide2Args a) {
+    __shared__ __attribute__((aligned(16))) f32x4_t red[4][2 * NT * MT][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m16 = lane & 15, kg = lane >> 4;
+    const int tile0 = blockIdx.x * NT;
+    const int KS = a.K >> 5;
+    const int q0 = (wave * KS) / 4, q1 = ((wave + 1) * KS) / 4;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, (int)a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W2), 0, (int)a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(a.xp, 0, KS * MT * 3 * 1024, 0x00020000);
+    const unsigned w_lane = ((unsigned)tile0 * (unsigned)a.kst * 64u + (unsigned)lane) * 16u;
+    const unsigned w_tile = (unsigned)a.kst * 1024u;                 // bytes from a tile row of the image to the next
+    constexpr unsigned OOB = 0x80000000u;
+    struct Set { u32x4_t g[NT], u[NT], b[MT][3]; };
+    auto request = [&](Set& r, int ks) {             // every request unconditional; a k-step past the quarter goes out of range
+        const bool live = ks < q1;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const unsigned off = live ? w_lane + (unsigned)n * w_tile + (unsigned)ks * 1024u : OOB;
+            r.g[n] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(grs, (int)off, 0, 2));
+            r.u[n] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(urs, (int)off, 0, 2));
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                r.b[t][pl] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(brs, (int)(live ? (unsigned)(((ks * MT + t) * 3 + pl) * 64 + lane) * 16u : OOB), 0, 0));
+    };
+    f32x4_t ag[NT][MT], au[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) { ag[n][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; au[n][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    auto multiply = [&](const Set& r) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) { ag[n][t] = mfma_bf16(r.g[n], r.b[t][pl], ag[n][t]); au[n][t] = mfma_bf16(r.u[n], r.b[t][pl], au[n][t]); }
+    };
+    auto step = [&](Set& cur, Set& nxt, int ks, int ahead) {
+        __builtin_amdgcn_sched_barrier(0); request(nxt, ks + ahead); __builtin_amdgcn_sched_barrier(0);
+        multiply(cur);
+    };
+    if constexpr (NT == 1) {                         // four k-steps of operands in flight
+        Set R0, R1, R2, R3;
+        request(R0, q0); request(R1, q0 + 1); request(R2, q0 + 2);
+        for (int ks = q0; ks < q1; ks += 4) {
+            step(R0, R3, ks, 3);
+            if (ks + 1 >= q1) break;
+            step(R1, R0, ks + 1, 3);
+            if (ks + 2 >= q1) break;
+            step(R2, R1, ks + 2, 3);
+            if (ks + 3 >= q1) break;
+            step(R3, R2, ks + 3, 3);
+        }
+    } else {                                         // two tiles per matrix: 64 VGPRs per k-step and 64 of accumulators — three sets fit without spilling
+        Set R0, R1, R2;
+        request(R0, q0); request(R1, q0 + 1);
+        for (int ks = q0; ks < q1; ks += 3) {
+            step(R0, R2, ks, 2);
+            if (ks + 1 >= q1) break;
+            step(R1, R0, ks + 1, 2);
+            if (ks + 2 >= q1) break;
+            step(R2, R1, ks + 2, 2);
+        }
+    }
+    zero_job(a.zero, a.zero_n, blockIdx.x, gridDim.x, tid, 256);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) { red[wave][n * MT + t][lane] = ag[n][t]; red[wave][(NT + n) * MT + t][lane] = au[n][t]; }
+    __syncthreads();
+    // the (column tile, weight tile) items are dealt to the waves: quarters added in order, 1/rms, SiLU(gate) * up, 16 bytes per lane
+    for (int it = wave; it < NT * MT; it += 4) {
+        const int n = it / MT, t = it - n * MT;
+        f32x4_t g = red[0][it][lane], u = red[0][NT * MT + it][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4_t g2 = red[w][it][lane], u2 = red[w][NT * MT + it][lane];
+            g[0] += g2[0]; g[1] += g2[1]; g[2] += g2[2]; g[3] += g2[3];
+            u[0] += u2[0]; u[1] += u2[1]; u[2] += u2[2]; u[3] += u2[3];
+        }
+        const int m = 16 * t + m16;
+        if (m < a.M) {
+            float tot = 0.0f;
+            for (int sl = 0; sl < a.nslab; ++sl) tot += a.ssq[(size_t)sl * a.M + m];
+            const float den = sqrtf(tot / (float)a.K + a.eps);
+            float4 o;
+            { const float gv = g[0] / den, uv = u[0] / den; o.x = (gv / (1.0f + expf(-gv))) * uv; }
+            { const float gv = g[1] / den, uv = u[1] / den; o.y = (gv / (1.0f + expf(-gv))) * uv; }
+            { const float gv = g[2] / den, uv = u[2] / den; o.z = (gv / (1.0f + expf(-gv))) * uv; }
+            { const float gv = g[3] / den, uv = u[3] / den; o.w = (gv / (1.0f + expf(-gv))) * uv; }
+            *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + (tile0 + n) * 16 + kg * 4) = o;
+        }
+    }
+}
+
 template <bool RMS, int NWV>
 hipError_t launch_gemm_t(const WideArgs& w, hipStream_t st) {
     const dim3 grid(w.rgm * w.nmat, w.S), blk(NWV * 64);
@@ -337,6 +516,35 @@ static hipError_t gemm_wide_impl(const LinArgs& a, hipStream_t st, WidePartial* 
     if (a.tiled != 1 || a.M < gemm_wide_min_rows() || a.M > 64 || a.N % 128 != 0 || a.K % 128 != 0 || a.Kpad != a.K || a.ldx % 4 != 0 || a.ldy % 4 != 0 || !a.ws ||
         (a.epi == EPI_RESID && a.ldr % 4 != 0) || ((a.epi == EPI_RESID || a.epi == EPI_SILU) && rms) || a.ksplit != 1)
         return hipErrorNotSupported;
+    // SwiGLU pair with a fused input norm: the single-launch form (k_wide2_split + k_wide2_swiglu); Q3_WIDE2=0: the split-K pair (A/B aid)
+    static const bool wide2 = [] { const char* e = getenv("Q3_WIDE2"); return !(e && atoi(e) == 0); }();
+    static const int wide2_nt2 = [] { const char* e = getenv("Q3_WIDE2_NT2"); return e ? atoi(e) : 4096; }();      // rows from which a workgroup takes two tiles per matrix (A/B aid)
+    if (wide2 && !partial && a.epi == EPI_SWIGLU && rms && !a.bias && a.N % 32 == 0 && a.K % 256 == 0) {
+        Wide2Args v{};
+        v.W = a.W; v.W2 = a.W2; v.x = a.x; v.ldx = a.ldx; v.norm_w = a.norm_w; v.M = a.M; v.N = a.N; v.K = a.K; v.kst = a.Kpad >> 5;
+        v.eps = a.eps; v.y = a.y; v.ldy = a.ldy; v.zero = a.zero; v.zero_n = a.zero_n;
+        const int MT = (a.M + 15) / 16;
+        const size_t plane_bytes = (size_t)(a.K >> 5) * MT * 3 * 1024;
+        v.nslab = a.K / 256;
+        const size_t wb = (size_t)a.N * a.Kpad * 2;
+        if (plane_bytes + (size_t)v.nslab * a.M * sizeof(float) <= a.ws_bytes && wb < 0x7fffffffu && plane_bytes < 0x7fffffffu) {
+            v.w_bytes = (unsigned)wb;
+            v.xp = reinterpret_cast<unsigned char*>(a.ws); v.ssq = reinterpret_cast<float*>(v.xp + plane_bytes);
+            hipLaunchKernelGGL((k_wide2_split<true>), dim3(MT, v.nslab), dim3(256), 0, st, v);
+            const bool nt2 = a.N > wide2_nt2;            // one round of workgroups for the talker's 6144 rows
+            const dim3 grid(a.N / (nt2 ? 32 : 16)), blk(256);
+            if (nt2) {
+                if (MT <= 2) hipLaunchKernelGGL((k_wide2_swiglu<2, 2>), grid, blk, 0, st, v);
+                else if (MT == 3) hipLaunchKernelGGL((k_wide2_swiglu<3, 2>), grid, blk, 0, st, v);
+                else hipLaunchKernelGGL((k_wide2_swiglu<4, 2>), grid, blk, 0, st, v);
+            } else {
+                if (MT <= 2) hipLaunchKernelGGL((k_wide2_swiglu<2, 1>), grid, blk, 0, st, v);
+                else if (MT == 3) hipLaunchKernelGGL((k_wide2_swiglu<3, 1>), grid, blk, 0, st, v);
+                else hipLaunchKernelGGL((k_wide2_swiglu<4, 1>), grid, blk, 0, st, v);
+            }
+            return hipGetLastError();
+        }
+    }
     WideArgs w{};
     w.W = a.W; w.W2 = a.W2; w.x = a.x; w.ldx = a.ldx; w.norm_w = a.norm_w; w.M = a.M; w.N = a.N; w.K = a.K; w.kst = a.Kpad >> 5;
     w.nmat = a.epi == EPI_SWIGLU ? 2 : 1;
