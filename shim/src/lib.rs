@@ -250,6 +250,16 @@ impl Qwen3TTS {
     pub fn from_pretrained(model_dir: &str, device: Device) -> Result<Self> {
         Self::from_pretrained_with_tokenizer(model_dir, None, device)
     }
+    /// Cap of the model's KV page pool in pages of 128 positions (0 = HBM is the limit). The reference sizes one cache per call and
+    /// bails on overflow (kv_cache.rs:293-300); here a request that needs a page beyond the cap fails with the same error before
+    /// anything runs.
+    pub fn set_kv_pool_limit(&self, max_pages: i32) -> Result<()> { check(unsafe { q3_model_kv_pool_limit(self.model, max_pages) }) }
+    /// (page positions, page bytes, pages held by the pool, pages in use, peak pages in use)
+    pub fn kv_pool_info(&self) -> Result<(i32, usize, i32, i32, i32)> {
+        let (mut pp, mut pb, mut tot, mut used, mut peak) = (0i32, 0usize, 0i32, 0i32, 0i32);
+        check(unsafe { q3_model_kv_pool_info(self.model, &mut pp, &mut pb, &mut tot, &mut used, &mut peak) })?;
+        Ok((pp, pb, tot, used, peak))
+    }
     fn from_pretrained_no_tokenizer(model_dir: &str, device: Device, tokenizer: tokenizers::Tokenizer) -> Result<Self> {
         let (mut h, mut mt) = (std::ptr::null_mut(), -1i32);
         check(unsafe { q3_model_load(cstr(model_dir).as_ptr(), device.0, &mut h, &mut mt) })?;
