@@ -26,7 +26,7 @@ if a.child:
         t0 = time.perf_counter(); s.generate(a.frames, use_graph=True); dt = time.perf_counter() - t0
         codes = np.stack([s.codes(b) for b in range(a.batch)]); s.close()
         best = min(best, dt)
-    np.save(f"/tmp/wide2_codes_{os.environ.get('Q3_WIDE2', '1')}.npy", codes)
+    np.save(f"/tmp/wide2_codes_{os.environ.get('Q3_WIDE2', '1')}{os.environ.get('Q3_WIDE_OPLANES', '')}.npy", codes)
     print(f"qkv M={a.batch} N=4096 K=1024: {bench_linear(a.batch, 4096, 1024, 0, True, tiled=1, device=0):.2f} us  K=2048: {bench_linear(a.batch, 4096, 2048, 0, True, tiled=1, device=0):.2f} us", flush=True)
     print(f"session B={a.batch}: {best * 1e3 / a.frames:.3f} ms/frame", flush=True)
     sys.exit(0)
@@ -34,10 +34,11 @@ import numpy as np
 for rnd in range(2):
     for mode in os.environ.get("WIDE2_MODES", "0,1").split(","):
         env = dict(os.environ); env["Q3_WIDE2"] = mode[0]
-        if len(mode) > 1: env["Q3_WIDE2_QKV"] = mode[1]
+        if len(mode) > 1: env["Q3_WIDE_OPLANES"] = mode[1]
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(a.batch), "--frames", str(a.frames)], capture_output=True, text=True, env=env, timeout=900)
         print(f"Q3_WIDE2={mode}: " + " | ".join(l for l in r.stdout.splitlines() if "us" in l or "ms/frame" in l) + ("" if r.returncode == 0 else "  FAILED " + r.stderr[-400:]), flush=True)
-c0, c1 = np.load("/tmp/wide2_codes_0.npy"), np.load("/tmp/wide2_codes_1.npy")
+ms = os.environ.get("WIDE2_MODES", "0,1").split(",")
+c0, c1 = np.load(f"/tmp/wide2_codes_{ms[0]}.npy"), np.load(f"/tmp/wide2_codes_{ms[-1]}.npy")
 rows_equal = int((c0 == c1).all(axis=(1, 2)).sum())
 first = [int(np.argmax((c0[b] != c1[b]).any(axis=1))) if (c0[b] != c1[b]).any() else -1 for b in range(c0.shape[0])]
 print(f"codes: {rows_equal} of {c0.shape[0]} rows identical over {c0.shape[1]} frames; first differing frame per row (-1 = none): {first}")
