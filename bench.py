@@ -259,7 +259,7 @@ def main():
     # HBM traffic per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_collect.sh) — PMC counters cannot be read from inside the run
     traffic = None; pmc_path = None
-    for cand in (f"r3_pmc_gemv_M{min(B, 16)}.json", f"r2_pmc_gemv_M{min(B, 16)}.json", f"r1_pmc_gemv_M{min(B, 16)}.json"):
+    for cand in (f"r4_pmc_gemv_M{min(B, 16)}.json", f"r3_pmc_gemv_M{min(B, 16)}.json", f"r2_pmc_gemv_M{min(B, 16)}.json", f"r1_pmc_gemv_M{min(B, 16)}.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             pmc_path = os.path.join(ROOT, "profiles", cand); break
     if args.model == "1.7b" and pmc_path:
@@ -343,11 +343,11 @@ def main():
     # ---- BASELINE.json's other configurations, same step definition, one warm + one timed step each (N = 1 only) ----
     others = {}
     if world == 1 and not args.no_other_configs and args.workload == "customvoice" and args.sampling == "default":
-        def timed(mdl, uu, oo, reps=1):
-            sw = mdl.session(uu, oo); sw.run_timing_only(use_graph=use_graph); sw.close()           # warm (graph capture, session-shape cache)
+        def timed(mdl, uu, oo, reps=1, kv_bf16=False):
+            sw = mdl.session(uu, oo, kv_bf16=kv_bf16); sw.run_timing_only(use_graph=use_graph); sw.close()           # warm (graph capture, session-shape cache)
             best = None; po = pcm_bufs(len(uu))
             for _ in range(reps):
-                sw = mdl.session(uu, oo); ta = time.perf_counter(); tt = sw.run_timing_only(use_graph=use_graph, pcm_out=po); wall = time.perf_counter() - ta; sw.close()
+                sw = mdl.session(uu, oo, kv_bf16=kv_bf16); ta = time.perf_counter(); tt = sw.run_timing_only(use_graph=use_graph, pcm_out=po); wall = time.perf_counter() - ta; sw.close()
                 if best is None or wall < best[0]:
                     best = (wall, tt)
             wall, tt = best
@@ -365,6 +365,10 @@ def main():
         args.workload = "voicedesign4k"
         guarded(f"{args.model}_voicedesign4k_b1", lambda: timed(model, [make_utt(0)], opts))
         args.workload = saved
+        # the reference GPU path's cache dtype as an opt-in session mode (q3_session_set_kv_dtype): NOT the headline — results are
+        # no longer bit-comparable with the F32 oracle; half the K/V bytes per frame
+        guarded(f"{args.model}_bf16kv_b{B}", lambda: timed(model, utts, opts, kv_bf16=True))
+        guarded(f"{args.model}_bf16kv_b64", lambda: timed(model, [make_utt(i) for i in range(64)], opts, kv_bf16=True))
         if args.model == "1.7b":
             def small():
                 m06 = q.Qwen3TTS.from_synthetic(q.qwen3_tts_0_6b(), device=dev, seed=synth.DEFAULT_SEED)

@@ -269,6 +269,11 @@ enum {
     Q3_GET_TOKEN = 7,           /* u32 current semantic token */
     Q3_GET_CP_LOGITS_HIST = 8   /* [frames][15][cp_vocab] (debug capture) */
 };
+/* K/V dtype of the talker cache, before q3_session_prefill: Q3_DTYPE_F32 (default — the parity contract is the reference's CPU
+ * F32 path) or Q3_DTYPE_BF16, the dtype of the reference GPU path's cache (kv_cache.rs:234-310; KVCache::new(..., dtype) at
+ * lib.rs:450): the prompt is prefilled in f32 and converted once, decode steps append and read bf16 — half the K/V bytes per
+ * frame; results are no longer bit-comparable with the F32 oracle. Needs the paged cache. */
+q3_status q3_session_set_kv_dtype(q3_session* s, int dtype);
 q3_status q3_session_set_debug(q3_session* s, int capture_logits);
 q3_status q3_session_prefill_len(q3_session* s, int b, int* prefill_len, int* trailing_len);
 q3_status q3_session_get(q3_session* s, int what, int b, void* out_host, size_t bytes);

@@ -84,6 +84,7 @@ SYMBOLS = {
     "q3_session_frames": (c_int, [c_void_p, c_int, P(c_int), P(c_int)]),
     "q3_session_codes": (c_int, [c_void_p, c_int, c_void_p, c_int, P(c_int)]),
     "q3_session_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_size_t, P(ctypes.c_size_t)]),
+    "q3_session_set_kv_dtype": (c_int, [c_void_p, c_int]),
     "q3_session_run": (c_int, [c_void_p, c_int, P(c_void_p), P(ctypes.c_size_t), P(ctypes.c_size_t), P(CTiming)]),
     "q3_session_next_chunk": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, P(ctypes.c_size_t), P(c_int)]),
     "q3_session_next_chunk_row": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_size_t, P(ctypes.c_size_t), P(c_int)]),

@@ -189,7 +189,7 @@ class Session:
     """A batch of utterances on one GPU (q3_session). Owns KV pages, RNG streams, penalty masks."""
 
     def __init__(self, model: "Qwen3TTS", utts: Sequence[Utterance], options: SynthesisOptions, debug: bool = False,
-                 frame_budget: int = 0, prompt_budget: int = 0):
+                 frame_budget: int = 0, prompt_budget: int = 0, kv_bf16: bool = False):
         """frame_budget / prompt_budget > 0: capacity (frames per row / prompt positions per row) for requests swapped in
         later with a larger max_length or a longer prompt (q3_session_create_reserved); the rows of `utts` still end at
         their own limits."""
@@ -209,6 +209,8 @@ class Session:
         else:
             check(lib.q3_session_create(model._h, reqs, self.B, ctypes.byref(h)))
         self._h = h
+        if kv_bf16:      # the reference GPU path's cache dtype (q3_session_set_kv_dtype): half the K/V bytes, not bit-comparable with the F32 oracle
+            check(lib.q3_session_set_kv_dtype(self._h, 1))
         if debug:
             check(lib.q3_session_set_debug(self._h, 1))
 
@@ -626,8 +628,8 @@ class Qwen3TTS:
         check(lib.q3_model_mark_loaded(self._h))
 
     # ---- synthesis API (lib.rs:416-501, 718-870, 1070-1110) ----
-    def session(self, utts: Sequence[Utterance], options: Optional[SynthesisOptions] = None, debug: bool = False) -> Session:
-        return Session(self, utts, options or SynthesisOptions(), debug)
+    def session(self, utts: Sequence[Utterance], options: Optional[SynthesisOptions] = None, debug: bool = False, kv_bf16: bool = False) -> Session:
+        return Session(self, utts, options or SynthesisOptions(), debug, kv_bf16=kv_bf16)
 
     def synthesize(self, text_ids: Sequence[int], options: Optional[SynthesisOptions] = None) -> AudioBuffer:
         return self.synthesize_with_voice(text_ids, Speaker.Ryan, Language.English, options)

@@ -171,17 +171,18 @@ struct KvPool {
     // V `v_delta()` floats behind K.
     static constexpr int SLAB_SLOTS = 32;
     std::mutex mu;
-    size_t run_floats = 0; int n_layers = 0;       // run = nkv * KV_PAGE_POS * HEAD_DIM (one layer's K of one page)
+    size_t run_floats = 0; int n_layers = 0;       // run = nkv * KV_PAGE_POS * HEAD_DIM ELEMENTS (one layer's K of one page)
+    size_t elem_bytes = sizeof(float);              // 4, or 2 for the pool of bf16 sessions (same geometry in elements)
     std::vector<void*> slabs; std::vector<float*> free_pages;
     int total = 0, in_use = 0, peak = 0, limit = 0;       // pages; limit 0 = bounded by HBM only
     // K -> V and layer -> layer distances are kept OFF powers of two (17 KB of padding behind every region): a lane asks for
     // the K row and the V row of a position together, and at exactly 16 MB apart the two requests meet in the same memory
     // channel (k_attn_fused 7.6 vs 6.9 us per launch at B = 8 against the contiguous caches, whose distance is arbitrary)
     static constexpr size_t PAD_FLOATS = 17 * 256;
-    size_t page_bytes() const { return (size_t)2 * n_layers * run_floats * sizeof(float); }
+    size_t page_bytes() const { return (size_t)2 * n_layers * run_floats * elem_bytes; }
     size_t v_delta() const { return (size_t)SLAB_SLOTS * run_floats + PAD_FLOATS; }
     size_t layer_stride() const { return 2 * v_delta(); }
-    size_t slab_bytes() const { return (size_t)n_layers * layer_stride() * sizeof(float); }
+    size_t slab_bytes() const { return (size_t)n_layers * layer_stride() * elem_bytes; }
     // n pages or none: hipErrorOutOfMemory when the limit (q3_model_kv_pool_limit) or the device says no
     hipError_t take(int n, std::vector<float*>& out) {
         std::lock_guard<std::mutex> g(mu);
@@ -191,7 +192,7 @@ struct KvPool {
             void* slab = nullptr;
             if (hipMalloc(&slab, slab_bytes()) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
             slabs.push_back(slab);
-            for (int i = SLAB_SLOTS - 1; i >= 0; --i) free_pages.push_back((float*)slab + (size_t)i * run_floats);
+            for (int i = SLAB_SLOTS - 1; i >= 0; --i) free_pages.push_back((float*)((char*)slab + (size_t)i * run_floats * elem_bytes));
             total += SLAB_SLOTS;
         }
         for (int i = 0; i < n; ++i) { out.push_back(free_pages.back()); free_pages.pop_back(); }
@@ -211,6 +212,7 @@ struct q3_model {
     q3_config cfg{};
     int device = 0;
     KvPool kv_pool;
+    KvPool kv_pool16;      // pages of bf16 sessions (q3_session_set_kv_dtype): the same geometry with 2-byte elements
     // sessions hold pages, streams and weights of their model: q3_model_free with sessions still alive only marks the model,
     // the last q3_session_free destroys it (a host that tears down in the wrong order must not crash)
     std::atomic<int> live_sessions{0}; std::atomic<bool> zombie{false};
@@ -481,6 +483,7 @@ extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model*
     HIPC(hipSetDevice(device));
     std::unique_ptr<q3_model> m(new q3_model());
     m->kv_pool.run_floats = (size_t)cfg->n_kv_heads * KV_PAGE_POS * HEAD_DIM; m->kv_pool.n_layers = cfg->n_layers;
+    m->kv_pool16.run_floats = m->kv_pool.run_floats; m->kv_pool16.n_layers = cfg->n_layers; m->kv_pool16.elem_bytes = 2;
     m->cfg = *cfg; m->device = device;
     build_manifest(m.get());
     HIPC(hipMalloc((void**)&m->arena, m->arena_bytes));
@@ -1292,6 +1295,9 @@ struct q3_session {
     // paged talker KV (the default; Q3_KV_CONTIGUOUS=1 keeps one extent per row: A/B aid): kv_table[b][KV_MAX_PAGES] page
     // pointers on the device (what the attention kernels read), kv_rows[b] = the pages row b holds, in position order
     bool paged = false; unsigned long long* kv_table = nullptr; std::vector<std::vector<float*>> kv_rows;
+    // bf16 K/V (opt-in, q3_session_set_kv_dtype; the reference GPU path's cache dtype): the prompt is prefilled into f32 pages
+    // as always, converted once into pages of the bf16 pool (kv_in_bf16 from then on), and the decode attention reads / appends bf16
+    bool kv_bf16 = false, kv_in_bf16 = false; unsigned long long* kv_conv = nullptr;      // kv_conv: [2][B * KV_MAX_PAGES] page lists of the conversion launch
     float *rows = nullptr, *embeds = nullptr, *xvec = nullptr; int n_rows_total = 0;
     // prefill scratch, session-lifetime (no hipMalloc / hipFree and no extra stream syncs on the time-to-first-audio path)
     uint32_t* ids_dev = nullptr; int *tr_dev = nullptr, *ci_dev = nullptr; float *proj_e = nullptr, *proj_h = nullptr;
@@ -1377,7 +1383,7 @@ static q3_status kv_reserve_row(q3_session* s, int b, int n_pos) {
     std::vector<float*>& row = s->kv_rows[(size_t)b];
     const int need = (n_pos + KV_PAGE_POS - 1) / KV_PAGE_POS, have = (int)row.size();
     if (need <= have) return Q3_OK;
-    KvPool& pool = s->m->kv_pool;
+    KvPool& pool = s->kv_in_bf16 ? s->m->kv_pool16 : s->m->kv_pool;
     if (pool.take(need - have, row) != hipSuccess)
         return set_err(Q3_KV_OVERFLOW, "KV page pool exhausted: row %d needs %d more page(s) of %d positions (pool: %d of %d in use, limit %d)",
                        b, need - have, KV_PAGE_POS, pool.in_use, pool.total, pool.limit);
@@ -1399,7 +1405,37 @@ static q3_status kv_reserve_frames(q3_session* s, int frames) {
     return Q3_OK;
 }
 static void kv_release_row(q3_session* s, int b) {        // the caller has drained every stream that may still touch the row
-    if (s->paged && !s->kv_rows[(size_t)b].empty()) s->m->kv_pool.give(s->kv_rows[(size_t)b]);
+    if (s->paged && !s->kv_rows[(size_t)b].empty()) (s->kv_in_bf16 ? s->m->kv_pool16 : s->m->kv_pool).give(s->kv_rows[(size_t)b]);
+}
+
+// bf16 sessions: every row's f32 pages -> as many pages of the bf16 pool (k_kv_pages_to_bf16), the table rewritten, the f32
+// pages returned. The caller has drained the stream; this drains it again before the f32 pages go back.
+static q3_status kv_convert_to_bf16(q3_session* s) {
+    if (!s->paged) return set_err(Q3_UNSUPPORTED, "bf16 K/V needs the paged cache");
+    const q3_config& c = s->m->cfg;
+    std::vector<unsigned long long> src, dst; std::vector<std::vector<float*>> fresh((size_t)s->B);
+    q3_status st = Q3_OK;
+    for (int b = 0; b < s->B && st == Q3_OK; ++b) {
+        const int n = (int)s->kv_rows[(size_t)b].size();
+        if (s->m->kv_pool16.take(n, fresh[(size_t)b]) != hipSuccess) { st = set_err(Q3_KV_OVERFLOW, "KV page pool (bf16) exhausted: row %d needs %d page(s)", b, n); break; }
+        for (int i = 0; i < n; ++i) { src.push_back((unsigned long long)s->kv_rows[(size_t)b][(size_t)i]); dst.push_back((unsigned long long)fresh[(size_t)b][(size_t)i]); }
+    }
+    if (st != Q3_OK) { for (auto& f : fresh) if (!f.empty()) s->m->kv_pool16.give(f); return st; }
+    const int n = (int)src.size();
+    hipError_t e = hipMemcpyAsync(s->kv_conv, src.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->kv_conv + (size_t)s->B * KV_MAX_PAGES, dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = launch_kv_pages_to_bf16(s->kv_conv, s->kv_conv + (size_t)s->B * KV_MAX_PAGES, n, c.n_layers, c.n_kv_heads, s->m->kv_pool.layer_stride(), s->m->kv_pool.v_delta(), s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) { for (auto& f : fresh) if (!f.empty()) s->m->kv_pool16.give(f); return set_err(Q3_HIP_ERROR, "K/V conversion to bf16: %s", hipGetErrorString(e)); }
+    for (int b = 0; b < s->B; ++b) {
+        s->m->kv_pool.give(s->kv_rows[(size_t)b]);
+        s->kv_rows[(size_t)b].assign(fresh[(size_t)b].begin(), fresh[(size_t)b].end());
+        if (!s->kv_rows[(size_t)b].empty())
+            HIPC(hipMemcpyAsync(s->kv_table + (size_t)b * KV_MAX_PAGES, s->kv_rows[(size_t)b].data(), s->kv_rows[(size_t)b].size() * 8, hipMemcpyHostToDevice, s->stream));
+    }
+    HIPC(hipStreamSynchronize(s->stream));
+    s->kv_in_bf16 = true;
+    return Q3_OK;
 }
 
 // one DecoderLayer (transformer.rs:442-467) for the single new token of every sequence
@@ -1439,6 +1475,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
         t.kv_pages = s->kv_table; t.kv_layer_off = (size_t)paged_layer * s->m->kv_pool.layer_stride();
         t.kv_vdelta = s->m->kv_pool.v_delta();
         t.kv_row_pages = (max_seq + KV_PAGE_POS - 1) / KV_PAGE_POS;
+        t.kv_bf16 = s->kv_in_bf16 ? 1 : 0;
     }
     if (wp.part) { t.qkv_part = wp.part; t.qkv_ssq = wp.ssq; t.qkv_S = wp.S; t.qkv_K = d.H; t.qkv_eps = d.eps; }
     // Split-K projections (LinArgs::ksplit, k_gemv_sk2): o-proj and down-proj with N <= 2048 and K >= 2048 at 3 .. 16 rows (wide
@@ -1458,6 +1495,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     // the GEMM pair — while the smaller matrices win: code predictor o 14.6 -> 6.8, down 15.7 -> 9.2, talker o 14.4 -> 11.7 us)
     const bool dn_big = B > 32 && (size_t)d.I * d.H * 2 > ((size_t)12 << 20);
     const bool dn_sk = sk_rows && !dn_big && w.down.t1 && w.gate.t1 && d.I >= 2048 && up32(d.I) / 32 >= 16;
+    if (t.kv_bf16 && (first2 || attn3)) return set_err(Q3_UNSUPPORTED, "multi-row talker steps are not available once a session's K/V is bf16");
     if (first2) {
         if (fold) {                                 // pass-1 gather folded: row 2b+1 = table row tok[b]
             t.g_tok = fold->tok; t.g_qkv_tab = fold->qkv_tab; t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim;
@@ -1838,6 +1876,7 @@ static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, 
         if (s->paged) {
             if (s->max_seq > KV_MAX_PAGES * KV_PAGE_POS) return set_err(Q3_KV_OVERFLOW, "sequence length %d exceeds a row's page table (%d)", s->max_seq, KV_MAX_PAGES * KV_PAGE_POS);
             HIPC(s->pool.alloc(&s->kv_table, (size_t)B * KV_MAX_PAGES));
+            HIPC(s->pool.alloc(&s->kv_conv, (size_t)2 * B * KV_MAX_PAGES));
             s->kv_rows.resize((size_t)B);
             for (auto& r : s->kv_rows) r.reserve(KV_MAX_PAGES);
         } else {
@@ -1916,6 +1955,18 @@ q3_session::~q3_session() {
 }
 
 extern "C" void q3_session_free(q3_session* s) { delete s; }
+
+// K/V dtype of the talker cache (before q3_session_prefill): Q3_DTYPE_F32 (default: the parity contract is the reference's CPU
+// F32 path) or Q3_DTYPE_BF16 — the reference GPU path's cache dtype (kv_cache.rs:234-310): half the K/V bytes per frame, results
+// no longer bit-comparable with the F32 oracle. Needs the paged cache.
+extern "C" q3_status q3_session_set_kv_dtype(q3_session* s, int dtype) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (s->prefilled) return set_err(Q3_INVALID_ARG, "q3_session_set_kv_dtype must be called before prefill");
+    if (dtype != Q3_DTYPE_F32 && dtype != Q3_DTYPE_BF16) return set_err(Q3_INVALID_ARG, "q3_session_set_kv_dtype: unknown dtype %d", dtype);
+    if (dtype == Q3_DTYPE_BF16 && !s->paged) return set_err(Q3_UNSUPPORTED, "bf16 K/V needs the paged cache (Q3_KV_CONTIGUOUS is set)");
+    s->kv_bf16 = dtype == Q3_DTYPE_BF16;
+    return Q3_OK;
+}
 
 extern "C" q3_status q3_session_set_debug(q3_session* s, int capture) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
@@ -2200,6 +2251,7 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     SampleArgs a; fill_sample_args(s, a); a.advance = 0;
     HIPC(launch_sample(a, s->stream));
     HIPC(hipStreamSynchronize(s->stream));
+    if (s->kv_bf16 && !s->kv_in_bf16) Q3C(kv_convert_to_bf16(s));       // the prompt's K/V moves into pages of the bf16 pool, once
     s->prefilled = true; s->frames_run = 0; s->codes_host_valid = false;
     return Q3_OK;
 }
@@ -2337,6 +2389,7 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     q3_session* side_raw = nullptr;
     Q3C(session_create(s->m, &r, 1, 0, 0, &side_raw, s->stream));      // on the host's stream: its frames and this prefill are serial anyway
     std::unique_ptr<q3_session> side(side_raw);
+    side->kv_bf16 = s->kv_bf16;                        // the side session prefills in f32 and converts, as the host session did
     lap("create");
     const SeqInfo& sq = side->seq[0];
     // (sampling options are per row — SampleRow —, resolved by the side session: an ICL request's repetition-penalty floor and
@@ -2345,6 +2398,7 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     const int limit = limit_req < sq.limit ? limit_req : sq.limit;
     if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
     if (s->paged != side->paged) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the sessions disagree on KV paging");
+    if (s->kv_bf16 != s->kv_in_bf16) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the session's K/V conversion has not happened yet");
     // max_seq bounds a row in both layouts: the captured frame was specialised for it (key splits, the page-table form of the
     // attention kernel); with pages it reserves nothing — only the pages a row really reaches are taken from the pool
     const int kv_cap = s->max_seq;
@@ -3243,7 +3297,7 @@ extern "C" q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* w
                            (c.hidden != c.cp_hidden ? (double)c.cp_hidden * c.hidden : 0.0);
     if (weight_bytes) *weight_bytes = 2.0 * (talker + 15.0 * cp_pass);          // bf16; SURVEY §8(d)
     if (kv_bytes) {
-        const double kv_tok = 2.0 * c.n_kv_heads * HEAD_DIM * 4.0 * c.n_layers;   // f32 KV in this build
+        const double kv_tok = 2.0 * c.n_kv_heads * HEAD_DIM * (s->kv_bf16 ? 2.0 : 4.0) * c.n_layers;   // f32 K/V (default) or a bf16 session's
         const double cp_tok = 2.0 * c.cp_kv_heads * HEAD_DIM * 4.0 * c.cp_layers;
         *kv_bytes = s->B * (kv_tok * kv_len + cp_tok * 135.0);
     }

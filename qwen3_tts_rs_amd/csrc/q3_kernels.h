@@ -135,6 +135,7 @@ struct AttnArgs {
     // a K row to its V row (both constants of the pool's slab layout)
     const unsigned long long* kv_pages = nullptr; size_t kv_layer_off = 0, kv_vdelta = 0;
     int kv_row_pages = 0;                   // most pages a row of this session can ever hold (0 = unknown: up to KV_MAX_PAGES)
+    int kv_bf16 = 0;                        // launch_attn_fused only: the pages hold bf16 (same geometry, 2-byte elements; q3_session_set_kv_dtype)
     float* qbuf;                            // [B][nh][128] normed+roped q
     float* part;                            // [B][nh][n_splits][PART_STRIDE]
     float* out; int ld_out;                 // [B][nh*128]
@@ -198,6 +199,10 @@ constexpr size_t KVP_TILE_BYTES = 6 * 32 * HEAD_DIM * 2;
 // planes of positions [0, n_pos) of every (sequence, kv head) pair, from the f32 cache launch_qknorm_rope_kv filled
 hipError_t launch_kv_planes(const AttnArgs& kv, int n_pairs, int n_pos, int tiles_alloc,
                             unsigned char* kvp, hipStream_t st);
+// pages of f32 K/V -> pages of bf16 (RNE), the first n_pos positions of every (layer, kv head) run: src / dst = device arrays
+// of page addresses [n_pages]; layer_stride / v_delta in ELEMENTS (the same counts in both pools)
+hipError_t launch_kv_pages_to_bf16(const unsigned long long* src_pages, const unsigned long long* dst_pages, int n_pages, int n_layers, int nkv,
+                                   size_t layer_stride, size_t v_delta, hipStream_t st);
 hipError_t launch_qknorm_rope_kv(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_merge(const AttnArgs& a, hipStream_t st);

@@ -471,7 +471,10 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
 // is uniform: 64 bytes through the scalar cache, which the workgroups of a CU share) spread over lanes 0..7; PAGED = 2: up to
 // KV_MAX_PAGES pages, one entry per lane from a vector load (2048 waves asking the same 4 KB of table cost ~1 us per launch
 // at B = 8 — measured: the frame 1.0 % slower than with contiguous extents — hence the scalar form where it fits).
-template <int NREP, int PAGED>
+// KV16 (paged only; an opt-in session mode, q3_session_set_kv_dtype): the cache holds bf16 — the reference GPU path's cache
+// dtype (kv_cache.rs:234-310) — in the same page geometry with 2-byte elements. A lane's K / V request is 8 bytes; the new
+// position's K / V are rounded to bf16 (RNE) before they are used or stored, as an append-then-attend over a bf16 cache does.
+template <int NREP, int PAGED, bool KV16 = false>
 __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const float* p_kc, const float* p_vc, const float* p_qkv, const float* p_qw,
                                                     const float* p_kw, int p_max_seq, int p_pk, AttnArgs a_in) {
     AttnArgs a = a_in;
@@ -532,9 +535,18 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
         // the integer: a generic pointer's loads are flat_load, which count on lgkmcnt as well and made every LDS / scalar
         // wait of the loop wait for the K/V stream: +1 us per launch)
         const char* gbase = reinterpret_cast<const char*>(p_kc);
-        float* page = reinterpret_cast<float*>(const_cast<char*>(gbase) + (ptrdiff_t)(pg - reinterpret_cast<unsigned long long>(gbase)));
-        return page + pg_off + (size_t)(((ok ? p : 0) + kv_rot(pg, (int)blockIdx.y)) & (KV_PAGE_POS - 1)) * HEAD_DIM;
+        char* page = const_cast<char*>(gbase) + (ptrdiff_t)(pg - reinterpret_cast<unsigned long long>(gbase));
+        const size_t elem = pg_off + (size_t)(((ok ? p : 0) + kv_rot(pg, (int)blockIdx.y)) & (KV_PAGE_POS - 1)) * HEAD_DIM;
+        return reinterpret_cast<float*>(page + elem * (KV16 ? 2 : 4));      // KV16: really a uint16_t*, see the callers
     };
+    struct KVReg { float4 f; };                      // one K or V fragment in flight: four floats, or four bf16 in .f.x / .f.y (KV16)
+    auto kv_unpack = [](const KVReg& r) -> float4 {
+        if constexpr (KV16) {
+            const uint32_t lo = __float_as_uint(r.f.x), hi = __float_as_uint(r.f.y);
+            return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+        } else return r.f;
+    };
+    auto bf16_rne = [](float v) -> uint32_t { uint32_t u = __float_as_uint(v); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
 
     // The first two cached K/V rows of this group are requested NOW, before the q/k-norm + RoPE prologue: they depend
     // on nothing but `pos`, and their round trip then runs under the prologue instead of after its barrier (the new
@@ -544,18 +556,22 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     // conditional hipcc waits for everything in flight — with the prefetch guarded, and the three register sets rotated
     // by copies, every key cost its own memory round trip.
     const size_t base = cache_base + li * 4;
-    auto request = [&](int p, float4& ko, float4& vo) {
+    auto request = [&](int p, KVReg& ko, KVReg& vo) {
         const int ps = (p < end && p != pos) ? p : 0;               // row 0 always exists
-        if constexpr (PAGED != 0) {
+        if constexpr (PAGED != 0 && KV16) {
+            const uint16_t* kr = reinterpret_cast<const uint16_t*>(krow_paged(p, p - (grp & 1), p < end && p != pos)) + li * 4;
+            const float2 k2 = *reinterpret_cast<const float2*>(kr), v2 = *reinterpret_cast<const float2*>(kr + pg_vd);
+            ko.f.x = k2.x; ko.f.y = k2.y; vo.f.x = v2.x; vo.f.y = v2.y;
+        } else if constexpr (PAGED != 0) {
             const float* kr = krow_paged(p, p - (grp & 1), p < end && p != pos) + li * 4;
-            ko = *reinterpret_cast<const float4*>(kr);
-            vo = *reinterpret_cast<const float4*>(kr + pg_vd);
+            ko.f = *reinterpret_cast<const float4*>(kr);
+            vo.f = *reinterpret_cast<const float4*>(kr + pg_vd);
         } else {
-            ko = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)ps * HEAD_DIM);
-            vo = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)ps * HEAD_DIM);
+            ko.f = *reinterpret_cast<const float4*>(a.kcache + base + (size_t)ps * HEAD_DIM);
+            vo.f = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)ps * HEAD_DIM);
         }
     };
-    float4 kA, vA, kB, vB, kC, vC;
+    KVReg kA, vA, kB, vB, kC, vC;
     const int p0 = start + grp;
     request(p0, kA, vA);
     request(p0 + 8, kB, vB);
@@ -600,12 +616,22 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             float v1, v2;
             if (from_slices) { v1 = pv1; v2 = pv2; }
             else { v1 = vs[lane]; v2 = vs[lane + 64]; }
+            if constexpr (KV16) {                  // the cache holds bf16: this position's K / V are what the cache will hold
+                const uint32_t b1 = bf16_rne(o1), b2 = bf16_rne(o2), c1 = bf16_rne(v1), c2 = bf16_rne(v2);
+                s_k[lane] = __uint_as_float(b1 << 16); s_k[lane + 64] = __uint_as_float(b2 << 16);
+                s_v[lane] = __uint_as_float(c1 << 16); s_v[lane + 64] = __uint_as_float(c2 << 16);
+                if (split == pos / chunk) {
+                    uint16_t* kc = reinterpret_cast<uint16_t*>(krow_paged(pos, pos, true)); uint16_t* vc = kc + pg_vd;
+                    kc[lane] = (uint16_t)b1; kc[lane + 64] = (uint16_t)b2; vc[lane] = (uint16_t)c1; vc[lane + 64] = (uint16_t)c2;
+                }
+            } else {
             s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
             if (split == pos / chunk) {
                 float* kc; float* vc;
                 if constexpr (PAGED != 0) { kc = krow_paged(pos, pos, true); vc = kc + pg_vd; }
                 else { kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM; vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM; }
                 kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
+            }
             }
         }
     }
@@ -624,7 +650,8 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
     // p + 16 are requested before position p is consumed. (Batches of 8 keys per group all in flight at once — one round
     // trip per batch — measured slower: 3.667 vs 3.609 ms/frame at B = 8; the 10-16 dummy requests of a short key range
     // cost more than the round trips they save.)
-    auto consume = [&](int p, float4 kk, float4 vv) {
+    auto consume = [&](int p, const KVReg& kr_, const KVReg& vr_) {
+        float4 kk = kv_unpack(kr_), vv = kv_unpack(vr_);
         if (p == pos) {                                            // the new position: from LDS
             kk = *reinterpret_cast<const float4*>(&s_k[li * 4]);
             vv = *reinterpret_cast<const float4*>(&s_v[li * 4]);
@@ -687,12 +714,21 @@ hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
     if (a.n_splits > 255 || a.nh > 255 || a.nkv > 255) return hipErrorInvalidValue;
     dim3 grid(a.n_splits, a.nkv, a.B);
     const int pk = a.n_splits | (a.nkv << 8) | (a.nh << 16);
-#define Q3_AF(R) hipLaunchKernelGGL((k_attn_fused<R, 0>), grid, dim3(256), 0, st, a.pos_dev, (const float*)a.kcache, (const float*)a.vcache, a.qkv, a.q_norm_w, a.k_norm_w, a.max_seq, pk, a)
-#define Q3_AFP(R, P) hipLaunchKernelGGL((k_attn_fused<R, P>), grid, dim3(256), 0, st, a.pos_dev, reinterpret_cast<const float*>(a.kv_pages), reinterpret_cast<const float*>(a.kv_layer_off), \
+#define Q3_AF(R) hipLaunchKernelGGL((k_attn_fused<R, 0, false>), grid, dim3(256), 0, st, a.pos_dev, (const float*)a.kcache, (const float*)a.vcache, a.qkv, a.q_norm_w, a.k_norm_w, a.max_seq, pk, a)
+#define Q3_AFP(R, P) hipLaunchKernelGGL((k_attn_fused<R, P, false>), grid, dim3(256), 0, st, a.pos_dev, reinterpret_cast<const float*>(a.kv_pages), reinterpret_cast<const float*>(a.kv_layer_off), \
                                         a.qkv, a.q_norm_w, a.k_norm_w, (int)a.kv_vdelta, pk, a)
     if (a.kv_pages) {
         if (a.kv_vdelta > 0x7fffffffu) return hipErrorInvalidValue;
         const bool few = a.kv_row_pages > 0 && a.kv_row_pages <= 8;        // the session's rows never hold more than 8 pages
+        if (a.kv_bf16) {
+#define Q3_AFP16(R, P) hipLaunchKernelGGL((k_attn_fused<R, P, true>), grid, dim3(256), 0, st, a.pos_dev, reinterpret_cast<const float*>(a.kv_pages), reinterpret_cast<const float*>(a.kv_layer_off), \
+                                          a.qkv, a.q_norm_w, a.k_norm_w, (int)a.kv_vdelta, pk, a)
+            if (nrep == 1) { if (few) Q3_AFP16(1, 1); else Q3_AFP16(1, 2); }
+            else if (nrep == 2) { if (few) Q3_AFP16(2, 1); else Q3_AFP16(2, 2); }
+            else if (nrep == 4) { if (few) Q3_AFP16(4, 1); else Q3_AFP16(4, 2); }
+            else return hipErrorInvalidValue;
+#undef Q3_AFP16
+        } else
         if (nrep == 1) { if (few) Q3_AFP(1, 1); else Q3_AFP(1, 2); }
         else if (nrep == 2) { if (few) Q3_AFP(2, 1); else Q3_AFP(2, 2); }
         else if (nrep == 4) { if (few) Q3_AFP(4, 1); else Q3_AFP(4, 2); }
@@ -702,6 +738,33 @@ hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
     else return hipErrorInvalidValue;
 #undef Q3_AF
 #undef Q3_AFP
+    return hipGetLastError();
+}
+
+// f32 pages -> bf16 pages (the prefill always runs on f32 pages; a bf16 session converts once, when its prompt is in):
+// grid (pages, layers * nkv * 2): one 128 x 128 run per workgroup, rows keep their rotated places (kv_rot depends on the
+// PAGE ADDRESS, so a row moves from src rotation to dst rotation)
+__global__ __launch_bounds__(256) void k_kv_pages_to_bf16(const unsigned long long* __restrict__ src_pages, const unsigned long long* __restrict__ dst_pages,
+                                                          int nkv, size_t layer_stride, size_t v_delta) {
+    const int pgi = blockIdx.x, run = blockIdx.y, tid = threadIdx.x;
+    const int is_v = run & 1, kvh = (run >> 1) % nkv, layer = (run >> 1) / nkv;
+    const unsigned long long sp = src_pages[pgi], dp = dst_pages[pgi];
+    const size_t off = (size_t)layer * layer_stride + (is_v ? v_delta : 0) + (size_t)kvh * KV_PAGE_POS * HEAD_DIM;
+    const float* src = reinterpret_cast<const float*>(sp) + off;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dp) + off;
+    const int rs = kv_rot(sp, kvh), rd = kv_rot(dp, kvh);
+    for (int i = tid; i < KV_PAGE_POS * HEAD_DIM / 4; i += 256) {
+        const int p = i / (HEAD_DIM / 4), c = (i % (HEAD_DIM / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)((p + rs) & (KV_PAGE_POS - 1)) * HEAD_DIM + c);
+        auto rne = [](float f) -> uint32_t { uint32_t u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
+        const uint32_t lo = rne(v.x) | (rne(v.y) << 16), hi = rne(v.z) | (rne(v.w) << 16);
+        *reinterpret_cast<uint2*>(dst + (size_t)((p + rd) & (KV_PAGE_POS - 1)) * HEAD_DIM + c) = make_uint2(lo, hi);
+    }
+}
+hipError_t launch_kv_pages_to_bf16(const unsigned long long* src_pages, const unsigned long long* dst_pages, int n_pages, int n_layers, int nkv,
+                                   size_t layer_stride, size_t v_delta, hipStream_t st) {
+    if (n_pages < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_kv_pages_to_bf16, dim3(n_pages, n_layers * nkv * 2), dim3(256), 0, st, src_pages, dst_pages, nkv, layer_stride, v_delta);
     return hipGetLastError();
 }
 

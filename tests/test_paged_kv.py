@@ -160,3 +160,44 @@ def test_replace_relinks_pages(monkeypatch):
         assert m.kv_pool_info()["pages_in_use"] == 0
     finally:
         m.close()
+
+
+def test_bf16_kv_session_mode(gm):
+    """Opt-in bf16 K/V (q3_session_set_kv_dtype; the reference GPU path's cache dtype, kv_cache.rs:234-310): the prompt is prefilled
+    in f32 pages and converted once into pages of the bf16 pool, decode steps append / read bf16. Not bit-comparable with the F32
+    oracle by construction, so the checks are: teacher-forced hidden states within bf16 distance of the f32 session's (crossing a
+    page boundary), deterministic free runs, a swap into a bf16 session equal to the request's own bf16 batch-1 run, and every
+    page of both pools returned."""
+    cfg = gm.config
+    opts = q.SynthesisOptions(max_length=150, eos_token_id=None, seed=7)
+    utts = [q.Utterance(synthetic_prompt(12, i), language=q.Language.German, instruct_ids=synthetic_prompt(110, 50 + i), seed=40 + i) for i in range(2)]   # 119 positions: page 0 nearly full
+    rng = np.random.default_rng(3)
+    emb = (0.5 * rng.standard_normal((20, 2, cfg.hidden))).astype(np.float32)
+    hs = {}
+    for mode in (False, True):
+        s = gm.session(utts, opts, kv_bf16=mode); s.prefill()
+        hs[mode] = np.stack([s.talker_step(emb[i])[0] for i in range(20)])      # positions 119 .. 138: across the page boundary
+        s.close()
+    scale = float(np.abs(hs[False]).max())
+    err = float(np.abs(hs[True] - hs[False]).max())
+    assert 0 < err <= 4e-2 * scale, (err, scale)             # bf16 K/V: 8 mantissa bits on every cached key and value; not zero (the mode is really on)
+    runs = []
+    for _ in range(2):
+        s = gm.session(utts, opts, kv_bf16=True); s.prefill(); s.generate(150)
+        runs.append([s.codes(b) for b in range(2)]); pcm = s.decode(0, 0, 8); s.close()
+    for b in range(2):
+        assert runs[0][b].shape == (150, 16)
+        np.testing.assert_array_equal(runs[0][b], runs[1][b])
+    assert np.isfinite(pcm).all()
+    # continuous batching in a bf16 session: the side session converts too, its bf16 pages are relinked
+    a = q.Utterance(synthetic_prompt(9, 0), q.Speaker.Ryan, q.Language.English, seed=5)
+    c = q.Utterance(synthetic_prompt(9, 2), language=q.Language.German, instruct_ids=synthetic_prompt(200, 52), seed=6)
+    o40 = q.SynthesisOptions(max_length=40, eos_token_id=None, seed=3)
+    s = api.Session(gm, [a, a], o40, frame_budget=40, prompt_budget=300, kv_bf16=True)
+    s.prefill(); s.generate(10); s.replace(1, c); s.generate(40)
+    s1 = gm.session([c], o40, kv_bf16=True); s1.prefill(); s1.generate(40)
+    np.testing.assert_array_equal(s.codes(1), s1.codes(0)); s1.close(); s.close()
+    with pytest.raises(_lib.Q3Error, match="before prefill"):
+        s = gm.session([a], o40); s.prefill(); _lib.check(_lib.lib.q3_session_set_kv_dtype(s._h, 1))
+    s.close()
+    assert gm.kv_pool_info()["pages_in_use"] == 0
