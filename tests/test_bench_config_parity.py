@@ -501,3 +501,30 @@ def test_icl_2k_reference_1_7b(gm17):
                                "pcm_ref_rms": float(np.sqrt(np.mean(fx["pcm"].astype(np.float64) ** 2)))})
     if exact:
         assert rms <= 1e-3, rms
+
+
+@pytest.mark.gpu
+def test_bf16_kv_mode_1_7b(gm17):
+    """The opt-in bf16 K/V mode at the benchmark's size (8 rows, 1.7B): three teacher-forced talker steps after the prefill stay within
+    bf16 distance of the f32 session (hidden states: 2e-2 of their scale; logits: 5e-2 of theirs), and a 40-frame graph run is
+    deterministic. (The mode is never the headline: bench.py reports it as separate other_configs lines.)"""
+    from make_golden_bench import bench_utt
+    cfg = gm17.config
+    utts = [bench_utt(i) for i in range(8)]
+    opts = q.SynthesisOptions(max_length=40, eos_token_id=None, seed=42)
+    rng = np.random.default_rng(5)
+    emb = (0.5 * rng.standard_normal((3, 8, cfg.hidden))).astype(np.float32)
+    out = {}
+    for mode in (False, True):
+        s = gm17.session(utts, opts, kv_bf16=mode); s.prefill()
+        out[mode] = [s.talker_step(emb[i]) for i in range(3)]
+        s.close()
+    eh = max(float(np.abs(a[0] - b[0]).max()) for a, b in zip(out[True], out[False])); sh = max(float(np.abs(b[0]).max()) for b in out[False])
+    el = max(float(np.abs(a[1] - b[1]).max()) for a, b in zip(out[True], out[False])); sl = max(float(np.abs(b[1]).max()) for b in out[False])
+    _dump("bench_bf16_kv_1_7b.json", {"hidden_max_abs_diff": eh, "hidden_scale": sh, "logits_max_abs_diff": el, "logits_scale": sl})
+    assert 0 < eh <= 2e-2 * sh and el <= 5e-2 * sl, (eh, sh, el, sl)
+    codes = []
+    for _ in range(2):
+        s = gm17.session(utts, opts, kv_bf16=True); s.prefill(); s.generate(40, use_graph=True)
+        codes.append(np.stack([s.codes(b) for b in range(8)])); s.close()
+    np.testing.assert_array_equal(codes[0], codes[1])
