@@ -369,6 +369,16 @@ def main():
         # no longer bit-comparable with the F32 oracle; half the K/V bytes per frame
         guarded(f"{args.model}_bf16kv_b{B}", lambda: timed(model, utts, opts, kv_bf16=True))
         guarded(f"{args.model}_bf16kv_b64", lambda: timed(model, [make_utt(i) for i in range(64)], opts, kv_bf16=True))
+        # the vocoder's convs on two bf16 planes per operand instead of three (q3_model_set_codec_planes(2)): an opt-in mode, NOT the
+        # headline — token ids are the same bits, the PCM is within 1e-4 RMS of the CPU path instead of 2.5e-5 (tolerance 1e-3)
+        def planes2(uu):
+            model.set_codec_planes(2)
+            try:
+                return timed(model, uu, opts)
+            finally:
+                model.set_codec_planes(3)
+        guarded(f"{args.model}_codec2p_b{B}", lambda: planes2(utts))
+        guarded(f"{args.model}_codec2p_b64", lambda: planes2([make_utt(i) for i in range(64)]))
         if args.model == "1.7b":
             def small():
                 m06 = q.Qwen3TTS.from_synthetic(q.qwen3_tts_0_6b(), device=dev, seed=synth.DEFAULT_SEED)

@@ -158,6 +158,13 @@ q3_status q3_model_mark_loaded(q3_model* m);
  * needs a page beyond it fails with Q3_KV_OVERFLOW before it runs (the reference's overflow bail). q3_model_kv_pool_info: page
  * geometry and occupancy (any pointer may be NULL). */
 q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages);
+/* Vocoder arithmetic. The codec decoder's convs (decoder_block.rs:81-92, 240-247; F32 in the reference on every device)
+ * run on the bf16 matrix cores with each f32 operand split into bf16 planes. planes = 3 (default): hi + mid + lo, six
+ * products per multiply-accumulate — every f32 product exact, PCM within 2.5e-5 RMS of the reference CPU path.
+ * planes = 2: hi + mid, three products — operands carry 16-17 mantissa bits (more than TF32's 11), PCM within 1e-4 RMS
+ * (the path's tolerance is 1e-3), the 640-frame decode 21.0 -> 14.7 ms. Codec token ids never depend on it. Applies to
+ * decodes started after the call; anything but 2 or 3 is Q3_INVALID_ARG. */
+q3_status q3_model_set_codec_planes(q3_model* m, int planes);
 q3_status q3_model_kv_pool_info(q3_model* m, int* page_positions, size_t* page_bytes, int* pages_total, int* pages_in_use, int* pages_peak);
 /* Verify every tensor is present ("Missing weight: <name>"), derive codebooks
  * (decoder_12hz.rs:189-225) and RoPE tables. */

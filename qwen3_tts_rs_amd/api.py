@@ -613,6 +613,11 @@ class Qwen3TTS:
         it fails with Q3_KV_OVERFLOW — the reference's cache-overflow bail (kv_cache.rs:293-300)."""
         check(lib.q3_model_kv_pool_limit(self._h, int(max_pages)))
 
+    def set_codec_planes(self, planes: int):
+        """bf16 planes per f32 operand in the vocoder's matrix-core convs (q3_model_set_codec_planes): 3 = exact f32 products
+        (default), 2 = hi + mid planes only (PCM within 1e-4 RMS of the reference instead of 2.5e-5; 30 % less vocoder time)."""
+        check(lib.q3_model_set_codec_planes(self._h, int(planes)))
+
     def kv_pool_info(self) -> dict:
         """Page geometry and occupancy of the model's KV pool (q3_model_kv_pool_info)."""
         pp = ctypes.c_int(); pb = ctypes.c_size_t(); tot = ctypes.c_int(); use = ctypes.c_int(); peak = ctypes.c_int()

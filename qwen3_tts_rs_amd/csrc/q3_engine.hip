@@ -211,6 +211,7 @@ struct KvPool {
 struct q3_model {
     q3_config cfg{};
     int device = 0;
+    int codec_planes = 3;  // q3_model_set_codec_planes: 3 = f32-exact bf16x3 products in the vocoder's convs, 2 = the two leading planes
     KvPool kv_pool;
     KvPool kv_pool16;      // pages of bf16 sessions (q3_session_set_kv_dtype): the same geometry with 2-byte elements
     // sessions hold pages, streams and weights of their model: q3_model_free with sessions still alive only marks the model,
@@ -509,6 +510,13 @@ static void model_destroy(q3_model* m) {
 
 // Paged KV pool of the model (KvPool above). limit: the most pages sessions may hold at once (0 = HBM is the limit); a session
 // that needs a page beyond it fails with Q3_KV_OVERFLOW — the reference's KV-overflow bail (kv_cache.rs:293-300).
+extern "C" q3_status q3_model_set_codec_planes(q3_model* m, int planes) {
+    if (!m) return set_err(Q3_INVALID_ARG, "q3_model_set_codec_planes: null model");
+    if (planes != 2 && planes != 3) return set_err(Q3_INVALID_ARG, "q3_model_set_codec_planes: %d (2 or 3)", planes);
+    m->codec_planes = planes;
+    return Q3_OK;
+}
+
 extern "C" q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages) {
     if (!m || m->device < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: no device model");
     if (max_pages < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: negative limit");
@@ -1069,17 +1077,21 @@ static int samples_per_frame(const q3_config& c) {
 
 static thread_local const q3_model* tl_codec_model = nullptr;     // set by codec_decode_dev: packed-weight lookup of the helpers below
 static const void* packed_of(const float* w) { return tl_codec_model ? tl_codec_model->pk(w) : nullptr; }
+// bf16 planes per operand in the vocoder's matrix-core convs (q3_model_set_codec_planes): only codec_decode_dev sets 2,
+// for its own launches — the encoders that share the kernels (speaker / speech tokenizer) always run the exact products
+static thread_local int tl_codec_planes = 3;
+struct CodecPlanesScope { explicit CodecPlanesScope(int p) { tl_codec_planes = p; } ~CodecPlanesScope() { tl_codec_planes = 3; } };
 static hipError_t conv1(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L, hipStream_t st,
                         const float* resid = nullptr, const float* scale = nullptr, int act = 0,
                         const float* sa = nullptr, const float* sib = nullptr) {
     ConvArgs a; a.x = x; a.w = w; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = 1; a.dil = 1;
-    a.resid = resid; a.scale = scale; a.act = act; a.snake_a = sa; a.snake_b = sib; a.wpk = packed_of(w);
+    a.resid = resid; a.scale = scale; a.act = act; a.snake_a = sa; a.snake_b = sib; a.wpk = packed_of(w); a.planes = tl_codec_planes;
     return launch_conv1d(a, st);
 }
 static hipError_t convk(const float* x, const float* w, const float* b, float* y, int cin, int cout, int L, int k, int dil,
                         hipStream_t st, const float* sa = nullptr, const float* sib = nullptr, int act = 0) {
     ConvArgs a; a.x = x; a.w = w; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = k; a.dil = dil;
-    a.snake_a = sa; a.snake_b = sib; a.act = act; a.wpk = packed_of(w);
+    a.snake_a = sa; a.snake_b = sib; a.act = act; a.wpk = packed_of(w); a.planes = tl_codec_planes;
     return launch_conv1d(a, st);
 }
 
@@ -1091,6 +1103,8 @@ static hipError_t convk(const float* x, const float* w, const float* b, float* y
 static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStream_t st, float** taps, int c0 = 0) {
     const q3_config& c = m->cfg;
     tl_codec_model = m;
+    const CodecPlanesScope planes_scope(m->codec_planes);
+    const int NPL = m->codec_planes;
     const int CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden, QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
     auto TAP = [&](int id, const float* dev, size_t n) -> q3_status {
         if (taps && taps[id]) { HIPC(hipStreamSynchronize(st)); HIPC(hipMemcpy(taps[id], dev, n * 4, hipMemcpyDeviceToHost)); }
@@ -1162,7 +1176,7 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
     for (int i = 0; i < 2; ++i) {
         const UpW& U = m->up[i];
         float* upo = (cur == C) ? A : C;            // transconv output [LAT][L*r]
-        HIPC(launch_transconv1d_taps(cur, U.tw, U.tb, upo, LAT, LAT, L, U.ratio, 1, nullptr, nullptr, st, nullptr, nullptr, nullptr, m->pk(U.tw)));
+        HIPC(launch_transconv1d_taps(cur, U.tw, U.tb, upo, LAT, LAT, L, U.ratio, 1, nullptr, nullptr, st, nullptr, nullptr, nullptr, m->pk(U.tw), NPL));
         L *= U.ratio;
         // dwconv → LN → pw1+GELU → pw2·gamma + residual (in place into upo)
         float* dw = (upo == A) ? C : A;             // [LAT][L]
@@ -1187,7 +1201,7 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
     // decoder.0 (k=7): raw only if tapped; activated with block 0's snake
     float* xact = other({cur});
     {
-        ConvArgs a; a.x = cur; a.w = m->init_w; a.wpk = m->pk(m->init_w); a.b = m->init_b; a.cin = LAT; a.cout = Cc; a.L = L; a.k = 7; a.dil = 1;
+        ConvArgs a; a.x = cur; a.w = m->init_w; a.wpk = m->pk(m->init_w); a.b = m->init_b; a.cin = LAT; a.cout = Cc; a.L = L; a.k = 7; a.dil = 1; a.planes = NPL;
         a.post_a = m->blk[0].a; a.post_ib = m->blk[0].ib;
         if (taps && taps[Q3_DEC_INIT]) { float* raw = other({cur, xact}); a.y = raw; a.y2 = xact; HIPC(launch_conv1d(a, st)); Q3C(TAP(Q3_DEC_INIT, raw, (size_t)Cc * L)); }
         else { a.y = xact; HIPC(launch_conv1d(a, st)); }
@@ -1198,7 +1212,7 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
         // transposed conv: raw Y (residual of unit 0) + YA = snake(act1 of unit 0)
         float* Y = other({xact});
         float* YA = other({xact, Y});
-        HIPC(launch_transconv1d_taps(xact, Bk.tw, Bk.tb, Y, Bk.cin, Bk.cout, L, Bk.rate, 2, nullptr, nullptr, st, Bk.res[0].a1, Bk.res[0].ib1, YA, m->pk(Bk.tw)));
+        HIPC(launch_transconv1d_taps(xact, Bk.tw, Bk.tb, Y, Bk.cin, Bk.cout, L, Bk.rate, 2, nullptr, nullptr, st, Bk.res[0].a1, Bk.res[0].ib1, YA, m->pk(Bk.tw), NPL));
         L *= Bk.rate; Cc = Bk.cout;
         float* T2 = other({Y, YA});
         for (int uu = 0; uu < 3; ++uu) {
@@ -1208,18 +1222,18 @@ static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStre
             {   // 96 / 192 channels: the whole unit in one launch (raw tensor updated in place, activated copy into T2)
                 ResUnitArgs r{};
                 r.xa = YA; r.y = Y; r.ya = T2; r.w1pk = m->pk(R.c1w); r.w2pk = m->pk(R.c2w); r.b1 = R.c1b; r.b2 = R.c2b;
-                r.mid_a = R.a2; r.mid_ib = R.ib2; r.post_a = nxt_a; r.post_ib = nxt_ib; r.C = Cc; r.L = L; r.dil = dils[uu];
+                r.mid_a = R.a2; r.mid_ib = R.ib2; r.post_a = nxt_a; r.post_ib = nxt_ib; r.C = Cc; r.L = L; r.dil = dils[uu]; r.planes = NPL;
                 const hipError_t e = launch_resunit(r, st);
                 if (e == hipSuccess) { float* t = YA; YA = T2; T2 = t; continue; }
                 if (e != hipErrorNotSupported) HIPC(e);
             }
             {   // conv7 (dilated) on the activated input; output activated with act2
-                ConvArgs a; a.x = YA; a.w = R.c1w; a.wpk = m->pk(R.c1w); a.b = R.c1b; a.y = T2; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 7; a.dil = dils[uu];
+                ConvArgs a; a.x = YA; a.w = R.c1w; a.wpk = m->pk(R.c1w); a.b = R.c1b; a.y = T2; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 7; a.dil = dils[uu]; a.planes = NPL;
                 a.post_a = R.a2; a.post_ib = R.ib2;
                 HIPC(launch_conv1d(a, st));
             }
             {   // conv1 + residual: raw → Y (in place), activated → YA for the next consumer
-                ConvArgs a; a.x = T2; a.w = R.c2w; a.wpk = m->pk(R.c2w); a.b = R.c2b; a.y = Y; a.y2 = YA; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 1; a.dil = 1; a.resid = Y;
+                ConvArgs a; a.x = T2; a.w = R.c2w; a.wpk = m->pk(R.c2w); a.b = R.c2b; a.y = Y; a.y2 = YA; a.cin = Cc; a.cout = Cc; a.L = L; a.k = 1; a.dil = 1; a.resid = Y; a.planes = NPL;
                 if (uu < 2) { a.post_a = Bk.res[uu + 1].a1; a.post_ib = Bk.res[uu + 1].ib1; }
                 else if (b < 3) { a.post_a = m->blk[b + 1].a; a.post_ib = m->blk[b + 1].ib; }
                 else { a.post_a = m->fin_a; a.post_ib = m->fin_ib; }

@@ -303,6 +303,7 @@ struct ConvArgs {
     const float* post_a = nullptr; const float* post_ib = nullptr;   // SnakeBeta of the CONSUMER applied to the output
     float* y2 = nullptr;             // if set: y = raw output, y2 = activated output; else y = activated output
     const void* wpk = nullptr;       // bf16x3-packed copy of w (launch_pack_conv_w) → bf16 matrix-core kernel; else f32 MFMA
+    int planes = 3;                  // bf16 planes per operand used by the matrix-core kernel: 3 = f32-exact products, 2 = ~2^-17
 };
 // one-time split of f32 conv weights [cout][cin][K] into bf16 hi/mid/lo MFMA A-operand tiles (cout % 32 == 0, cin % 16 == 0)
 hipError_t launch_pack_conv_w(const float* w, void* out, int cout, int cin, int K, hipStream_t st);
@@ -315,13 +316,15 @@ struct ResUnitArgs {
     const void* w1pk; const void* w2pk; const float* b1; const float* b2;
     const float* mid_a; const float* mid_ib; const float* post_a; const float* post_ib;
     int C, L, dil;
+    int planes = 3;                  // as ConvArgs::planes
 };
 hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st);
 // polyphase transposed conv: wp = per-phase causal-conv weights [stride][cout][cin][taps]
 hipError_t launch_transconv1d_taps(const float* x, const float* wp, const float* b, float* y, int cin, int cout, int L,
                                    int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st,
                                    const float* post_a = nullptr, const float* post_ib = nullptr, float* y2 = nullptr,
-                                   const void* wpk = nullptr);   // wpk: per-phase packed weights, phase-major
+                                   const void* wpk = nullptr,    // wpk: per-phase packed weights, phase-major
+                                   int planes = 3);
 hipError_t launch_snake_tables(const float* alpha, const float* beta, float* a, float* ib, int C, hipStream_t st);
 hipError_t launch_dwconv7(const float* x, const float* w, const float* b, float* y, int C, int L, hipStream_t st);
 hipError_t launch_layernorm_c(const float* x, const float* w, const float* b, float* y, int C, int L, float eps,

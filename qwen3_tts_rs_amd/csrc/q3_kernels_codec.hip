@@ -67,6 +67,7 @@ struct ConvDev {
     const void* wpk;              // bf16x3-packed weights (launch_pack_conv_w) or nullptr
     size_t wpk_phase_stride;      // 16-byte units per phase
     int phases;                   // k_conv_bf16x3: phases folded into its 1-D grid (set by the launcher)
+    int planes;                   // bf16 planes per operand in the matrix-core kernels: 3 (f32-exact products) or 2
 };
 
 __global__ __launch_bounds__(256) void k_conv1d(ConvDev a) {
@@ -334,6 +335,17 @@ __device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t
     return acc;
 }
 
+// NP = 2: the h and m planes only (products hm + mh + hh): operands carry 16-17 mantissa bits, a product is good to
+// ~2^-17 — half the MFMAs, two thirds of the fragment and LDS traffic (the opt-in "x2" vocoder mode)
+template <int NP>
+__device__ __forceinline__ f32x16_t mfmaP(const cu32x4_t (&A)[NP], const cu32x4_t (&B)[NP], f32x16_t acc) {
+#define Q3_MF(ap, bp) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8_t, A[ap]), __builtin_bit_cast(cbf16x8_t, B[bp]), acc, 0, 0, 0)
+    if constexpr (NP == 3) { Q3_MF(1, 1); Q3_MF(2, 0); Q3_MF(0, 2); }
+    Q3_MF(1, 0); Q3_MF(0, 1); Q3_MF(0, 0);
+#undef Q3_MF
+    return acc;
+}
+
 // Summation order of the 1x1 convs whose cin is a multiple of 512 (the pre-transformer / ConvNeXt linears): 128-channel
 // segments are accumulated from zero and added to the total in ascending order — the order k_lin_small_bf16x3 (short
 // sequences, one wave per segment) can reproduce, so both kernels give a position the same bits.
@@ -342,7 +354,7 @@ __host__ __device__ __forceinline__ bool conv_segmented(int k, int cin) { return
 // CIS = input channels per LDS stage: 32, or 128 for the 1x1 convs on 64-column tiles (with a single tap a 32-channel
 // stage is two 16-channel MFMA steps between two barriers and a global round trip).
 // LDS row pitch = CIS x 2 B + 16: an odd number of 16-byte slots, so the 16 rows of a ds_read_b128 group spread over all.
-template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false, bool SEG = false, int CIS = 32>
+template <int K, int CO_M, int T_M, int WCO, int WT, bool PRE = false, bool SEG = false, int CIS = 32, int NP = 3>
 __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) void k_conv_bf16x3(ConvDev a) {     // waves per SIMD the register budget must allow
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
@@ -414,12 +426,12 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
     const uint64_t wpu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wpa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)wpa);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wpu), 0, 0x7fffffff, 0x00020000);
     const int co32 = __builtin_amdgcn_readfirstlane(co0 >> 5);
-    auto load_A = [&](cu32x4_t (&A)[CO_M][3], int ci0, int kk, int c16l) {
+    auto load_A = [&](cu32x4_t (&A)[CO_M][NP], int ci0, int kk, int c16l) {
 #pragma unroll
         for (int cm = 0; cm < CO_M; ++cm) {
             const int tile = ((co32 + cm) * K + kk) * nc16 + (ci0 >> 4) + c16l;            // < 2^21 tiles of 3 KB
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 A[cm][pl] = __builtin_bit_cast(cu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (tile * 3 + pl) * 1024, 0));
         }
     };
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
         const int n16 = (a.cin - ci0) >= CIS ? CIS / 16 : (a.cin - ci0) >> 4;
         // the first weight fragments of the stage do not depend on the staging: request them before the barrier
         const int n_steps = K * n16;
-        cu32x4_t A[NA][CO_M][3];
+        cu32x4_t A[NA][CO_M][NP];
         load_A(A[0], ci0, 0, 0);
         if constexpr (NA == 3) load_A(A[1], ci0, (n_steps > 1 ? 1 : 0) / n16, (n_steps > 1 ? 1 : 0) % n16);
         __syncthreads();
@@ -475,15 +487,15 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
                     unsigned char* row = smem + (unsigned)tt * XPB + q * 16;
                     *reinterpret_cast<cu32x4_t*>(row) = h;
                     *reinterpret_cast<cu32x4_t*>(row + plane) = m;
-                    *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
+                    if constexpr (NP == 3) *reinterpret_cast<cu32x4_t*>(row + 2 * plane) = l;
                 }
             }
         }
         __syncthreads();
         // steps (kk, c16l) flattened; the weight fragments of step s + NA - 1 are requested before the MFMAs of step s
-        auto do_step = [&](const cu32x4_t (&A)[CO_M][3], int s) {
+        auto do_step = [&](const cu32x4_t (&A)[CO_M][NP], int s) {
             const int kk = s / n16, c16l = s - kk * n16;
-            cu32x4_t B[T_M][3];
+            cu32x4_t B[T_M][NP];
             // one VGPR add per plane and step: lane part fixed for the kernel (bfrag), step part scalar, column tiles as
             // immediate offsets
             const unsigned so = (unsigned)(kk * a.dil * XPB + c16l * 32);
@@ -494,12 +506,12 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
             for (int tm = 0; tm < T_M; ++tm) {
                 B[tm][0] = *reinterpret_cast<const cu32x4_t*>(bp0 + tm * (32 * XPB));
                 B[tm][1] = *reinterpret_cast<const cu32x4_t*>(bp1 + tm * (32 * XPB));
-                B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp2 + tm * (32 * XPB));
+                if constexpr (NP == 3) B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp2 + tm * (32 * XPB));
             }
 #pragma unroll
             for (int cm = 0; cm < CO_M; ++cm)
 #pragma unroll
-                for (int tm = 0; tm < T_M; ++tm) acc[cm][tm] = mfma6(A[cm], B[tm], acc[cm][tm]);
+                for (int tm = 0; tm < T_M; ++tm) acc[cm][tm] = mfmaP<NP>(A[cm], B[tm], acc[cm][tm]);
         };
         // Steps in pairs of straight-line code, the prefetch UNCONDITIONAL (index clamped: the last pair re-requests the
         // last step). `s_waitcnt vmcnt` counts in issue order: behind a prefetch that sits in a conditional the compiler
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
         const int last = n_steps - 1;
         // (pinned: left to itself hipcc sinks the requests into the second half of the current step, where the previous
         // fragments' registers come free — half a step of cover for an L2 round trip)
-        auto fetch = [&](cu32x4_t (&Ad)[CO_M][3], int sp) {
+        auto fetch = [&](cu32x4_t (&Ad)[CO_M][NP], int sp) {
             sp = sp < last ? sp : last;
             __builtin_amdgcn_sched_barrier(0); load_A(Ad, ci0, sp / n16, sp % n16); __builtin_amdgcn_sched_barrier(0);
         };
@@ -614,7 +626,7 @@ struct ResUnitDev {
     int C, L, dil;
 };
 
-template <int NW>
+template <int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
     constexpr int K = 7, T_M = 4, NT = 64 * NW, C = 32 * NW, T_WG = 128;
     constexpr int XPB = 80, NOCT = 4;                             // x staging: 32 channels per stage (as k_conv_bf16x3)
@@ -646,16 +658,16 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(pu), 0, 0x7fffffff, 0x00020000);
     };
     const __amdgpu_buffer_rsrc_t w1rs = rsrc(a.w1pk), w2rs = rsrc(a.w2pk);
-    auto load_A = [&](cu32x4_t (&A)[3], int ci0, int kk, int c16l) {
+    auto load_A = [&](cu32x4_t (&A)[NP], int ci0, int kk, int c16l) {
         const int tile = (wave * K + kk) * nc16 + (ci0 >> 4) + c16l;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             A[pl] = __builtin_bit_cast(cu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(w1rs, lane * 16, (tile * 3 + pl) * 1024, 0));
     };
     // ---- conv7: the main loop of k_conv_bf16x3<7, 1, 4, NW, 1> ----
     for (int ci0 = 0; ci0 < C; ci0 += 32) {
         constexpr int n16 = 2, n_steps = K * n16;
-        cu32x4_t A[2][3];
+        cu32x4_t A[2][NP];
         load_A(A[0], ci0, 0, 0);
         __syncthreads();
         constexpr int NCHK = (T_WG + (K - 1) * 9 + 63) / 64, NBF = (NOCT * NCHK + NW - 1) / NW;
@@ -689,14 +701,14 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
                     unsigned char* row = smem + (unsigned)tt * XPB + q * 16;
                     *reinterpret_cast<cu32x4_t*>(row) = h;
                     *reinterpret_cast<cu32x4_t*>(row + plane32) = m;
-                    *reinterpret_cast<cu32x4_t*>(row + 2 * plane32) = l;
+                    if constexpr (NP == 3) *reinterpret_cast<cu32x4_t*>(row + 2 * plane32) = l;
                 }
             }
         }
         __syncthreads();
-        auto do_step = [&](const cu32x4_t (&Af)[3], int s) {
+        auto do_step = [&](const cu32x4_t (&Af)[NP], int s) {
             const int kk = s >> 1, c16l = s & 1;
-            cu32x4_t B[T_M][3];
+            cu32x4_t B[T_M][NP];
             const unsigned so = (unsigned)(kk * a.dil * XPB + c16l * 32);
             const unsigned char* bp0 = smem + (bfrag + so);
             const unsigned char* bp1 = smem + (bfrag + so + plane32);
@@ -705,12 +717,12 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
             for (int tm = 0; tm < T_M; ++tm) {
                 B[tm][0] = *reinterpret_cast<const cu32x4_t*>(bp0 + tm * (32 * XPB));
                 B[tm][1] = *reinterpret_cast<const cu32x4_t*>(bp1 + tm * (32 * XPB));
-                B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp2 + tm * (32 * XPB));
+                if constexpr (NP == 3) B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp2 + tm * (32 * XPB));
             }
 #pragma unroll
-            for (int tm = 0; tm < T_M; ++tm) acc[tm] = mfma6(Af, B[tm], acc[tm]);
+            for (int tm = 0; tm < T_M; ++tm) acc[tm] = mfmaP<NP>(Af, B[tm], acc[tm]);
         };
-        auto fetch = [&](cu32x4_t (&Ad)[3], int sp) {
+        auto fetch = [&](cu32x4_t (&Ad)[NP], int sp) {
             sp = sp < n_steps - 1 ? sp : n_steps - 1;
             __builtin_amdgcn_sched_barrier(0); load_A(Ad, ci0, sp >> 1, sp & 1); __builtin_amdgcn_sched_barrier(0);
         };
@@ -720,17 +732,17 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
         }
     }
     // ---- the 1x1 conv over the activated conv7 result, 64 columns (two column tiles) at a time ----
-    auto load_A2 = [&](cu32x4_t (&A)[3], int s) {
+    auto load_A2 = [&](cu32x4_t (&A)[NP], int s) {
         const int tile = wave * nc16 + s;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             A[pl] = __builtin_bit_cast(cu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (tile * 3 + pl) * 1024, 0));
     };
     constexpr unsigned plane2 = 64u * XP2;
     const unsigned bfrag2 = (unsigned)(li * XP2 + lk * 16);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        cu32x4_t A2[3][3];
+        cu32x4_t A2[3][NP];
         load_A2(A2[0], 0); load_A2(A2[1], 1);                       // in flight across the barriers and the activation below
         // the residual of this half: 32 values per lane, requested before anything waits (one batch, see the PRE note above)
         float rs[2][16];
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
                 split3_pair(v[0], v[1], h0, m0, l0); split3_pair(v[2], v[3], h1, m1, l1);
                 *reinterpret_cast<uint2*>(row + g * 16) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(row + g * 16 + plane2) = make_uint2(m0, m1);
-                *reinterpret_cast<uint2*>(row + g * 16 + 2 * plane2) = make_uint2(l0, l1);
+                if constexpr (NP == 3) *reinterpret_cast<uint2*>(row + g * 16 + 2 * plane2) = make_uint2(l0, l1);
             }
         }
         __syncthreads();
@@ -768,19 +780,19 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
-        auto step2 = [&](const cu32x4_t (&Af)[3], int s) {
-            cu32x4_t B[2][3];
+        auto step2 = [&](const cu32x4_t (&Af)[NP], int s) {
+            cu32x4_t B[2][NP];
             const unsigned char* bp = smem + (bfrag2 + (unsigned)s * 32);
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 B[tm][0] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2));
                 B[tm][1] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2) + plane2);
-                B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2) + 2 * plane2);
+                if constexpr (NP == 3) B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2) + 2 * plane2);
             }
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) acc2[tm] = mfma6(Af, B[tm], acc2[tm]);
+            for (int tm = 0; tm < 2; ++tm) acc2[tm] = mfmaP<NP>(Af, B[tm], acc2[tm]);
         };
-        auto fetch2 = [&](cu32x4_t (&Ad)[3], int sp) {
+        auto fetch2 = [&](cu32x4_t (&Ad)[NP], int sp) {
             sp = sp < nc16 - 1 ? sp : nc16 - 1;
             __builtin_amdgcn_sched_barrier(0); load_A2(Ad, sp); __builtin_amdgcn_sched_barrier(0);
         };
@@ -809,6 +821,13 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
     }
 }
 
+// planes requested by the caller (ConvArgs::planes); Q3_CODEC_PLANES overrides it for A/B runs
+static int conv_planes(int asked) {
+    static const int env = [] { const char* e = getenv("Q3_CODEC_PLANES"); return e ? atoi(e) : 0; }();
+    const int p = env ? env : asked;
+    return p == 2 ? 2 : 3;
+}
+
 hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st) {
     static const bool off = getenv("Q3_CONV_F32") != nullptr || getenv("Q3_CODEC_NO_UNIT_FUSE") != nullptr;    // A/B aids
     // 192 channels = six waves per workgroup: measured 1803 us per unit against 1050 + 414 for the two launches (the conv7
@@ -821,11 +840,17 @@ hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st) {
     a.xa = r.xa; a.y = r.y; a.ya = r.ya; a.w1pk = r.w1pk; a.w2pk = r.w2pk; a.b1 = r.b1; a.b2 = r.b2;
     a.mid_a = r.mid_a; a.mid_ib = r.mid_ib; a.post_a = r.post_a; a.post_ib = r.post_ib; a.C = r.C; a.L = r.L; a.dil = r.dil;
     const int W = 128 + 6 * r.dil;
-    const size_t lds_x = (size_t)3 * W * 80, lds_mid = (size_t)3 * 64 * (r.C * 2 + 16);
+    const int np = conv_planes(r.planes);
+    const size_t lds_x = (size_t)np * W * 80, lds_mid = (size_t)np * 64 * (r.C * 2 + 16);
     const size_t lds = lds_x > lds_mid ? lds_x : lds_mid;
     const dim3 grid((r.L + 127) / 128);
-    if (r.C == 96) hipLaunchKernelGGL(k_resunit_bf16x3<3>, grid, dim3(192), lds, st, a);
-    else hipLaunchKernelGGL(k_resunit_bf16x3<6>, grid, dim3(384), lds, st, a);
+    if (np == 2) {
+        if (r.C == 96) hipLaunchKernelGGL((k_resunit_bf16x3<3, 2>), grid, dim3(192), lds, st, a);
+        else hipLaunchKernelGGL((k_resunit_bf16x3<6, 2>), grid, dim3(384), lds, st, a);
+    } else {
+        if (r.C == 96) hipLaunchKernelGGL((k_resunit_bf16x3<3, 3>), grid, dim3(192), lds, st, a);
+        else hipLaunchKernelGGL((k_resunit_bf16x3<6, 3>), grid, dim3(384), lds, st, a);
+    }
     return hipGetLastError();
 }
 
@@ -920,8 +945,8 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
     }
 }
 
-template <int K, int CO_M, int T_M, int WCO, int WT>
-static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
+template <int K, int CO_M, int T_M, int WCO, int WT, int NP>
+static hipError_t launch_bf16x3_vp(const ConvDev& a, int phases, hipStream_t st) {
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     constexpr bool K1 = K == 1;
     // 1x1 convs on 64-column tiles (the pre-transformer / ConvNeXt linears): 128 channels per stage, 33 -> 29 and
@@ -930,14 +955,14 @@ static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) 
     static const bool cis32 = getenv("Q3_CONV_CIS32") != nullptr;
     constexpr int CIS1 = T_WG <= 64 ? 128 : 32;
     const bool wide = K1 && CIS1 > 32 && !cis32 && a.cin >= 2 * CIS1;
-    const size_t lds = (size_t)3 * (T_WG + (K - 1) * a.dil) * ((wide ? CIS1 : 32) * 2 + 16);
+    const size_t lds = (size_t)NP * (T_WG + (K - 1) * a.dil) * ((wide ? CIS1 : 32) * 2 + 16);
     dim3 grid(((a.L + T_WG - 1) / T_WG) * (a.cout / CO_WG) * phases);         // tile order: see the kernel
     ConvDev ap = a; ap.phases = phases;
     const bool segm = conv_segmented(a.k, a.cin);
     const dim3 blk(64 * WCO * WT);
     if constexpr (K1) {
         const bool pre = CO_M == 1 && a.resid;
-#define Q3_CV(P, S, C) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, P, S, C>), grid, blk, lds, st, ap)
+#define Q3_CV(P, S, C) hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, P, S, C, NP>), grid, blk, lds, st, ap)
         if (wide) {
             if (segm) { if (pre) Q3_CV(CO_M == 1, true, CIS1); else Q3_CV(false, true, CIS1); }
             else { if (pre) Q3_CV(CO_M == 1, false, CIS1); else Q3_CV(false, false, CIS1); }
@@ -950,9 +975,13 @@ static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) 
     // between two barriers — was measured and lost at every width: 614 -> 645, 791 -> 903, 880 -> 1209, 841 -> 1260 us;
     // the larger x tile costs the 96-channel geometry its third workgroup per CU)
     } else {
-        hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT>), grid, blk, lds, st, ap);
+        hipLaunchKernelGGL((k_conv_bf16x3<K, CO_M, T_M, WCO, WT, false, false, 32, NP>), grid, blk, lds, st, ap);
     }
     return hipGetLastError();
+}
+template <int K, int CO_M, int T_M, int WCO, int WT>
+static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
+    return a.planes == 2 ? launch_bf16x3_vp<K, CO_M, T_M, WCO, WT, 2>(a, phases, st) : launch_bf16x3_vp<K, CO_M, T_M, WCO, WT, 3>(a, phases, st);
 }
 template <int K>
 static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) {
@@ -1071,7 +1100,7 @@ hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
     a.snake_a = c.snake_a; a.snake_ib = c.snake_b; a.resid = c.resid; a.scale = c.scale; a.act = c.act;
     a.ostride = 1; a.ooff = 0; a.oL = c.L; a.w_phase_stride = 0; a.ooff_phase = 0;
     a.post_a = c.post_a; a.post_ib = c.post_ib; a.y2 = c.y2;
-    a.wpk = c.wpk; a.wpk_phase_stride = 0;
+    a.wpk = c.wpk; a.wpk_phase_stride = 0; a.planes = conv_planes(c.planes);
     if (c.cout == 1) {
         if (c.k == 7 && c.dil == 1 && c.L % 4 == 0 && (((uintptr_t)c.x | (uintptr_t)c.y) & 15) == 0)
             hipLaunchKernelGGL(k_conv_out1_v4, dim3((c.L / 4 + 255) / 256), dim3(256), 0, st, a);
@@ -1093,8 +1122,9 @@ hipError_t launch_conv1d(const ConvArgs& c, hipStream_t st) {
 // t = j*stride + ph; the right-trim k - s of causal_trans_conv.rs:79 is implicit (length L*stride).
 hipError_t launch_transconv1d_taps(const float* x, const float* wp, const float* b, float* y, int cin, int cout, int L,
                                    int stride, int taps, const float* snake_a, const float* snake_ib, hipStream_t st,
-                                   const float* post_a, const float* post_ib, float* y2, const void* wpk) {
+                                   const float* post_a, const float* post_ib, float* y2, const void* wpk, int planes) {
     ConvDev a{};
+    a.planes = conv_planes(planes);
     a.wpk = wpk; a.wpk_phase_stride = packed_conv_w_bytes(cout, cin, taps) / 16;
     a.post_a = post_a; a.post_ib = post_ib; a.y2 = y2;
     a.x = x; a.w = wp; a.b = b; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.k = taps; a.dil = 1;

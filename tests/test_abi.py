@@ -151,6 +151,7 @@ def test_null_handles_return_status_not_crash():
         lambda: L.q3_session_next_chunk(None, None, 0, ctypes.byref(sz), ctypes.byref(i)),
         lambda: L.q3_session_set_stream_mode(None, 1),
         lambda: L.q3_session_set_kv_dtype(None, 1),
+        lambda: L.q3_model_set_codec_planes(None, 2),
         lambda: L.q3_session_create_reserved(None, None, 1, 8, 16, ctypes.byref(null)),
         lambda: L.q3_session_replace(None, 0, None),
         lambda: L.q3_session_next_chunk_row(None, 0, None, 0, ctypes.byref(sz), ctypes.byref(i)),

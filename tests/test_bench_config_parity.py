@@ -297,6 +297,43 @@ def test_full_size_vocoder_long(gm17, T):
     assert rms <= 1e-3 and rms_unsat <= 1e-3, (rms, rms_unsat)
 
 
+@pytest.mark.parametrize("T", [128, 640])
+def test_vocoder_two_plane_mode_1_7b(gm17, T):
+    """q3_model_set_codec_planes(2): the vocoder's matrix-core convs use the hi + mid bf16 planes of each f32 operand
+    (three products per multiply-accumulate instead of six). Opt-in; the stated bounds: PCM within 3e-4 RMS of the
+    reference CPU path (measured 1.0e-4; the path's tolerance is 1e-3), every stage tap within 1e-3 of its max magnitude
+    (measured <= 2.9e-4). The mode must really be engaged (the PCM differs from the three-plane bits) and must leave the
+    default untouched afterwards (bit-identical decode before and after)."""
+    fx = np.load(os.path.join(G, f"bench_vocoder_T{T}.npz"))
+    codes = fx["codes"]
+    exact = gm17.decode_codes(codes).samples
+    shapes = O.decoder_tap_shapes(gm17.config, T)
+    taps = [np.zeros(sh, dtype=np.float32) for sh in shapes]
+    gm17.set_codec_planes(2)
+    try:
+        pcm = gm17.decode_codes(codes, taps=taps).samples
+    finally:
+        gm17.set_codec_planes(3)
+    errs = {}
+    for i, t in enumerate(taps):
+        flat = t.reshape(-1)
+        errs[i] = float(np.abs(flat[tap_indices(flat.size, i, T)] - fx[f"tap{i}"]).max() / (float(fx[f"tap{i}_absmax"][0]) + 1e-9))
+        assert errs[i] <= 1e-3, (i, errs[i])
+    if T <= 128:
+        ref = fx["pcm"]; got = pcm
+    else:
+        ref = fx["pcm_decimated"]; got = pcm[pcm_decimate_idx(pcm.size)]
+    rms = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)))
+    _dump(f"bench_vocoder_2planes_T{T}.json", {"tap_rel_err": errs, "pcm_rms_err": rms,
+                                               "pcm_rms_vs_three_planes": float(np.sqrt(np.mean((pcm.astype(np.float64) - exact) ** 2)))})
+    assert rms <= 3e-4, rms
+    assert not np.array_equal(pcm, exact)
+    assert np.array_equal(gm17.decode_codes(codes).samples, exact)
+    from qwen3_tts_rs_amd import _lib
+    with pytest.raises(_lib.Q3Error):
+        gm17.set_codec_planes(4)
+
+
 def test_streaming_chunks_1_7b(gm17):
     """config[2]: 1.7B CustomVoice streaming; the first two 10-frame chunks against the oracle's context-free decodes."""
     fx = np.load(os.path.join(G, "bench_1_7b_stream.npz"))
