@@ -328,13 +328,6 @@ hipError_t launch_pack_conv_w(const float* w, void* out, int cout, int cin, int 
 }
 size_t packed_conv_w_bytes(int cout, int cin, int K) { return (size_t)(cout / 32) * K * (cin / 16) * 3 * 1024; }
 
-__device__ __forceinline__ f32x16_t mfma6(const cu32x4_t (&A)[3], const cu32x4_t (&B)[3], f32x16_t acc) {
-#define Q3_MF(ap, bp) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8_t, A[ap]), __builtin_bit_cast(cbf16x8_t, B[bp]), acc, 0, 0, 0)
-    Q3_MF(1, 1); Q3_MF(2, 0); Q3_MF(0, 2); Q3_MF(1, 0); Q3_MF(0, 1); Q3_MF(0, 0);     // small terms first
-#undef Q3_MF
-    return acc;
-}
-
 // NP = 2: the h and m planes only (products hm + mh + hh): operands carry 16-17 mantissa bits, a product is good to
 // ~2^-17 — half the MFMAs, two thirds of the fragment and LDS traffic (the opt-in "x2" vocoder mode)
 template <int NP>
@@ -863,7 +856,7 @@ hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st) {
 // LDS. That is the segmented summation order conv_segmented() defines, which the tiled kernel follows for the same
 // shapes — a frame position gets bit-identical values from either kernel (continuous streaming mode depends on it).
 // ------------------------------------------------------------------------------------------------
-template <int W>
+template <int W, int NP = 3>
 __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
     __shared__ float part[W][16][64];
     constexpr int NR = 16 / W;
@@ -880,13 +873,13 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
     for (int s0 = 0; s0 < nseg; s0 += W) {
         const int seg = s0 + wave;
         if (seg < nseg) {                                         // wave-uniform
-            cu32x4_t A[8][3];
+            cu32x4_t A[8][NP];
             float xv[8][8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const size_t tile = (size_t)co32 * nc16 + seg * 8 + i;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) A[i][pl] = wpk[(tile * 3 + pl) * 64 + lane];
+                for (int pl = 0; pl < NP; ++pl) A[i][pl] = wpk[(tile * 3 + pl) * 64 + lane];
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -909,10 +902,10 @@ __global__ __launch_bounds__(64 * W) void k_lin_small_bf16x3(ConvDev a) {
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                cu32x4_t B[3];
+                cu32x4_t B[NP];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { uint32_t h, m, l; split3_pair(xv[i][2 * e], xv[i][2 * e + 1], h, m, l); B[0][e] = h; B[1][e] = m; B[2][e] = l; }
-                acc = mfma6(A[i], B, acc);
+                for (int e = 0; e < 4; ++e) { uint32_t h, m, l; split3_pair(xv[i][2 * e], xv[i][2 * e + 1], h, m, l); B[0][e] = h; B[1][e] = m; if constexpr (NP == 3) B[2][e] = l; }
+                acc = mfmaP<NP>(A[i], B, acc);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
@@ -1022,8 +1015,13 @@ static hipError_t launch_conv_bf16x3(const ConvDev& a, int phases, hipStream_t s
     const bool small_tiles = a.L > 32 && a.cin >= 1024 && small_wgs <= 512 && !no_small_tiles;
     if (conv_segmented(a.k, a.cin) && (a.L <= 32 || small_tiles) && phases == 1 && a.cout % 64 == 0 && !no_small) {
         const dim3 grid(a.cout / 32, (a.L + 31) / 32);
-        if (a.cin >= 1024) hipLaunchKernelGGL(k_lin_small_bf16x3<8>, grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL(k_lin_small_bf16x3<4>, grid, dim3(256), 0, st, a);
+        if (a.planes == 2) {                                          // the mode's summation is the tiled kernel's in either form
+            if (a.cin >= 1024) hipLaunchKernelGGL((k_lin_small_bf16x3<8, 2>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_lin_small_bf16x3<4, 2>), grid, dim3(256), 0, st, a);
+        } else {
+            if (a.cin >= 1024) hipLaunchKernelGGL((k_lin_small_bf16x3<8, 3>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_lin_small_bf16x3<4, 3>), grid, dim3(256), 0, st, a);
+        }
         return hipGetLastError();
     }
     switch (a.k) {

@@ -334,6 +334,24 @@ def test_vocoder_two_plane_mode_1_7b(gm17, T):
         gm17.set_codec_planes(4)
 
 
+@pytest.mark.parametrize("planes", [3, 2])
+def test_continuous_streaming_full_size_vocoder_is_seamless(gm17, planes):
+    """Continuous streaming at production widths, in both vocoder modes: the 10-frame chunks (the short-sequence linear
+    kernel in the pre-transformer / ConvNeXt stages) concatenate to the bits of the whole-utterance decode (the tiled
+    kernel) — both kernels follow one summation order and one plane count."""
+    u = bench_utt(0)
+    opts = q.SynthesisOptions(max_length=30, eos_token_id=None, seed=42, chunk_frames=10)
+    gm17.set_codec_planes(planes)
+    try:
+        ss = gm17.synthesize_streaming(u.text_ids, u.speaker, u.language, opts, continuous=True)
+        got = np.concatenate([c.samples for c in ss])
+        s = gm17.session([q.Utterance(u.text_ids, u.speaker, u.language)], opts); s.prefill(); s.generate(30)
+        full = s.decode(0); s.close()
+    finally:
+        gm17.set_codec_planes(3)
+    np.testing.assert_array_equal(got, full)
+
+
 def test_streaming_chunks_1_7b(gm17):
     """config[2]: 1.7B CustomVoice streaming; the first two 10-frame chunks against the oracle's context-free decodes."""
     fx = np.load(os.path.join(G, "bench_1_7b_stream.npz"))
