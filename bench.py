@@ -371,14 +371,16 @@ def main():
         guarded(f"{args.model}_bf16kv_b64", lambda: timed(model, [make_utt(i) for i in range(64)], opts, kv_bf16=True))
         # the vocoder's convs on two bf16 planes per operand instead of three (q3_model_set_codec_planes(2)): an opt-in mode, NOT the
         # headline — token ids are the same bits, the PCM is within 1e-4 RMS of the CPU path instead of 2.5e-5 (tolerance 1e-3)
-        def planes2(uu):
+        def planes2(uu, kv_bf16=False):
             model.set_codec_planes(2)
             try:
-                return timed(model, uu, opts)
+                return timed(model, uu, opts, kv_bf16=kv_bf16)
             finally:
                 model.set_codec_planes(3)
         guarded(f"{args.model}_codec2p_b{B}", lambda: planes2(utts))
         guarded(f"{args.model}_codec2p_b64", lambda: planes2([make_utt(i) for i in range(64)]))
+        # both opt-in modes together (bf16 K/V pages + two-plane vocoder): what a throughput-first deployment would run
+        guarded(f"{args.model}_bf16kv_codec2p_b64", lambda: planes2([make_utt(i) for i in range(64)], kv_bf16=True))
         if args.model == "1.7b":
             def small():
                 m06 = q.Qwen3TTS.from_synthetic(q.qwen3_tts_0_6b(), device=dev, seed=synth.DEFAULT_SEED)
