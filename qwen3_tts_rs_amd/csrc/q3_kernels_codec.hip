@@ -352,7 +352,11 @@ __global__ __launch_bounds__(64 * WCO * WT, (CO_M == 2 || T_M >= 8) ? 2 : 3) voi
     constexpr int NT = 64 * WCO * WT;
     constexpr int CO_WG = 32 * CO_M * WCO, T_WG = 32 * T_M * WT;
     constexpr int XPB = CIS * 2 + 16, NOCT = CIS / 8;           // LDS bytes per time row per plane; channel octets per stage
-    constexpr int NA = 2;                                         // ring of weight-fragment register sets (3, two steps of prefetch: 918 -> 934 us)
+    // ring of weight-fragment register sets. Two (one step of prefetch) for the tapped three-plane convs — a step is 24 MFMAs
+    // and three sets cost more registers than they hide (k = 7: 918 -> 934 us; k = 2: 853 -> 887). Three where a step is
+    // short: single-tap convs (416 -> 384, 307 -> 286, 199 -> 186 us) and everything in two-plane mode (12 MFMAs per step:
+    // 640-frame decode 14.6 -> 14.3 ms). Prefetch depth only: same bits.
+    constexpr int NA = (NP == 2 || K == 1) ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [3 planes][W rows][XP bytes]
     // per-output-row epilogue operands (bias, layer scale, the consumer's SnakeBeta pair), fetched once per workgroup:
     // read from global inside the store loop they cannot be hoisted over the stores and cost a round trip per row
