@@ -978,7 +978,12 @@ static hipError_t launch_bf16x3_vp(const ConvDev& a, int phases, hipStream_t st)
 }
 template <int K, int CO_M, int T_M, int WCO, int WT>
 static hipError_t launch_bf16x3_v(const ConvDev& a, int phases, hipStream_t st) {
-    return a.planes == 2 ? launch_bf16x3_vp<K, CO_M, T_M, WCO, WT, 2>(a, phases, st) : launch_bf16x3_vp<K, CO_M, T_M, WCO, WT, 3>(a, phases, st);
+    // two-plane instances only for the tap counts the vocoder's heavy layers use (1, 2, 7); its one k = 3 conv (pre_conv,
+    // 0.06 ms) and the encoders' k = 3 / 5 convs always run three planes — in every decode mode alike, so chunked and
+    // whole-utterance decodes still agree
+    if constexpr (K == 1 || K == 2 || K == 7)
+        if (a.planes == 2) return launch_bf16x3_vp<K, CO_M, T_M, WCO, WT, 2>(a, phases, st);
+    return launch_bf16x3_vp<K, CO_M, T_M, WCO, WT, 3>(a, phases, st);
 }
 template <int K>
 static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) {
