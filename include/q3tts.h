@@ -162,7 +162,7 @@ q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages);
  * run on the bf16 matrix cores with each f32 operand split into bf16 planes. planes = 3 (default): hi + mid + lo, six
  * products per multiply-accumulate — every f32 product exact, PCM within 2.5e-5 RMS of the reference CPU path.
  * planes = 2: hi + mid, three products — operands carry 16-17 mantissa bits (more than TF32's 11), PCM within 1e-4 RMS
- * (the path's tolerance is 1e-3), the 640-frame decode 21.0 -> 14.7 ms. Codec token ids never depend on it. Applies to
+ * (the path's tolerance is 1e-3), the 640-frame decode 20.6 -> 14.4 ms. Codec token ids never depend on it. Applies to
  * decodes started after the call; anything but 2 or 3 is Q3_INVALID_ARG. */
 q3_status q3_model_set_codec_planes(q3_model* m, int planes);
 q3_status q3_model_kv_pool_info(q3_model* m, int* page_positions, size_t* page_bytes, int* pages_total, int* pages_in_use, int* pages_peak);
