@@ -1103,8 +1103,10 @@ static hipError_t convk(const float* x, const float* w, const float* b, float* y
 static q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStream_t st, float** taps, int c0 = 0) {
     const q3_config& c = m->cfg;
     tl_codec_model = m;
-    const CodecPlanesScope planes_scope(m->codec_planes);
-    const int NPL = m->codec_planes;
+    // Q3_CODEC_PLANES=2|3: A/B aid, overrides q3_model_set_codec_planes for the vocoder only (never the encoders)
+    static const int env_planes = [] { const char* e = getenv("Q3_CODEC_PLANES"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 3) ? v : 0; }();
+    const int NPL = env_planes ? env_planes : m->codec_planes;
+    const CodecPlanesScope planes_scope(NPL);
     const int CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden, QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
     auto TAP = [&](int id, const float* dev, size_t n) -> q3_status {
         if (taps && taps[id]) { HIPC(hipStreamSynchronize(st)); HIPC(hipMemcpy(taps[id], dev, n * 4, hipMemcpyDeviceToHost)); }

@@ -818,12 +818,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
     }
 }
 
-// planes requested by the caller (ConvArgs::planes); Q3_CODEC_PLANES overrides it for A/B runs
-static int conv_planes(int asked) {
-    static const int env = [] { const char* e = getenv("Q3_CODEC_PLANES"); return e ? atoi(e) : 0; }();
-    const int p = env ? env : asked;
-    return p == 2 ? 2 : 3;
-}
+static int conv_planes(int asked) { return asked == 2 ? 2 : 3; }      // ConvArgs::planes: anything but 2 means the exact products
 
 hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st) {
     static const bool off = getenv("Q3_CONV_F32") != nullptr || getenv("Q3_CODEC_NO_UNIT_FUSE") != nullptr;    // A/B aids
