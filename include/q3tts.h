@@ -155,9 +155,16 @@ q3_status q3_model_mark_loaded(q3_model* m);
  * row is replaced or the session ends: a 4k-position prompt and a ten-position prompt share the memory, and
  * q3_session_replace relinks the prefilled pages into the row instead of copying them.
  * q3_model_kv_pool_limit: the most pages the model's sessions may hold at once (0 = no limit but HBM); a session that
- * needs a page beyond it fails with Q3_KV_OVERFLOW before it runs (the reference's overflow bail). q3_model_kv_pool_info: page
- * geometry and occupancy (any pointer may be NULL). */
+ * needs a page beyond it fails with Q3_KV_OVERFLOW before it runs (the reference's overflow bail). ONE budget covers f32 and
+ * bf16 sessions (q3_session_set_kv_dtype): pages are counted in f32 equivalents, a bf16 page is half of one — the f32 pages a
+ * bf16 session's prompt is prefilled into count in full until they are converted. The native batcher (q3_batcher_*) admits a
+ * request only when its worst case (prompt + max_length) fits beside what the running rows may still take, so under a limit a
+ * request waits in the queue instead of failing mid-generation; a request that cannot fit even alone fails on its ticket.
+ * q3_model_kv_pool_info: page geometry and occupancy in f32-equivalent pages (any pointer may be NULL).
+ * q3_model_kv_pool_trim: slabs (32 pages, ~1 GB at 28 layers x 8 KV heads) none of whose pages is held go back to the device;
+ * the first f32 slab is allocated by q3_model_finalize so that it is not on the first request's time to first audio. */
 q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages);
+q3_status q3_model_kv_pool_trim(q3_model* m, size_t* bytes_freed);
 /* Vocoder arithmetic. The codec decoder's convs (decoder_block.rs:81-92, 240-247; F32 in the reference on every device)
  * run on the bf16 matrix cores with each f32 operand split into bf16 planes. planes = 3 (default): hi + mid + lo, six
  * products per multiply-accumulate — every f32 product exact, PCM within 2.5e-5 RMS of the reference CPU path.
@@ -178,9 +185,13 @@ q3_status q3_synth_fill(uint64_t seed, const char* name, int dtype, float scale,
 /* ---------------- session = one batch of utterances on one GPU ----------------
  * Owns KV pages, RNG streams, penalty masks (the fields of StreamingSession, lib.rs:1484-1508).
  * batch > 1 has no reference counterpart (reference batch = 1): every sequence behaves exactly
- * as its own batch-1 run. One restriction: the sequences of a batch must have equal PREFILL lengths
- * (same mode and, for voice design / ICL, same instruct / reference lengths — text length is free, it
- * rides along as trailing text); otherwise Q3_UNSUPPORTED. Group requests by prefill shape, one session each.
+ * as its own batch-1 run. The sequences may be of ANY mix of prompt kinds and lengths (CustomVoice lib.rs:718-784,
+ * VoiceDesign 802-870, x-vector / ICL voice clone 897-1046): rows of one prefill length are prefilled together (the text
+ * length is free — it rides along as trailing text — so all CustomVoice requests share one batched prefill); a RAGGED
+ * batch is prefilled in groups of equal prefill length by q3_session_prefill, each group on the side, and every row is then
+ * moved into the session the way q3_session_replace does — decode runs in one captured frame graph over all rows. A
+ * malformed request of a ragged batch is reported by q3_session_prefill (equal-length batches: by q3_session_create);
+ * debug / profiling sessions (q3_session_set_debug) need rows of one prefill length.
  * Every request keeps its own q3_options — temperature, top-k / top-p, repetition penalty, min_new_tokens, EOS id, seed,
  * max_length: one sampler row per sequence on the device; only chunk_frames must be the same for all of them. */
 q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out);

@@ -73,6 +73,7 @@ SYMBOLS = {
     "q3_model_arena": (c_int, [c_void_p, P(c_void_p), P(ctypes.c_size_t)]),
     "q3_model_kv_pool_limit": (c_int, [c_void_p, c_int]),
     "q3_model_set_codec_planes": (c_int, [c_void_p, c_int]),
+    "q3_model_kv_pool_trim": (c_int, [c_void_p, P(ctypes.c_size_t)]),
     "q3_model_kv_pool_info": (c_int, [c_void_p, P(c_int), P(ctypes.c_size_t), P(c_int), P(c_int), P(c_int)]),
     "q3_model_mark_loaded": (c_int, [c_void_p]),
     "q3_model_finalize": (c_int, [c_void_p]),

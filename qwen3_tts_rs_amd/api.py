@@ -618,8 +618,15 @@ class Qwen3TTS:
         (default), 2 = hi + mid planes only (PCM within 1e-4 RMS of the reference instead of 2.5e-5; 30 % less vocoder time)."""
         check(lib.q3_model_set_codec_planes(self._h, int(planes)))
 
+    def kv_pool_trim(self) -> int:
+        """Slabs of the KV page pool that hold no page in use go back to the device (q3_model_kv_pool_trim); bytes freed."""
+        n = ctypes.c_size_t()
+        check(lib.q3_model_kv_pool_trim(self._h, ctypes.byref(n)))
+        return n.value
+
     def kv_pool_info(self) -> dict:
-        """Page geometry and occupancy of the model's KV pool (q3_model_kv_pool_info)."""
+        """Page geometry and occupancy of the model's KV pool in f32-equivalent pages — a bf16 session's page counts half
+        (q3_model_kv_pool_info)."""
         pp = ctypes.c_int(); pb = ctypes.c_size_t(); tot = ctypes.c_int(); use = ctypes.c_int(); peak = ctypes.c_int()
         check(lib.q3_model_kv_pool_info(self._h, ctypes.byref(pp), ctypes.byref(pb), ctypes.byref(tot), ctypes.byref(use), ctypes.byref(peak)))
         return {"page_positions": pp.value, "page_bytes": pb.value, "pages_total": tot.value, "pages_in_use": use.value, "pages_peak": peak.value}
@@ -671,36 +678,30 @@ class Qwen3TTS:
 
     @staticmethod
     def prefill_shape(u: "Utterance") -> Tuple[int, int, int, int]:
-        """What fixes an utterance's prefill length (q3_session_create): a session takes utterances of ONE shape."""
+        """What fixes an utterance's prefill length: rows of one shape are prefilled together (q3_session_create groups a
+        ragged batch by it)."""
         icl = u.ref_codes is not None and u.ref_text_ids is not None
         n_ins = len(u.instruct_ids) if u.instruct_ids is not None else 0
         n_icl = (len(np.asarray(u.ref_codes).reshape(-1, 16)) + 1) if icl else 0
         return (u.mode(), n_ins, 1 if (len(u.text_ids) > 0 and not icl) else 0, n_icl)
 
     def synthesize_batch(self, utts: Sequence[Utterance], options=None):
-        """Batch of arbitrary requests: utterances are grouped by prefill shape, one session per group (sessions need
-        equal prefill lengths), results returned in request order. The timing is the sum over the groups."""
-        groups = {}
-        o = options or SynthesisOptions()
-        for i, u in enumerate(utts):
-            key = self.prefill_shape(u)
-            if key[3]:      # ICL: q3_session_create caps max_length at max(75, 6 * n_text) per sequence (lib.rs:913-929) and a
-                key = key + (min(o.max_length, max(75, 6 * len(u.text_ids))),)      # session needs ONE resolved max_length
-            groups.setdefault(key, []).append(i)
+        """Batch of arbitrary requests (any mix of prompt kinds and lengths): up to Q3_MAX_BATCH (64) of them per session — a
+        session prefills rows of equal prefill length together and decodes all rows in one captured frame graph
+        (q3_session_create on a ragged batch) —, results in request order. The timing is the sum over the sessions."""
         audio: List[Optional[AudioBuffer]] = [None] * len(utts)
         tot = SynthesisTiming(0.0, 0.0, 0, 0.0)
-        for idx in groups.values():
-            for k in range(0, len(idx), MAX_BATCH):             # a session holds up to Q3_MAX_BATCH (64) sequences
-                part = idx[k:k + MAX_BATCH]
-                s = self.session([utts[i] for i in part], options)
-                try:
-                    a, t = s.run()
-                finally:
-                    s.close()
-                for j, i in enumerate(part):
-                    audio[i] = a[j]
-                tot = SynthesisTiming(tot.prefill_ms + t.prefill_ms, tot.generation_ms + t.generation_ms,
-                                      tot.generation_frames + t.generation_frames, tot.decode_ms + t.decode_ms)
+        for k in range(0, len(utts), MAX_BATCH):
+            part = list(range(k, min(k + MAX_BATCH, len(utts))))
+            s = self.session([utts[i] for i in part], options)
+            try:
+                a, t = s.run()
+            finally:
+                s.close()
+            for j, i in enumerate(part):
+                audio[i] = a[j]
+            tot = SynthesisTiming(tot.prefill_ms + t.prefill_ms, tot.generation_ms + t.generation_ms,
+                                  tot.generation_frames + t.generation_frames, tot.decode_ms + t.decode_ms)
         return audio, tot
 
     def synthesize_continuous(self, utts: Sequence[Utterance], options=None, slots: int = 8, poll_frames: int = 32,
@@ -708,9 +709,7 @@ class Qwen3TTS:
         """Continuous batching over ONE session of `slots` rows: the first `slots` requests start together; whenever a row ends
         (EOS, or its own max_length) its codes are collected and the next waiting request is swapped into the row
         (q3_session_replace) while the other rows keep running — no row idles until the slowest one is done. The requests
-        may be of any prompt kind and length: when the first `slots` of them do not share one prefill shape the session is
-        opened on copies of the first request and the others are swapped in before the first frame (each prefilled on the
-        side, as later arrivals are). Returns (codes per request, PCM per request or None, frames generated, wall seconds
+        may be of any prompt kind and length (a session prefills rows of equal prefill length together). Returns (codes per request, PCM per request or None, frames generated, wall seconds
         of the generation loop)."""
         import time as _time
         o = options or SynthesisOptions()
@@ -720,17 +719,13 @@ class Qwen3TTS:
         # capacity for the longest request and the longest prompt, whenever they arrive (prompt positions: instruct + role /
         # codec overlay rows + ICL reference frames; 16 covers the fixed part of every prompt kind, talker.rs:451-627)
         prompt = max((0 if u.instruct_ids is None else len(u.instruct_ids)) + (0 if u.ref_codes is None else int(np.asarray(u.ref_codes).reshape(-1, 16).shape[0])) + 16 for u in utts)
-        mixed = len({self.prefill_shape(u) for u in utts[:n0]}) > 1
-        s = Session(self, [utts[0]] * n0 if mixed else utts[:n0], o, frame_budget=budget, prompt_budget=prompt)
+        s = Session(self, utts[:n0], o, frame_budget=budget, prompt_budget=prompt)
         owner = list(range(n0)); nxt = n0
         codes: List[Optional[np.ndarray]] = [None] * len(utts); pcm: List[Optional[np.ndarray]] = [None] * len(utts)
         frames = 0
         t0 = _time.perf_counter()
         try:
             s.prefill()
-            if mixed:
-                for b in range(1, n0):
-                    s.replace(b, utts[b])
             while any(i is not None for i in owner):
                 s.generate(poll_frames, use_graph=use_graph)
                 for b in range(n0):

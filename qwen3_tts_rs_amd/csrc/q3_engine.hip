@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <memory>
@@ -162,6 +163,14 @@ struct UpW { const float *tw, *tb, *dww, *dwb, *nw, *nb, *p1w, *p1b, *p2w, *p2b,
 // prefilled pages of the side session into the row instead of copying extents. Pages are never cleared: the attention
 // kernels read a position only after it was written.
 // ------------------------------------------------------------------------------------------------
+// One page budget for both pools of a model (q3_model_kv_pool_limit), in UNITS of half an f32 page: an f32 page costs 2, a
+// bf16 page (same geometry, 2-byte elements) 1 — so the documented limit, the Q3_KV_OVERFLOW bail and the occupancy figures hold
+// for bf16 sessions and for the f32 pages their prompts are prefilled into alike.
+struct KvBudget {
+    std::mutex mu;
+    long limit = 0, used = 0, peak = 0;            // units; limit 0 = bounded by HBM only
+    bool fits(long units) { std::lock_guard<std::mutex> g(mu); return limit <= 0 || used + units <= limit; }
+};
 struct KvPool {
     // Slab layout (layer-major, so that ONE layer's K/V of every page of a slab sits in one contiguous run — the attention
     // launch of a layer touches SLAB_SLOTS x 512 KB = 16 MB runs instead of one 64 KB run per (page, head) spread 29 MB
@@ -174,7 +183,8 @@ struct KvPool {
     size_t run_floats = 0; int n_layers = 0;       // run = nkv * KV_PAGE_POS * HEAD_DIM ELEMENTS (one layer's K of one page)
     size_t elem_bytes = sizeof(float);              // 4, or 2 for the pool of bf16 sessions (same geometry in elements)
     std::vector<void*> slabs; std::vector<float*> free_pages;
-    int total = 0, in_use = 0, peak = 0, limit = 0;       // pages; limit 0 = bounded by HBM only
+    int total = 0, in_use = 0;                      // pages of this pool
+    KvBudget* budget = nullptr; int unit = 2;       // the model's shared budget and what one page of this pool costs of it
     // K -> V and layer -> layer distances are kept OFF powers of two (17 KB of padding behind every region): a lane asks for
     // the K row and the V row of a position together, and at exactly 16 MB apart the two requests meet in the same memory
     // channel (k_attn_fused 7.6 vs 6.9 us per launch at B = 8 against the contiguous caches, whose distance is arbitrary)
@@ -187,7 +197,10 @@ struct KvPool {
     hipError_t take(int n, std::vector<float*>& out) {
         std::lock_guard<std::mutex> g(mu);
         if (n <= 0) return hipSuccess;
-        if (limit > 0 && in_use + n > limit) return hipErrorOutOfMemory;
+        {
+            std::lock_guard<std::mutex> gb(budget->mu);
+            if (budget->limit > 0 && budget->used + (long)n * unit > budget->limit) return hipErrorOutOfMemory;
+        }
         while ((int)free_pages.size() < n) {          // whole slabs (~1 GB at 28 layers x 8 KV heads), kept for the model's lifetime: no hipMalloc in steady state
             void* slab = nullptr;
             if (hipMalloc(&slab, slab_bytes()) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
@@ -196,14 +209,44 @@ struct KvPool {
             total += SLAB_SLOTS;
         }
         for (int i = 0; i < n; ++i) { out.push_back(free_pages.back()); free_pages.pop_back(); }
-        in_use += n; if (in_use > peak) peak = in_use;
+        in_use += n;
+        std::lock_guard<std::mutex> gb(budget->mu);      // (sessions of one model may run on several host threads: two takers can
+        budget->used += (long)n * unit;                  //  overshoot the limit by one request between the check and here; the
+        if (budget->used > budget->peak) budget->peak = budget->used;      // limit is an admission bound, not a hard allocator wall)
         return hipSuccess;
     }
     void give(std::vector<float*>& pages) {
         std::lock_guard<std::mutex> g(mu);
         for (float* p : pages) free_pages.push_back(p);
         in_use -= (int)pages.size();
+        { std::lock_guard<std::mutex> gb(budget->mu); budget->used -= (long)pages.size() * unit; }
         pages.clear();
+    }
+    // slabs none of whose pages is held go back to the device (q3_model_kv_pool_trim); returns the bytes freed
+    size_t trim() {
+        std::lock_guard<std::mutex> g(mu);
+        size_t freed = 0;
+        for (size_t i = 0; i < slabs.size();) {
+            char* lo = (char*)slabs[i]; char* hi = lo + (size_t)SLAB_SLOTS * run_floats * elem_bytes;      // the slab's layer-0 K runs name its pages
+            int n_free = 0;
+            for (float* p : free_pages) n_free += ((char*)p >= lo && (char*)p < hi) ? 1 : 0;
+            if (n_free < SLAB_SLOTS) { ++i; continue; }
+            free_pages.erase(std::remove_if(free_pages.begin(), free_pages.end(), [&](float* p) { return (char*)p >= lo && (char*)p < hi; }), free_pages.end());
+            (void)hipFree(slabs[i]); slabs.erase(slabs.begin() + (long)i);
+            total -= SLAB_SLOTS; freed += slab_bytes();
+        }
+        return freed;
+    }
+    // the first slab ahead of the first request (q3_model_finalize): its hipMalloc (~1 GB) is then not on a session's time to first audio
+    hipError_t prewarm() {
+        std::vector<float*> one;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!slabs.empty()) return hipSuccess;
+        }
+        const hipError_t e = take(1, one);
+        if (e == hipSuccess) give(one);
+        return e;
     }
     ~KvPool() { for (void* s : slabs) (void)hipFree(s); }
 };
@@ -212,11 +255,12 @@ struct q3_model {
     q3_config cfg{};
     int device = 0;
     int codec_planes = 3;  // q3_model_set_codec_planes: 3 = f32-exact bf16x3 products in the vocoder's convs, 2 = the two leading planes
+    KvBudget kv_budget;    // one limit / occupancy for both pools below, in half-f32-page units
     KvPool kv_pool;
     KvPool kv_pool16;      // pages of bf16 sessions (q3_session_set_kv_dtype): the same geometry with 2-byte elements
     // sessions hold pages, streams and weights of their model: q3_model_free with sessions still alive only marks the model,
     // the last q3_session_free destroys it (a host that tears down in the wrong order must not crash)
-    std::atomic<int> live_sessions{0}; std::atomic<bool> zombie{false};
+    std::atomic<int> live_sessions{0}; std::atomic<bool> zombie{false}; std::atomic<bool> claimed{false};     // claimed: someone is destroying it
     std::vector<Slot> slots;
     std::unordered_map<std::string, int> index;
     char* arena = nullptr; size_t arena_bytes = 0;
@@ -485,6 +529,7 @@ extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model*
     std::unique_ptr<q3_model> m(new q3_model());
     m->kv_pool.run_floats = (size_t)cfg->n_kv_heads * KV_PAGE_POS * HEAD_DIM; m->kv_pool.n_layers = cfg->n_layers;
     m->kv_pool16.run_floats = m->kv_pool.run_floats; m->kv_pool16.n_layers = cfg->n_layers; m->kv_pool16.elem_bytes = 2;
+    m->kv_pool.budget = &m->kv_budget; m->kv_pool.unit = 2; m->kv_pool16.budget = &m->kv_budget; m->kv_pool16.unit = 1;
     m->cfg = *cfg; m->device = device;
     build_manifest(m.get());
     HIPC(hipMalloc((void**)&m->arena, m->arena_bytes));
@@ -496,7 +541,12 @@ extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model*
 static void model_destroy(q3_model* m);
 extern "C" void q3_model_free(q3_model* m) {
     if (!m) return;
-    if (m->live_sessions.load() > 0) { m->zombie.store(true); return; }
+    // zombie first, THEN look at the count: a session freed between a check and a later store would find zombie unset, leave,
+    // and nobody would destroy the model. With this order either the last session sees zombie (its fetch_sub comes after the
+    // store) and destroys the model, or this thread sees the count at zero — `claimed` makes sure only one of them does.
+    m->zombie.store(true);
+    if (m->live_sessions.load() > 0) return;
+    if (m->claimed.exchange(true)) return;
     model_destroy(m);
 }
 static void model_destroy(q3_model* m) {
@@ -520,19 +570,34 @@ extern "C" q3_status q3_model_set_codec_planes(q3_model* m, int planes) {
 extern "C" q3_status q3_model_kv_pool_limit(q3_model* m, int max_pages) {
     if (!m || m->device < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: no device model");
     if (max_pages < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: negative limit");
-    std::lock_guard<std::mutex> g(m->kv_pool.mu);
-    if (max_pages > 0 && max_pages < m->kv_pool.in_use) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: %d pages are in use", m->kv_pool.in_use);
-    m->kv_pool.limit = max_pages;
+    std::lock_guard<std::mutex> g(m->kv_budget.mu);
+    if (max_pages > 0 && 2L * max_pages < m->kv_budget.used)
+        return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_limit: %ld pages (f32 equivalents) are in use", (m->kv_budget.used + 1) / 2);
+    m->kv_budget.limit = 2L * max_pages;
     return Q3_OK;
 }
+// Pages are counted in f32 equivalents: a page of a bf16 session (q3_session_set_kv_dtype) is half of one, rounded up in the
+// totals below — one budget covers both pools.
 extern "C" q3_status q3_model_kv_pool_info(q3_model* m, int* page_positions, size_t* page_bytes, int* pages_total, int* pages_in_use, int* pages_peak) {
     if (!m || m->device < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_info: no device model");
-    std::lock_guard<std::mutex> g(m->kv_pool.mu);
+    int tot = 0;
+    { std::lock_guard<std::mutex> g(m->kv_pool.mu); tot += m->kv_pool.total; }
+    { std::lock_guard<std::mutex> g(m->kv_pool16.mu); tot += (m->kv_pool16.total + 1) / 2; }
+    std::lock_guard<std::mutex> g(m->kv_budget.mu);
     if (page_positions) *page_positions = KV_PAGE_POS;
     if (page_bytes) *page_bytes = m->kv_pool.page_bytes();
-    if (pages_total) *pages_total = m->kv_pool.total;
-    if (pages_in_use) *pages_in_use = m->kv_pool.in_use;
-    if (pages_peak) *pages_peak = m->kv_pool.peak;
+    if (pages_total) *pages_total = tot;
+    if (pages_in_use) *pages_in_use = (int)((m->kv_budget.used + 1) / 2);
+    if (pages_peak) *pages_peak = (int)((m->kv_budget.peak + 1) / 2);
+    return Q3_OK;
+}
+// Slabs of either pool none of whose pages is held go back to the device (a server that has seen one very long prompt need not
+// keep its ~1 GB slabs for the model's lifetime). Safe beside running sessions: held pages pin their slab.
+extern "C" q3_status q3_model_kv_pool_trim(q3_model* m, size_t* bytes_freed) {
+    if (!m || m->device < 0) return set_err(Q3_INVALID_ARG, "q3_model_kv_pool_trim: no device model");
+    HIPC(hipSetDevice(m->device));
+    const size_t n = m->kv_pool.trim() + m->kv_pool16.trim();
+    if (bytes_freed) *bytes_freed = n;
     return Q3_OK;
 }
 
@@ -903,6 +968,9 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
     }
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
+    // the f32 page pool's first slab now, not inside the first session's prefill (its ~1 GB hipMalloc sat on the first request's
+    // time to first audio); a failure here is not fatal — the first session will report it. Q3_KV_NO_PREWARM=1: lazily, as before
+    if (!getenv("Q3_KV_NO_PREWARM")) { if (m->kv_pool.prewarm() != hipSuccess) (void)hipGetLastError(); }
     m->finalized = true;
     return Q3_OK;
 }
@@ -1281,6 +1349,26 @@ extern "C" q3_status q3_decode_codes(q3_model* m, const uint32_t* frames_host, i
 struct LmBuf { float *X, *SUM, *QKV, *Q, *ATT, *ACT, *PART; };
 struct LmDims { int H, I, nh, nkv, layers; float eps; };
 
+// a request with its arrays owned (queued tickets of the batcher; the rows of a ragged first batch until they are prefilled)
+struct BatReq {
+    q3_request r{}; std::vector<uint32_t> text, instruct, ref_codes, ref_text; std::vector<float> xvec;
+    void own(const q3_request& q, int hidden) {
+        r = q;
+        text.assign(q.text_ids, q.text_ids + (q.text_ids ? q.n_text : 0));
+        instruct.assign(q.instruct_ids, q.instruct_ids + (q.instruct_ids ? q.n_instruct : 0));
+        ref_codes.assign(q.ref_codes, q.ref_codes + (q.ref_codes ? (size_t)q.n_ref * 16 : 0));
+        ref_text.assign(q.ref_text_ids, q.ref_text_ids + (q.ref_text_ids ? q.n_ref_text : 0));
+        if (q.xvector) xvec.assign(q.xvector, q.xvector + hidden);
+        fix();
+    }
+    void fix() {      // pointers into this object's own storage (after a move of the object)
+        r.text_ids = text.empty() ? nullptr : text.data(); r.n_text = (int32_t)text.size();
+        r.instruct_ids = instruct.empty() ? nullptr : instruct.data(); r.n_instruct = (int32_t)instruct.size();
+        r.ref_codes = ref_codes.empty() ? nullptr : ref_codes.data(); r.n_ref = (int32_t)(ref_codes.size() / 16);
+        r.ref_text_ids = ref_text.empty() ? nullptr : ref_text.data(); r.n_ref_text = (int32_t)ref_text.size();
+        r.xvector = xvec.empty() ? nullptr : xvec.data();
+    }
+};
 struct SeqInfo {
     q3_request req; std::vector<uint32_t> text, instruct, ref_codes, ref_text; std::vector<float> xvec; bool icl = false;
     int prefill_len = 0, trailing_len = 0, row_base = 0, n_rows = 0, trail_base = 0, pad_row = 0;
@@ -1288,6 +1376,7 @@ struct SeqInfo {
     // rows end at different frames: a row generates at most `limit` frames (its own max_length) counted from session frame
     // `start_run` (0, or the session's frame count when the row was swapped in: q3_session_replace)
     int start_run = 0, limit = 0, stream_pos = 0;
+    bool idle = false;      // frozen by session_idle_row: holds one page (the one its frozen position lies in), takes no more
 };
 
 struct ProfAcc { double ms = 0; double bytes = 0; long launches = 0; };
@@ -1311,6 +1400,11 @@ struct q3_session {
     // paged talker KV (the default; Q3_KV_CONTIGUOUS=1 keeps one extent per row: A/B aid): kv_table[b][KV_MAX_PAGES] page
     // pointers on the device (what the attention kernels read), kv_rows[b] = the pages row b holds, in position order
     bool paged = false; unsigned long long* kv_table = nullptr; std::vector<std::vector<float*>> kv_rows;
+    // ragged first batch (q3_session_create with rows of different prefill lengths / prompt kinds): the session was opened on
+    // idle rows, these are the real requests; q3_session_prefill prefills them in groups of equal prefill length and moves each
+    // row in (transplant_row), exactly as a continuous-batching swap would
+    std::vector<BatReq> ragged;
+    int kv_overflow_row = -1;             // the row whose page request the pool refused (kv_reserve_row): the batcher fails that row alone
     // bf16 K/V (opt-in, q3_session_set_kv_dtype; the reference GPU path's cache dtype): the prompt is prefilled into f32 pages
     // as always, converted once into pages of the bf16 pool (kv_in_bf16 from then on), and the decode attention reads / appends bf16
     bool kv_bf16 = false, kv_in_bf16 = false; unsigned long long* kv_conv = nullptr;      // kv_conv: [2][B * KV_MAX_PAGES] page lists of the conversion launch
@@ -1401,8 +1495,11 @@ static q3_status kv_reserve_row(q3_session* s, int b, int n_pos) {
     if (need <= have) return Q3_OK;
     KvPool& pool = s->kv_in_bf16 ? s->m->kv_pool16 : s->m->kv_pool;
     if (pool.take(need - have, row) != hipSuccess)
-        return set_err(Q3_KV_OVERFLOW, "KV page pool exhausted: row %d needs %d more page(s) of %d positions (pool: %d of %d in use, limit %d)",
-                       b, need - have, KV_PAGE_POS, pool.in_use, pool.total, pool.limit);
+    {
+        s->kv_overflow_row = b;
+        return set_err(Q3_KV_OVERFLOW, "KV page pool exhausted: row %d needs %d more %s page(s) of %d positions (budget: %ld of %ld half-pages in use)",
+                       b, need - have, s->kv_in_bf16 ? "bf16" : "f32", KV_PAGE_POS, s->m->kv_budget.used, s->m->kv_budget.limit);
+    }
     static_assert(sizeof(float*) == sizeof(unsigned long long), "page table entries are 64-bit pointers");
     HIPC(hipMemcpyAsync(s->kv_table + (size_t)b * KV_MAX_PAGES + have, row.data() + have, (size_t)(need - have) * 8, hipMemcpyHostToDevice, s->stream));
     return Q3_OK;
@@ -1411,8 +1508,10 @@ static q3_status kv_reserve_row(q3_session* s, int b, int n_pos) {
 // that reached its limit keeps rewriting position prefill_len + limit (k_sample freezes its counters)
 static q3_status kv_reserve_frames(q3_session* s, int frames) {
     if (!s->paged) return Q3_OK;
+    s->kv_overflow_row = -1;
     for (int b = 0; b < s->B; ++b) {
         const SeqInfo& q = s->seq[(size_t)b];
+        if (q.idle) continue;
         int upto = s->frames_run - q.start_run + frames;
         if (upto > q.limit) upto = q.limit;
         if (upto < 0) upto = 0;
@@ -1743,12 +1842,75 @@ static q3_status frame_launch(q3_session* s) {
 
 static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out,
                                 hipStream_t borrow = nullptr);
+// prefill positions and frame limit of a request as session_create will resolve them (talker.rs:451-491 / 511-564 / 585-627; the
+// ICL length cap of lib.rs:913-929) — for callers that must know a row's worst-case KV extent before a session exists
+static void request_shape(const q3_request& r, int* prefill_len, int* limit) {
+    const bool icl = r.mode == Q3_MODE_VOICE_CLONE && r.n_ref > 0 && r.ref_codes && r.ref_text_ids;
+    const int n_ins = r.mode == Q3_MODE_VOICE_DESIGN ? r.n_instruct : 0;
+    const int overlay = r.mode == Q3_MODE_VOICE_DESIGN ? 5 : 6;
+    *prefill_len = n_ins + 3 + overlay + ((r.n_text > 0 && !icl) ? 1 : 0) + (icl ? r.n_ref + 1 : 0);
+    int lim = r.opts.max_length;
+    if (icl) { int cap = 6 * r.n_text; if (cap < 75) cap = 75; if (lim > cap) lim = cap; }
+    *limit = lim;
+}
+// worst-case cost of a row against the model's KV budget (KvBudget units): every page prompt + limit + 1 positions can reach; a
+// bf16 row holds f32 pages for its prompt and, while they are converted, bf16 pages beside them
+static long row_worst_units(int prefill_len, int limit, bool bf16) {
+    const long full = (prefill_len + limit + 1 + KV_PAGE_POS - 1) / KV_PAGE_POS, pre = (prefill_len + 1 + KV_PAGE_POS - 1) / KV_PAGE_POS;
+    return bf16 ? std::max(3 * pre, full) : 2 * full;
+}
+// a request that only occupies a row: a one-token CustomVoice prompt with a one-frame limit, built from fixed, known-valid values
+// (ten prefill positions). Rows of the batcher's session before a ticket enters them; rows of a ragged first batch before prefill.
+static q3_request idle_request(int chunk_frames) {
+    static const uint32_t one_tok[1] = {0};
+    q3_request d{};
+    d.mode = Q3_MODE_CUSTOM_VOICE; d.text_ids = one_tok; d.n_text = 1;
+    d.speaker_id = 0; d.language_id = 0;                                       // codec token 0: valid in every vocabulary
+    d.opts.temperature = 0.9; d.opts.top_p = 0.9; d.opts.repetition_penalty = 1.05; d.opts.top_k = 50;      // SynthesisOptions::default (lib.rs:1786-1836)
+    d.opts.eos_token_id = -1; d.opts.min_new_tokens = 2; d.opts.max_length = 1; d.opts.has_seed = 1; d.opts.seed = 0;
+    d.opts.chunk_frames = chunk_frames;
+    return d;
+}
+// Sessions take rows of ANY mix of prompt kinds and lengths (round 5; BASELINE config[3] on a Base checkpoint mixes x-vector and
+// ICL prompts, lib.rs:718-784, 802-870, 897-1046 are per-call in the reference). Rows of one prefill length are prefilled
+// together by the session itself (the fast path: one batched prefill). A RAGGED batch is opened on idle rows sized for the
+// longest prompt / largest limit; q3_session_prefill then prefills the rows in groups of equal prefill length — each group a
+// batched side prefill — and moves every row in the way a continuous-batching swap does (transplant_row), so every row carries
+// the bits of its own run and decode proceeds in one captured frame graph over all rows.
+static q3_status session_create_any(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out) {
+    if (!m || !reqs || !out) return set_err(Q3_INVALID_ARG, "q3_session_create: null argument");
+    if (batch < 1 || batch > Q3_MAX_BATCH) return set_err(Q3_UNSUPPORTED, "batch %d unsupported (1..%d sequences per session)", batch, Q3_MAX_BATCH);
+    bool ragged = false; int S0 = 0, L0 = 0, Smax = 0, Lmax = 0, rows_max = 0;
+    for (int b = 0; b < batch; ++b) {
+        const q3_request& r = reqs[b];
+        if (r.n_text < 0 || r.n_instruct < 0 || r.n_ref < 0 || r.n_ref_text < 0) return set_err(Q3_INVALID_ARG, "bad token id arrays");
+        int S = 0, L = 0; request_shape(r, &S, &L);
+        if (b == 0) { S0 = S; L0 = L; }
+        ragged = ragged || S != S0;
+        Smax = std::max(Smax, S); Lmax = std::max(Lmax, L);
+        rows_max = std::max(rows_max, (r.mode == Q3_MODE_VOICE_DESIGN ? r.n_instruct : 0) + 5 + r.n_ref_text + r.n_text + 1);
+        if (r.opts.chunk_frames != reqs[0].opts.chunk_frames) return set_err(Q3_UNSUPPORTED, "all requests of a batch must share chunk_frames (the streaming chunk is a property of the session)");
+    }
+    (void)L0;
+    if (!ragged) return session_create(m, reqs, batch, frame_budget, prompt_budget, out);
+    if (Lmax < 1) return set_err(Q3_INVALID_ARG, "max_length must be >= 1");
+    const int fb = std::max(frame_budget, Lmax);
+    int pb = std::max(std::max(prompt_budget, Smax), 16);
+    if (rows_max > pb + 1024) pb = rows_max - 1024;          // a row's text-row slot is prompt_budget + 1024 rows
+    std::vector<q3_request> idle((size_t)batch, idle_request(reqs[0].opts.chunk_frames));
+    q3_session* s = nullptr;
+    Q3C(session_create(m, idle.data(), batch, fb, pb, &s));
+    s->ragged.resize((size_t)batch);
+    for (int b = 0; b < batch; ++b) s->ragged[(size_t)b].own(reqs[b], m->cfg.hidden);
+    *out = s;
+    return Q3_OK;
+}
 extern "C" q3_status q3_session_create(q3_model* m, const q3_request* reqs, int batch, q3_session** out) {
-    return session_create(m, reqs, batch, 0, 0, out);
+    return session_create_any(m, reqs, batch, 0, 0, out);
 }
 extern "C" q3_status q3_session_create_reserved(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out) {
-    if (frame_budget < 0 || prompt_budget < 0) return set_err(Q3_INVALID_ARG, "q3_session_create_reserved: budgets must be >= 0");
-    return session_create(m, reqs, batch, frame_budget, prompt_budget, out);
+    if (frame_budget < 0 || prompt_budget < 0) return set_err(Q3_INVALID_ARG, "q3_session_create_reserved: negative budget");
+    return session_create_any(m, reqs, batch, frame_budget, prompt_budget, out);
 }
 static q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int frame_budget, int prompt_budget, q3_session** out,
                                 hipStream_t borrow) {
@@ -1967,7 +2129,7 @@ q3_session::~q3_session() {
     }
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
     pool.release_all();                                          // the model's device must still be current for these
-    if (m->live_sessions.fetch_sub(1) == 1 && m->zombie.load()) model_destroy(m);
+    if (m->live_sessions.fetch_sub(1) == 1 && m->zombie.load() && !m->claimed.exchange(true)) model_destroy(m);
 }
 
 extern "C" void q3_session_free(q3_session* s) { delete s; }
@@ -2008,6 +2170,12 @@ extern "C" q3_status q3_session_stream(q3_session* s, void** stream) {
 }
 extern "C" q3_status q3_session_prefill_len(q3_session* s, int b, int* prefill_len, int* trailing_len) {
     if (!s || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad sequence index");
+    if (!s->ragged.empty()) {                    // a ragged batch before its prefill: the rows are still idle placeholders
+        int S = 0, L = 0; request_shape(s->ragged[(size_t)b].r, &S, &L);
+        if (prefill_len) *prefill_len = S;
+        if (trailing_len) *trailing_len = -1;
+        return Q3_OK;
+    }
     if (prefill_len) *prefill_len = s->seq[b].prefill_len;
     if (trailing_len) *trailing_len = s->seq[b].trailing_len;
     return Q3_OK;
@@ -2151,11 +2319,50 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
     return Q3_OK;
 }
 
+static q3_status transplant_row(q3_session* s, int b, q3_session* side, int j, int limit);
+static q3_status transplant_check(q3_session* s, q3_session* side, int j, int limit_req, int* limit_out);
+// q3_session_prefill of a ragged first batch (session_create_any): the idle rows never run — every row's state comes from a side
+// session. Rows are grouped by prefill length in row order; a group of G rows is one batched side prefill.
+static q3_status prefill_ragged(q3_session* s) {
+    if (s->debug || s->profile) return set_err(Q3_UNSUPPORTED, "debug / profiling sessions need rows of one prefill length");
+    const int B = s->B;
+    s->kv_in_bf16 = s->kv_bf16;                          // the idle rows hold no pages: nothing to convert
+    s->prefilled = true; s->frames_run = 0; s->codes_host_valid = false;      // transplant_row stamps rows with start_run = frames_run
+    std::vector<char> placed((size_t)B, 0);
+    for (int b0 = 0; b0 < B; ++b0) {
+        if (placed[(size_t)b0]) continue;
+        int S0 = 0, L = 0; request_shape(s->ragged[(size_t)b0].r, &S0, &L);
+        std::vector<int> rows; std::vector<q3_request> reqs; std::vector<int> limits;
+        for (int b = b0; b < B; ++b) {
+            int S = 0; request_shape(s->ragged[(size_t)b].r, &S, &L);
+            if (placed[(size_t)b] || S != S0) continue;
+            q3_request r = s->ragged[(size_t)b].r;
+            if (r.opts.max_length < 1 || r.opts.max_length > s->max_frames) { s->prefilled = false; return set_err(Q3_INVALID_ARG, "row %d: max_length %d outside 1..%d", b, r.opts.max_length, s->max_frames); }
+            limits.push_back(r.opts.max_length);
+            r.opts.max_length = s->max_frames;           // the side session draws the row's PCG stream with the host session's stride
+            rows.push_back(b); reqs.push_back(r); placed[(size_t)b] = 1;
+        }
+        q3_session* side_raw = nullptr;
+        q3_status st = session_create(s->m, reqs.data(), (int)reqs.size(), 0, 0, &side_raw, s->stream);
+        std::unique_ptr<q3_session> side(side_raw);
+        if (st == Q3_OK) { side->kv_bf16 = s->kv_bf16; }
+        std::vector<int> lim(rows.size(), 0);
+        for (size_t j = 0; j < rows.size() && st == Q3_OK; ++j) st = transplant_check(s, side.get(), (int)j, limits[j], &lim[j]);
+        if (st == Q3_OK) st = q3_session_prefill(side.get());
+        if (st == Q3_OK && hipStreamSynchronize(s->stream) != hipSuccess) st = set_err(Q3_HIP_ERROR, "ragged prefill: stream");
+        for (size_t j = 0; j < rows.size() && st == Q3_OK; ++j) st = transplant_row(s, rows[j], side.get(), (int)j, lim[j]);
+        if (st != Q3_OK) { s->prefilled = false; return st; }
+    }
+    s->ragged.clear();
+    return Q3_OK;
+}
+
 extern "C" q3_status q3_session_prefill(q3_session* s) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     if (s->prefilled) return set_err(Q3_INVALID_ARG, "session already prefilled");
     const q3_model* m = s->m; const q3_config& c = m->cfg;
     HIPC(hipSetDevice(m->device));
+    if (!s->ragged.empty()) return prefill_ragged(s);
     const int B = s->B, H = c.hidden, S = s->prefill_len;
     for (int b = 0; b < B; ++b) Q3C(kv_reserve_row(s, b, S + 1));      // paged KV: the prompt's positions and the first frame's
     // 1. ids to project, per sequence: [instruct…, IM_START, ASSISTANT, NEWLINE, TTS_PAD, TTS_BOS, text…, TTS_EOS]
@@ -2387,11 +2594,80 @@ static q3_status decode_range_on(q3_session* s, int b, int f0, int f1, hipStream
 // (the unchanged prefill path) and copy its slice in: K/V extents of the prompt positions, last hidden state, first sampled
 // token, penalty mask, counters, the pre-drawn PCG stream, projected text rows. The captured frame graph is untouched — it
 // only ever reads these arrays — and the other rows do not notice: their state, and therefore their bits, are unchanged.
+// Row j of a prefilled side session becomes row b of the host session: the per-row state the captured frame graph reads is
+// copied in, the prompt's K/V pages are relinked (contiguous extents: copied). Both streams are idle (the caller drained them).
+static q3_status transplant_row(q3_session* s, int b, q3_session* side, int j, int limit) {
+    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    const SeqInfo& sq = side->seq[(size_t)j];
+    const int H = c.hidden, S = sq.prefill_len, nkv = c.n_kv_heads;
+    const size_t row_bytes = (size_t)HEAD_DIM * 4;
+    if (s->paged) {
+        // the prompt's K/V is not copied: the side session's pages become the row's (its old ones go back to the pool), and the
+        // row's table entries are rewritten
+        kv_release_row(s, b);
+        std::vector<float*>& row = s->kv_rows[(size_t)b];
+        row.assign(side->kv_rows[(size_t)j].begin(), side->kv_rows[(size_t)j].end());
+        side->kv_rows[(size_t)j].clear();
+        HIPC(hipMemcpyAsync(s->kv_table + (size_t)b * KV_MAX_PAGES, row.data(), row.size() * 8, hipMemcpyHostToDevice, s->stream));
+    } else
+    for (int l = 0; l < c.n_layers; ++l) {
+        const size_t so = (size_t)l * side->kv_layer_stride + (size_t)j * nkv * side->max_seq * HEAD_DIM, dof = (size_t)l * s->kv_layer_stride + (size_t)b * nkv * s->max_seq * HEAD_DIM;
+        HIPC(hipMemcpy2DAsync(s->kcache + dof, s->max_seq * row_bytes, side->kcache + so, side->max_seq * row_bytes, S * row_bytes, nkv, hipMemcpyDeviceToDevice, s->stream));
+        HIPC(hipMemcpy2DAsync(s->vcache + dof, s->max_seq * row_bytes, side->vcache + so, side->max_seq * row_bytes, S * row_bytes, nkv, hipMemcpyDeviceToDevice, s->stream));
+    }
+    auto d2d = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->stream); };
+    HIPC(d2d(s->LASTH + (size_t)b * H, side->LASTH + (size_t)j * H, (size_t)H * 4));
+    HIPC(d2d(s->tok + b, side->tok + j, 4));
+    HIPC(d2d(s->seen + (size_t)b * c.codec_vocab, side->seen + (size_t)j * c.codec_vocab, (size_t)c.codec_vocab));
+    HIPC(d2d(s->token_count + b, side->token_count + j, 4));
+    HIPC(d2d(s->pos + b, side->pos + j, 4));
+    HIPC(d2d(s->frame_idx + b, side->frame_idx + j, 4));
+    // the row's pre-drawn PCG stream: the side session drew max_frames(side) + 1 >= limit + 1 of them (an ICL cap may make it the shorter one)
+    HIPC(d2d(s->U + (size_t)b * (s->max_frames + 2), side->U + (size_t)j * (side->max_frames + 2),
+             (size_t)((side->max_frames < s->max_frames ? side->max_frames : s->max_frames) + 2) * 4));
+    const int row0 = s->repl_base + b * s->row_cap;
+    HIPC(d2d(s->rows + (size_t)row0 * H, side->rows + (size_t)sq.row_base * H, (size_t)sq.n_rows * H * 4));
+    const int hv[4] = {row0 + (sq.trail_base - sq.row_base), sq.trailing_len, row0 + (sq.pad_row - sq.row_base), limit};
+    HIPC(hipMemcpyAsync(s->trail_base + b, &hv[0], 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->trail_len + b, &hv[1], 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->pad_row + b, &hv[2], 4, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipMemcpyAsync(s->limit + b, &hv[3], 4, hipMemcpyHostToDevice, s->stream));
+    const SampleRow srow = sample_row(sq.req.opts);
+    HIPC(hipMemcpyAsync(s->sample_rows + b, &srow, sizeof srow, hipMemcpyHostToDevice, s->stream));
+    HIPC(hipStreamSynchronize(s->stream));
+    SeqInfo nq = sq;
+    nq.row_base = row0; nq.trail_base = hv[0]; nq.pad_row = hv[2];
+    nq.start_run = s->frames_run; nq.limit = limit; nq.n_frames = 0; nq.done = false; nq.stream_pos = 0; nq.req.opts.max_length = limit; nq.idle = false;
+    s->seq[(size_t)b] = nq;
+    {   // the request's arrays live in the row's own vectors (the caller's pointers need not outlive the call)
+        SeqInfo& q = s->seq[(size_t)b];
+        q.req.text_ids = q.text.data(); q.req.instruct_ids = q.instruct.data(); q.req.ref_codes = q.ref_codes.data();
+        q.req.ref_text_ids = q.ref_text.data(); q.req.xvector = q.xvec.empty() ? nullptr : q.xvec.data();
+    }
+    if (b == 0) s->stream_pos = 0;       // q3_session_next_chunk (the row-0 streaming call) starts over with the new utterance too
+    s->codes_host_valid = false;
+    return Q3_OK;
+}
+// what a side session must satisfy before its rows may enter the host session
+static q3_status transplant_check(q3_session* s, q3_session* side, int j, int limit_req, int* limit_out) {
+    const SeqInfo& sq = side->seq[(size_t)j];
+    if (side->opts.chunk_frames != s->opts.chunk_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: chunk_frames is a property of the session");
+    const int limit = limit_req < sq.limit ? limit_req : sq.limit;
+    if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
+    if (s->paged != side->paged) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the sessions disagree on KV paging");
+    if (s->kv_bf16 != s->kv_in_bf16) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the session's K/V conversion has not happened yet");
+    // max_seq bounds a row in both layouts: the captured frame was specialised for it (key splits, the page-table form of the
+    // attention kernel); with pages it reserves nothing — only the pages a row really reaches are taken from the pool
+    if (sq.prefill_len + limit + 1 > s->max_seq) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", sq.prefill_len, limit, s->max_seq);
+    *limit_out = limit;
+    return Q3_OK;
+}
+
 extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* req) {
     if (!s || !req || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "q3_session_replace: bad argument");
     if (!s->prefilled) return set_err(Q3_INVALID_ARG, "q3_session_replace: session not prefilled");
     if (s->debug || s->profile) return set_err(Q3_UNSUPPORTED, "q3_session_replace: not on debug / profiling sessions");
-    const q3_model* m = s->m; const q3_config& c = m->cfg;
+    const q3_model* m = s->m;
     HIPC(hipSetDevice(m->device));
     q3_request r = *req;
     const int limit_req = r.opts.max_length;
@@ -2407,62 +2683,14 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     std::unique_ptr<q3_session> side(side_raw);
     side->kv_bf16 = s->kv_bf16;                        // the side session prefills in f32 and converts, as the host session did
     lap("create");
-    const SeqInfo& sq = side->seq[0];
     // (sampling options are per row — SampleRow —, resolved by the side session: an ICL request's repetition-penalty floor and
     // length cap, lib.rs:913-929, come along)
-    if (side->opts.chunk_frames != s->opts.chunk_frames) return set_err(Q3_UNSUPPORTED, "q3_session_replace: chunk_frames is a property of the session");
-    const int limit = limit_req < sq.limit ? limit_req : sq.limit;
-    if (sq.n_rows > s->row_cap) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the request's %d text rows exceed the session's slot (%d rows: 1024, or the longest text of the original batch)", sq.n_rows, s->row_cap);
-    if (s->paged != side->paged) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the sessions disagree on KV paging");
-    if (s->kv_bf16 != s->kv_in_bf16) return set_err(Q3_UNSUPPORTED, "q3_session_replace: the session's K/V conversion has not happened yet");
-    // max_seq bounds a row in both layouts: the captured frame was specialised for it (key splits, the page-table form of the
-    // attention kernel); with pages it reserves nothing — only the pages a row really reaches are taken from the pool
-    const int kv_cap = s->max_seq;
-    if (side->prefill_len + limit + 1 > kv_cap) return set_err(Q3_KV_OVERFLOW, "q3_session_replace: prompt of %d positions + %d frames exceeds the row's KV extent (%d)", side->prefill_len, limit, kv_cap);
+    int limit = 0;
+    Q3C(transplant_check(s, side.get(), 0, limit_req, &limit));
     Q3C(q3_session_prefill(side.get()));               // ends with a synchronisation of the side stream
     lap("prefill");
     HIPC(hipStreamSynchronize(s->stream));             // no frame of the host session in flight while its row changes
-    const int H = c.hidden, S = side->prefill_len, nkv = c.n_kv_heads;
-    const size_t row_bytes = (size_t)HEAD_DIM * 4;
-    if (s->paged) {
-        // the prompt's K/V is not copied: the side session's pages become the row's (its old ones go back to the pool — both
-        // streams are idle), and the row's table entries are rewritten
-        kv_release_row(s, b);
-        std::vector<float*>& row = s->kv_rows[(size_t)b];
-        row.assign(side->kv_rows[0].begin(), side->kv_rows[0].end());
-        side->kv_rows[0].clear();
-        HIPC(hipMemcpyAsync(s->kv_table + (size_t)b * KV_MAX_PAGES, row.data(), row.size() * 8, hipMemcpyHostToDevice, s->stream));
-    } else
-    for (int l = 0; l < c.n_layers; ++l) {
-        const size_t so = (size_t)l * side->kv_layer_stride, dof = (size_t)l * s->kv_layer_stride + (size_t)b * nkv * s->max_seq * HEAD_DIM;
-        HIPC(hipMemcpy2DAsync(s->kcache + dof, s->max_seq * row_bytes, side->kcache + so, side->max_seq * row_bytes, S * row_bytes, nkv, hipMemcpyDeviceToDevice, s->stream));
-        HIPC(hipMemcpy2DAsync(s->vcache + dof, s->max_seq * row_bytes, side->vcache + so, side->max_seq * row_bytes, S * row_bytes, nkv, hipMemcpyDeviceToDevice, s->stream));
-    }
-    auto d2d = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->stream); };
-    HIPC(d2d(s->LASTH + (size_t)b * H, side->LASTH, (size_t)H * 4));
-    HIPC(d2d(s->tok + b, side->tok, 4));
-    HIPC(d2d(s->seen + (size_t)b * c.codec_vocab, side->seen, (size_t)c.codec_vocab));
-    HIPC(d2d(s->token_count + b, side->token_count, 4));
-    HIPC(d2d(s->pos + b, side->pos, 4));
-    HIPC(d2d(s->frame_idx + b, side->frame_idx, 4));
-    // the row's pre-drawn PCG stream: the side session drew max_frames(side) + 1 >= limit + 1 of them (an ICL cap may make it the shorter one)
-    HIPC(d2d(s->U + (size_t)b * (s->max_frames + 2), side->U, (size_t)((side->max_frames < s->max_frames ? side->max_frames : s->max_frames) + 2) * 4));
-    const int row0 = s->repl_base + b * s->row_cap;
-    HIPC(d2d(s->rows + (size_t)row0 * H, side->rows, (size_t)sq.n_rows * H * 4));
-    const int hv[4] = {row0 + (sq.trail_base - sq.row_base), sq.trailing_len, row0 + (sq.pad_row - sq.row_base), limit};
-    HIPC(hipMemcpyAsync(s->trail_base + b, &hv[0], 4, hipMemcpyHostToDevice, s->stream));
-    HIPC(hipMemcpyAsync(s->trail_len + b, &hv[1], 4, hipMemcpyHostToDevice, s->stream));
-    HIPC(hipMemcpyAsync(s->pad_row + b, &hv[2], 4, hipMemcpyHostToDevice, s->stream));
-    HIPC(hipMemcpyAsync(s->limit + b, &hv[3], 4, hipMemcpyHostToDevice, s->stream));
-    const SampleRow srow = sample_row(sq.req.opts);
-    HIPC(hipMemcpyAsync(s->sample_rows + b, &srow, sizeof srow, hipMemcpyHostToDevice, s->stream));
-    HIPC(hipStreamSynchronize(s->stream));
-    SeqInfo nq = sq;
-    nq.row_base = row0; nq.trail_base = hv[0]; nq.pad_row = hv[2];
-    nq.start_run = s->frames_run; nq.limit = limit; nq.n_frames = 0; nq.done = false; nq.stream_pos = 0; nq.req.opts.max_length = limit;
-    s->seq[b] = nq;
-    if (b == 0) s->stream_pos = 0;       // q3_session_next_chunk (the row-0 streaming call) starts over with the new utterance too
-    s->codes_host_valid = false;
+    Q3C(transplant_row(s, b, side.get(), 0, limit));
     lap("copies");
     side.reset();
     lap("free");
@@ -2479,25 +2707,6 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
 // copy, rows of any prompt kind), runs up to n_frames frames of the shared frame graph, and collects the rows that ended
 // (codes, and the PCM if the request asked for it). Every request gets the bits of its own batch-1 run.
 // ------------------------------------------------------------------------------------------------
-struct BatReq {
-    q3_request r{}; std::vector<uint32_t> text, instruct, ref_codes, ref_text; std::vector<float> xvec;
-    void own(const q3_request& q, int hidden) {
-        r = q;
-        text.assign(q.text_ids, q.text_ids + (q.text_ids ? q.n_text : 0));
-        instruct.assign(q.instruct_ids, q.instruct_ids + (q.instruct_ids ? q.n_instruct : 0));
-        ref_codes.assign(q.ref_codes, q.ref_codes + (q.ref_codes ? (size_t)q.n_ref * 16 : 0));
-        ref_text.assign(q.ref_text_ids, q.ref_text_ids + (q.ref_text_ids ? q.n_ref_text : 0));
-        if (q.xvector) xvec.assign(q.xvector, q.xvector + hidden);
-        fix();
-    }
-    void fix() {      // pointers into this object's own storage (after a move of the object)
-        r.text_ids = text.empty() ? nullptr : text.data(); r.n_text = (int32_t)text.size();
-        r.instruct_ids = instruct.empty() ? nullptr : instruct.data(); r.n_instruct = (int32_t)instruct.size();
-        r.ref_codes = ref_codes.empty() ? nullptr : ref_codes.data(); r.n_ref = (int32_t)(ref_codes.size() / 16);
-        r.ref_text_ids = ref_text.empty() ? nullptr : ref_text.data(); r.n_ref_text = (int32_t)ref_text.size();
-        r.xvector = xvec.empty() ? nullptr : xvec.data();
-    }
-};
 struct BatTicket {
     BatReq req; int state = Q3_TICKET_QUEUED; int row = -1; bool want_pcm = false;
     std::vector<uint32_t> codes; std::vector<float> pcm; int n_frames = 0;
@@ -2507,6 +2716,7 @@ struct q3_batcher {
     q3_model* m = nullptr; int slots = 0, frame_budget = 0, prompt_budget = 0, chunk_frames = 0;
     q3_session* s = nullptr;
     std::vector<int64_t> owner;                       // ticket running in each row, -1 = free
+    std::vector<long> commit;                         // KvBudget units row r may still come to hold (worst case of its request), 0 = free row
     std::vector<int64_t> queue;                       // FIFO of waiting tickets
     std::unordered_map<int64_t, std::unique_ptr<BatTicket>> t;
     int64_t next_id = 1;
@@ -2518,7 +2728,24 @@ static q3_status session_idle_row(q3_session* s, int b) {
     SeqInfo& q = s->seq[b];
     int ran = s->frames_run - q.start_run; if (ran < 0) ran = 0; if (ran > q.limit) ran = q.limit;
     q.limit = ran;
+    HIPC(hipStreamSynchronize(s->stream));          // no frame in flight while the row's limit and pages change
     HIPC(hipMemcpy(s->limit + b, &q.limit, sizeof(int), hipMemcpyHostToDevice));
+    // A frozen row still runs through every frame (its results are dropped): it reads its keys and rewrites the K/V of its
+    // frozen position, prefill_len + ran. It keeps the ONE page that position lies in and every table entry it can reach points
+    // there (stale keys are as good as any for a row nobody reads); the other pages go back to the pool, and the row takes no
+    // more (kv_reserve_frames skips it) — a finished row must not sit on pages the queue is waiting for.
+    if (s->paged && !q.idle && !s->kv_rows[(size_t)b].empty()) {
+        std::vector<float*>& row = s->kv_rows[(size_t)b];
+        size_t keep = (size_t)(q.prefill_len + ran) / KV_PAGE_POS; if (keep >= row.size()) keep = row.size() - 1;
+        float* kept = row[keep];
+        std::vector<float*> back;
+        for (size_t i = 0; i < row.size(); ++i) if (i != keep) back.push_back(row[i]);
+        if (!back.empty()) (s->kv_in_bf16 ? s->m->kv_pool16 : s->m->kv_pool).give(back);
+        row.assign(1, kept);
+        std::vector<unsigned long long> ent(keep + 1, (unsigned long long)kept);
+        HIPC(hipMemcpy(s->kv_table + (size_t)b * KV_MAX_PAGES, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
+    }
+    q.idle = true;
     s->codes_host_valid = false;
     return Q3_OK;
 }
@@ -2534,7 +2761,7 @@ extern "C" q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget,
     }
     std::unique_ptr<q3_batcher> b(new q3_batcher());
     b->m = m; b->slots = slots; b->frame_budget = frame_budget; b->prompt_budget = prompt_budget;
-    b->owner.assign(slots, -1);
+    b->owner.assign(slots, -1); b->commit.assign(slots, 0);
     *out = b.release();
     return Q3_OK;
 }
@@ -2573,8 +2800,10 @@ static q3_status bat_collect(q3_batcher* b, int row) {
         t.pcm.resize(ns);
     }
     t.state = Q3_TICKET_DONE; t.row = -1;
-    b->owner[row] = -1;
-    return Q3_OK;
+    b->owner[row] = -1; b->commit[row] = 0;
+    // the device freezes a row at its frame limit, not at EOS: idle it now so that it stops advancing — and taking pages — while
+    // the queue is empty or waits for room; its pages but one go back to the pool
+    return session_idle_row(b->s, row);
 }
 
 extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph, int* n_running, int* n_queued, int* n_finished) {
@@ -2589,17 +2818,11 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
         // The idle rows are built from fixed, known-valid values — never from a queued request: a malformed first request must
         // fail alone, at its own q3_session_replace below, not wedge the queue by failing the session every step.
         const q3_request& first = b->t[b->queue.front()]->req.r;
-        static const uint32_t one_tok[1] = {0};
-        q3_request d{};
-        d.mode = Q3_MODE_CUSTOM_VOICE; d.text_ids = one_tok; d.n_text = 1;
-        d.speaker_id = 0; d.language_id = 0;                                       // codec token 0: valid in every vocabulary
-        d.opts.temperature = 0.9; d.opts.top_p = 0.9; d.opts.repetition_penalty = 1.05; d.opts.top_k = 50;      // SynthesisOptions::default (lib.rs:1786-1836)
-        d.opts.eos_token_id = -1; d.opts.min_new_tokens = 2; d.opts.max_length = 1; d.opts.has_seed = 1; d.opts.seed = 0;
         b->chunk_frames = first.opts.chunk_frames >= 1 ? first.opts.chunk_frames : 10;       // the one option a session shares
-        d.opts.chunk_frames = b->chunk_frames;
+        const q3_request d = idle_request(b->chunk_frames);
         std::vector<q3_request> reqs((size_t)b->slots, d);
         q3_session* s = nullptr;
-        q3_status st = q3_session_create_reserved(b->m, reqs.data(), b->slots, b->frame_budget, b->prompt_budget > 16 ? b->prompt_budget : 16, &s);
+        q3_status st = session_create(b->m, reqs.data(), b->slots, b->frame_budget, b->prompt_budget > 16 ? b->prompt_budget : 16, &s);
         if (st == Q3_OK) st = q3_session_prefill(s);
         if (st != Q3_OK) {
             // nothing a request could have caused (the budgets were checked at q3_batcher_create): a device failure. The head
@@ -2614,16 +2837,50 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
         for (int r = 0; r < b->slots; ++r) Q3C(session_idle_row(s, r));
     }
     if (!b->s) { if (n_running) *n_running = 0; if (n_queued) *n_queued = 0; if (n_finished) *n_finished = finished; return Q3_OK; }
+    // Admission under a page limit (q3_model_kv_pool_limit): a request enters a row only if its WORST CASE (prompt + max_length
+    // positions; row_worst_units) fits beside what the running rows may still come to hold and what everything else on the model
+    // holds now — so a page shortage shows up here, as a request that waits in the queue (rows are running: room will come) or
+    // fails on its ticket (it cannot fit even alone), never in the middle of a generation where it would stop every row.
+    auto held_units = [&](int r) -> long { return (long)b->s->kv_rows[(size_t)r].size() * (b->s->kv_in_bf16 ? 1 : 2); };
+    auto admit = [&](const q3_request& rq, long* units_out, bool* wait) -> bool {
+        *wait = false; *units_out = 0;
+        if (!b->s->paged) return true;
+        int S = 0, lim = 0; request_shape(rq, &S, &lim);
+        const long units = row_worst_units(S, lim, b->s->kv_bf16);
+        *units_out = units;
+        long mine = 0, claimed = 0; int running = 0;
+        for (int r = 0; r < b->slots; ++r) {
+            const long h = held_units(r);
+            mine += h;
+            if (b->owner[r] >= 0) { claimed += std::max(b->commit[r], h); running++; } else claimed += h;
+        }
+        std::lock_guard<std::mutex> g(b->m->kv_budget.mu);
+        if (b->m->kv_budget.limit <= 0) return true;
+        const long others = b->m->kv_budget.used - mine;
+        if (others + claimed + units <= b->m->kv_budget.limit) return true;
+        *wait = running > 0;
+        return false;
+    };
     auto fill = [&]() -> q3_status {               // free rows <- waiting requests
         for (int r = 0; r < b->slots && !b->queue.empty(); ++r) {
             if (b->owner[r] >= 0) continue;
             while (!b->queue.empty()) {
-                const int64_t id = b->queue.front(); b->queue.erase(b->queue.begin());
+                const int64_t id = b->queue.front();
                 BatTicket& t = *b->t[id];
+                long units = 0; bool wait = false;
+                if (!admit(t.req.r, &units, &wait)) {
+                    if (wait) return Q3_OK;          // FIFO: the head of the queue waits for running rows to end
+                    b->queue.erase(b->queue.begin());
+                    int S = 0, lim = 0; request_shape(t.req.r, &S, &lim);
+                    bat_fail(t, set_err(Q3_KV_OVERFLOW, "KV page pool exhausted: the request's %d prompt positions + %d frames need %ld page(s) (f32 equivalents), more than the pool's limit leaves",
+                                        S, lim, (units + 1) / 2));
+                    finished++; continue;
+                }
+                b->queue.erase(b->queue.begin());
                 t.req.r.opts.chunk_frames = b->chunk_frames;        // the one option a session shares
                 const q3_status st = q3_session_replace(b->s, r, &t.req.r);
                 if (st != Q3_OK) { bat_fail(t, st); finished++; continue; }     // does not fit: the ticket carries the reason; try the next one
-                t.state = Q3_TICKET_RUNNING; t.row = r; b->owner[r] = id;
+                t.state = Q3_TICKET_RUNNING; t.row = r; b->owner[r] = id; b->commit[r] = units;
                 break;
             }
         }
@@ -2641,7 +2898,21 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
             const int rem = q.limit - (b->s->frames_run - q.start_run);
             if (rem > 0) { busy++; if (rem < piece) piece = rem; }
         }
-        if (busy > 0) { Q3C(q3_session_generate(b->s, piece, use_graph)); left -= piece; }
+        if (busy > 0) {
+            const q3_status gst = q3_session_generate(b->s, piece, use_graph);
+            if (gst == Q3_KV_OVERFLOW && b->s->kv_overflow_row >= 0 && b->owner[b->s->kv_overflow_row] >= 0) {
+                // (only reachable when something outside this batcher took the pages its admission counted on) nothing ran: the
+                // row that needs the page fails alone and is frozen; the others go on
+                const int row = b->s->kv_overflow_row;
+                bat_fail(*b->t[b->owner[row]], gst);
+                b->owner[row] = -1; b->commit[row] = 0;
+                Q3C(session_idle_row(b->s, row));
+                finished++;
+                continue;
+            }
+            Q3C(gst);
+            left -= piece;
+        }
         int collected = 0;
         for (int r = 0; r < b->slots; ++r) {
             if (b->owner[r] < 0) continue;

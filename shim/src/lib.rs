@@ -42,6 +42,7 @@ pub mod ffi {
         pub fn q3_model_set_tensor(m: *mut c_void, name: *const c_char, dtype: i32, data: *const c_void, n: i64) -> i32;
         pub fn q3_model_finalize(m: *mut c_void) -> i32;
         pub fn q3_model_kv_pool_limit(m: *mut c_void, max_pages: i32) -> i32;
+        pub fn q3_model_kv_pool_trim(m: *mut c_void, bytes_freed: *mut usize) -> i32;
         pub fn q3_model_set_codec_planes(m: *mut c_void, planes: i32) -> i32;
         pub fn q3_model_kv_pool_info(m: *mut c_void, page_positions: *mut i32, page_bytes: *mut usize, pages_total: *mut i32, pages_in_use: *mut i32, pages_peak: *mut i32) -> i32;
         pub fn q3_codes_to_tensor(frames: *const u32, n_frames: i32, out: *mut i64);
@@ -255,6 +256,12 @@ impl Qwen3TTS {
     /// bails on overflow (kv_cache.rs:293-300); here a request that needs a page beyond the cap fails with the same error before
     /// anything runs.
     pub fn set_kv_pool_limit(&self, max_pages: i32) -> Result<()> { check(unsafe { q3_model_kv_pool_limit(self.model, max_pages) }) }
+    /// Slabs of the KV page pool none of whose pages is held go back to the device; returns the bytes freed.
+    pub fn kv_pool_trim(&self) -> Result<usize> {
+        let mut n: usize = 0;
+        check(unsafe { q3_model_kv_pool_trim(self.model, &mut n) })?;
+        Ok(n)
+    }
     /// bf16 planes per f32 operand in the vocoder's convs: 3 = exact f32 products (default), 2 = hi + mid only (PCM within
     /// 1e-4 RMS of the CPU path instead of 2.5e-5, the vocoder 30 % faster). Token ids do not depend on it.
     pub fn set_codec_planes(&self, planes: i32) -> Result<()> { check(unsafe { q3_model_set_codec_planes(self.model, planes) }) }

@@ -823,9 +823,10 @@ def test_run_decodes_utterances_side_by_side(pair):
 
 
 @pytest.mark.gpu
-def test_synthesize_batch_groups_by_prefill_shape(pair):
-    """A mixed batch (CustomVoice, voice design with two instruct lengths, x-vector clone, 20 requests > one session's 16)
-    is served group by group and every utterance equals its own batch-1 run."""
+def test_synthesize_batch_mixed_prompt_kinds(pair):
+    """A mixed batch (CustomVoice, voice design with two instruct lengths, x-vector clone: 20 requests, four prefill shapes)
+    is served by ONE session — rows of a shape prefilled together, all rows decoded in one frame graph (round 5: ragged first
+    batch) — and every utterance equals its own batch-1 run."""
     cfg, gm, om = pair
     kinds = ["custom", "design", "clone", "custom", "design"]
     utts = []
@@ -841,8 +842,10 @@ def test_synthesize_batch_groups_by_prefill_shape(pair):
     for i in (0, 1, 6, 12, 19):
         s = gm.session([utts[i]], opts); a1, _ = s.run(); s.close()
         np.testing.assert_array_equal(audio[i].samples, a1[0].samples)
-    with pytest.raises(_lib.Q3Error, match="same prefill length"):
-        gm.session([utts[0], utts[1]], opts)
+    s = gm.session([utts[0], utts[1]], opts)                          # two prefill lengths in one session: accepted since round 5
+    assert s.prefill_len(0)[0] != s.prefill_len(1)[0]
+    a2, _ = s.run(); s.close()
+    np.testing.assert_array_equal(a2[1].samples, audio[1].samples)
 
 
 @pytest.mark.gpu
@@ -868,7 +871,7 @@ def test_ref_codes_without_transcript_are_prepended_at_decode(pair):
 @pytest.mark.gpu
 def test_synthesize_batch_icl_requests_with_different_text_lengths(pair):
     """Two ICL voice-clone requests with the same reference but different text lengths resolve to different max_length
-    caps (max(75, 6 * n_text), lib.rs:913-929): synthesize_batch must serve them in separate sessions, not fail."""
+    caps (max(75, 6 * n_text), lib.rs:913-929): one session, every row ending at its own cap."""
     cfg, gm, om = pair
     rng = np.random.default_rng(5)
     ref = rng.integers(0, 2048, size=(4, 16)).astype(np.uint32); ref[:, 0] = rng.integers(0, 3072, 4)

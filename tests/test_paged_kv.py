@@ -201,3 +201,90 @@ def test_bf16_kv_session_mode(gm):
         s = gm.session([a], o40); s.prefill(); _lib.check(_lib.lib.q3_session_set_kv_dtype(s._h, 1))
     s.close()
     assert gm.kv_pool_info()["pages_in_use"] == 0
+
+
+def test_batcher_under_a_tight_pool_limit_waits_instead_of_wedging():
+    """with a page limit, admission used to be optimistic (prompt + 1 positions). Three 300-frame requests through three
+    rows of a 4-page pool were all admitted at one page each, met the limit together at position 128, and q3_session_generate
+    then returned Q3_KV_OVERFLOW for the whole session on every step — no ticket failed, nothing moved. Now a request enters a
+    row only when its worst case (3 pages) fits beside the running rows' (so they run one after the other here), finished rows
+    are idled at once and give their pages back, and every ticket completes with the codes of its batch-1 run."""
+    cfg = q.tiny()
+    m = q.Qwen3TTS.from_synthetic(cfg, device=0, seed=1234)
+    try:
+        F = 300
+        opts = q.SynthesisOptions(max_length=F, eos_token_id=None, seed=3)
+        utts = [q.Utterance(synthetic_prompt(5 + i, i + 1), q.Speaker.Ryan, q.Language.English, seed=20 + i) for i in range(4)]
+        utts[3].max_length = 40                                  # 1 page: fits beside a running 3-page request
+        want = []
+        for u in utts:
+            s1 = m.session([u], opts); s1.prefill(); s1.generate(F); want.append(s1.codes(0)); s1.close()
+        m.kv_pool_limit(3 + 3)                                   # three idle rows (1 page each) + one 3-page request
+        b = q.Batcher(m, slots=3, frame_budget=F, prompt_budget=32, options=opts)
+        try:
+            tickets = [b.submit(u, want_pcm=False) for u in utts]
+            peak, most_running = 0, 0
+            for _ in range(400):
+                running, queued, _ = b.step(32)
+                peak = max(peak, m.kv_pool_info()["pages_in_use"]); most_running = max(most_running, running)
+                if running == 0 and queued == 0:
+                    break
+            assert [b.poll(t)[0] for t in tickets] == [q.Batcher.DONE] * 4
+            got = [b.fetch(t)[0] for t in tickets]
+        finally:
+            b.close()
+        assert peak <= 6 and m.kv_pool_info()["pages_peak"] <= 6
+        assert most_running <= 2                                 # never two 3-page requests at once
+        for w, g in zip(want, got):
+            np.testing.assert_array_equal(w, g)
+        assert m.kv_pool_info()["pages_in_use"] == 0
+        # a finished row stops taking pages while the queue is empty: one short request, then many idle steps
+        m.kv_pool_limit(0)
+        b = q.Batcher(m, slots=2, frame_budget=F, prompt_budget=32, options=opts)
+        try:
+            u = q.Utterance(synthetic_prompt(5, 1), q.Speaker.Ryan, q.Language.English, seed=20); u.max_length = 200
+            u.options = q.SynthesisOptions(max_length=200, seed=3)            # EOS live: the row ends early or at 200
+            t = b.submit(u, want_pcm=False)
+            for _ in range(20):
+                b.step(32)
+            assert b.poll(t)[0] == q.Batcher.DONE
+            assert m.kv_pool_info()["pages_in_use"] == 2         # two idle rows, one page each — not the finished row's three
+        finally:
+            b.close()
+        assert m.kv_pool_info()["pages_in_use"] == 0
+    finally:
+        m.close()
+
+
+def test_pool_limit_covers_bf16_sessions():
+    """the page limit and the occupancy figures acted on the f32 pool only; a bf16-KV session took its decode pages from
+    a second, unlimited pool. One budget now covers both, in f32-equivalent pages (a bf16 page is half of one)."""
+    cfg = q.tiny()
+    m = q.Qwen3TTS.from_synthetic(cfg, device=0, seed=1234)
+    try:
+        m.kv_pool_limit(2)                                       # = 4 bf16 pages
+        opts = q.SynthesisOptions(max_length=600, eos_token_id=None, seed=3)
+        u = q.Utterance(synthetic_prompt(9, 0), q.Speaker.Ryan, q.Language.English, seed=5)
+        s = m.session([u], opts, kv_bf16=True); s.prefill()      # 1 f32 page -> 1 bf16 page
+        info = m.kv_pool_info()
+        assert info["pages_in_use"] == 1 and info["pages_peak"] == 2, info      # half a page, rounded up; f32 + bf16 page side by side at the conversion
+        s.generate(400)                                          # positions .. 410: 4 bf16 pages = the limit
+        assert m.kv_pool_info()["pages_in_use"] == 2
+        with pytest.raises(_lib.Q3Error, match="KV page pool exhausted") as ei:
+            s.generate(200)                                      # a fifth bf16 page
+        assert ei.value.status == 4 and s.frames(0)[0] == 400
+        s.close()
+        assert m.kv_pool_info()["pages_in_use"] == 0
+        # two f32 pages are the limit for an f32 session too, and a bf16 prompt that needs 2 f32 pages + their 2 bf16 copies does not fit
+        long_u = q.Utterance(synthetic_prompt(9, 0), language=q.Language.German, instruct_ids=synthetic_prompt(200, 50), seed=11)   # 209 positions: 2 pages
+        s = m.session([long_u], opts, kv_bf16=True)
+        with pytest.raises(_lib.Q3Error, match="exhausted"):
+            s.prefill()
+        s.close()
+        assert m.kv_pool_info()["pages_in_use"] == 0
+        freed = m.kv_pool_trim()
+        assert freed > 0 and m.kv_pool_info()["pages_total"] == 0           # nothing held: every slab goes back
+        s = m.session([u], q.SynthesisOptions(max_length=8, eos_token_id=None, seed=3)); s.prefill(); s.generate(8); s.close()      # and the pool grows again on demand
+        assert m.kv_pool_info()["pages_total"] > 0
+    finally:
+        m.close()
