@@ -27,6 +27,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Figures that cannot be taken from inside the run (rocprofv3 kernel tables, PMC passes) come from files committed under
+# profiles/ for THIS round only: an older round's profile is never substituted silently — the field is null instead.
+PROFILE_ROUND = "r5"
 
 
 def committed_rocprof_table(avg_bytes_per_launch, model, batch):
@@ -37,7 +40,7 @@ def committed_rocprof_table(avg_bytes_per_launch, model, batch):
     configuration the table was taken on (1.7B, 8 rows)."""
     if model != "1.7b" or batch != 8:
         return None
-    for name in ("r4_rocprof_kernel_stats_bench_b8.txt",):
+    for name in (f"{PROFILE_ROUND}_rocprof_kernel_stats_bench_b8.txt",):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -186,6 +189,7 @@ def main():
         step_wall.append((time.perf_counter() - ts) * 1000.0)
     torch.cuda.synchronize(dev); dp.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     elapsed = dp.max_over_ranks(elapsed, device=f"cuda:{dev}" if world > 1 else None)
     frames_rank = sum(t.generation_frames for t in timings)
     frames_total = dp.sum_over_ranks(float(frames_rank), device=f"cuda:{dev}" if world > 1 else None)
@@ -199,6 +203,23 @@ def main():
         dist.all_gather(seen, mine)
         rccl = {"world": dist.get_world_size(), "backend": dist.get_backend(), "ranks_seen": [[int(t[0]), int(t[1])] for t in seen],
                 "same_gpu_test_mode": same_gpu}
+        # per-rank view (a straggler or a rank that ran fewer frames is visible from the line alone)
+        mine_f = torch.tensor([float(rank), float(frames_rank), float(elapsed_local)], dtype=torch.float64, device=f"cuda:{dev}" if not same_gpu else "cpu")
+        got = [torch.zeros_like(mine_f) for _ in range(world)]
+        dist.all_gather(got, mine_f)
+        rccl["per_rank"] = [{"rank": int(t[0]), "frames": int(t[1]), "seconds": float(t[2]), "frames_per_s": float(t[1]) / float(t[2])} for t in got]
+        # A multi-GPU line is only valid when it really ran one rank per device over RCCL: every rank checks the same gathered
+        # list, so all of them leave together (no rank is left waiting in a collective).
+        if not same_gpu:
+            devices = {d for _, d in rccl["ranks_seen"]}
+            ranks = {r for r, _ in rccl["ranks_seen"]}
+            problem = None
+            if rccl["backend"] != "nccl": problem = f"backend is {rccl['backend']!r}, not 'nccl' (= RCCL on ROCm)"
+            elif rccl["world"] != args.gpus or len(ranks) != args.gpus: problem = f"{len(ranks)} distinct rank(s) of world {rccl['world']} for --gpus {args.gpus}"
+            elif len(devices) != args.gpus: problem = f"{len(devices)} distinct device(s) for {args.gpus} ranks: {sorted(devices)}"
+            if problem:
+                dist.destroy_process_group()
+                raise SystemExit(f"bench.py: invalid multi-GPU run — {problem}; rccl = {json.dumps(rccl)}")
 
     def finish():
         # every rank leaves through the same door: ranks != 0 wait here until rank 0 has printed its line (its roofline /
@@ -259,9 +280,9 @@ def main():
     # HBM traffic per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_collect.sh) — PMC counters cannot be read from inside the run
     traffic = None; pmc_path = None
-    for cand in (f"r4_pmc_gemv_M{min(B, 16)}.json", f"r3_pmc_gemv_M{min(B, 16)}.json", f"r2_pmc_gemv_M{min(B, 16)}.json", f"r1_pmc_gemv_M{min(B, 16)}.json"):
-        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
-            pmc_path = os.path.join(ROOT, "profiles", cand); break
+    cand = f"{PROFILE_ROUND}_pmc_gemv_M{min(B, 16)}.json"          # this round's profile or nothing (traffic: null)
+    if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+        pmc_path = os.path.join(ROOT, "profiles", cand)
     if args.model == "1.7b" and pmc_path:
         pmc = json.load(open(pmc_path)).get("shapes", {})
         by_dims = {(v["N"], v["K"], v["epi"]): v["fetch_bytes_corrected"] + v["write_bytes"] for v in pmc.values() if "N" in v}
@@ -498,7 +519,9 @@ def main():
                    "pcm_copy_out": True},      # every utterance's samples are copied to (pinned) host memory inside the timed step
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,
-                                                        "gbps": (bcast_bytes / bcast_s / 1e9) if bcast_s > 0 else None},
+                                                        "gbps": (bcast_bytes / bcast_s / 1e9) if bcast_s > 0 else None,
+                                                        "expected": "one RCCL broadcast of the 4.4 GB arena from rank 0: ~30 ms per-link bound on xGMI (~150 GB/s), "
+                                                                    "more on the first call (communicator set-up); steady state has no collective (DESIGN 6)"},
         "roofline": roofline, "cpu_baseline": cpu, "other_batches": wide, "other_configs": others, "eos_mix": eos_mix, "rccl": rccl,
     }
     print(json.dumps(out), flush=True)

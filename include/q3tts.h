@@ -352,8 +352,10 @@ q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int
 /* raw stream handle (hipStream_t) the session launches on */
 q3_status q3_session_stream(q3_session* s, void** stream);
 /* How this session's captured frame is replayed: *path = 0 nothing captured yet / eager launches, 1 = hipGraphLaunch, 2 = the
- * library's own AQL queue with HIP's packet headers (agent-scope fences at every kernel boundary), 3 = own AQL queue without
- * boundary fences (the kernels exchange activations write-through); *nodes = dispatch packets per frame (0 on paths 0 / 1).
+ * library's own AQL queue with HIP's packet headers (agent-scope fences at every kernel boundary; bit-identical to path 1), 3 =
+ * own AQL queue without boundary fences — a measurement probe: the product kernels move activations with plain loads and
+ * stores, so path 3 gives WRONG results and is reachable only with Q3_AQL=2 plus the explicit opt-in Q3_AQL_UNSAFE=1 (a warning
+ * is printed); *nodes = dispatch packets per frame (0 on paths 0 / 1).
  * The reference replays nothing — every op is an eager candle launch (src/lib.rs:580-652); new here (environment: Q3_AQL). */
 q3_status q3_session_submit_info(q3_session* s, int* path, int* nodes);
 /* Algorithmic HBM bytes of one frame for this session's batch at KV length L */

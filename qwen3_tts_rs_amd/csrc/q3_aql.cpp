@@ -4,9 +4,14 @@
 // packets whose headers HIP chooses: barrier bit set, agent-scope acquire and release fences on every packet. The fences are
 // cache maintenance at every kernel boundary (L2 write-back of the producer XCD, L1 / non-local L2 invalidation for the
 // consumer) and cost ~0.25 us per dependent node on MI355X (tools/hw/aql_probe.hip, profiles/r4_aql_chain_probe.txt: 2.83 ->
-// 2.48 us per 2 MB stage) — time the frame does not need to spend where producer and consumer already exchange their few KB of
-// activations write-through (sc1 stores) and L1-bypassing (sc1 loads). HIP offers no way to say so, so the engine converts its
-// captured frame graph into a PACKET PROGRAM once and submits the packets itself:
+// 2.48 us per 2 MB stage). A boundary could do without them only if producer and consumer exchanged their activations
+// write-through (sc1 stores) and L1-bypassing (sc1 loads) — THE PRODUCT KERNELS DO NOT: they use plain loads and stores (the
+// sc1 conversion was built for one kernel family, measured slower than what the fence returns, and rejected: DESIGN 4.4a),
+// so packets WITHOUT fences give wrong codes. This path therefore exists to (1) price the boundary — with HIP's own header
+// policy it is bit-identical to and as fast as hipGraphLaunch, which shows that nothing in the frame time is runtime
+// overhead — and (2) carry the fence-free probes, which need an explicit unsafe opt-in (Q3_AQL_UNSAFE=1, q3_engine.hip).
+// HIP offers no way to choose packet headers, so the engine converts its captured frame graph into a PACKET PROGRAM once
+// and submits the packets itself:
 //   * the kernels are the very same code objects: the .hip_fatbin section of this library is unbundled and loaded through the
 //     HSA loader (hsa_executable_*), kernel descriptors are looked up by the names HIP reports for the graph's kernel nodes;
 //   * kernel-argument blocks are packed from the nodes' parameter pointers using the argument table of the code object's
@@ -299,6 +304,7 @@ struct AqlProgram {
     std::vector<hsa_kernel_dispatch_packet_t> pk;        // templates (header / setup filled, completion signal empty)
     void* kernargs = nullptr;                            // device memory, one block per node
     hsa_signal_t done{}; bool pending = false;
+    bool dead = false;      // a submission timed out: the ring may hold a partial burst without a completion signal — never submit or wait again
 };
 
 int aql_program_nodes(const AqlProgram* p) { return p ? (int)p->pk.size() : 0; }
@@ -306,8 +312,9 @@ int aql_program_nodes(const AqlProgram* p) { return p ? (int)p->pk.size() : 0; }
 void aql_program_destroy(AqlProgram* p) {
     if (!p) return;
     std::string w;
-    if (p->pending) aql_wait(p, &w);
-    if (p->kernargs) (void)hipFree(p->kernargs);
+    if (p->pending && !p->dead) aql_wait(p, &w);         // (a dead program's signal may never fire: do not block on it)
+    if (p->kernargs && !p->dead) (void)hipFree(p->kernargs);      // dead: packets still in the ring may point at the blocks — leak them
+    if (p->dead) p->kernargs = nullptr;
     if (p->done.handle) hsa.hsa_signal_destroy(p->done);
     delete p;
 }
@@ -395,9 +402,11 @@ AqlProgram* aql_program_create(hipGraph_t graph, int device, const AqlPolicy& po
     return p.release();
 }
 
-bool aql_submit(AqlProgram* p, int frames, std::string* why) {
+bool aql_submit(AqlProgram* p, int frames, std::string* why, int* submitted) {
     std::string dummy; if (!why) why = &dummy;
+    if (submitted) *submitted = 0;
     if (!p || frames <= 0) { *why = "aql_submit: bad argument"; return false; }
+    if (p->dead) { *why = "aql_submit: this program's queue stopped draining earlier"; return false; }
     if (p->pending && !aql_wait(p, why)) return false;
     Runtime* rt = p->rt;
     std::lock_guard<std::mutex> lk(rt->mu);
@@ -410,7 +419,15 @@ bool aql_submit(AqlProgram* p, int frames, std::string* why) {
     for (int f = 0; f < frames; ++f) {
         // room for one frame (the ring holds at least two)
         while (rt->write_idx + n - hsa.hsa_queue_load_read_index_scacquire(q) > q->size) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { *why = "aql_submit: the packet ring did not drain within 120 s"; return false; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                // f whole frames are in the ring and none of them carries the completion signal (only the burst's last packet
+                // would have): the program is dead — nothing waits on its signal any more, the caller accounts for the f frames
+                // that were handed to the device and leaves this path
+                *why = "aql_submit: the packet ring did not drain within 120 s";
+                p->dead = true; p->pending = false;
+                if (submitted) *submitted = f;
+                return false;
+            }
             std::this_thread::yield();
         }
         for (size_t i = 0; i < n; ++i) {
@@ -427,17 +444,19 @@ bool aql_submit(AqlProgram* p, int frames, std::string* why) {
         hsa.hsa_queue_store_write_index_relaxed(q, rt->write_idx);
         hsa.hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(rt->write_idx - 1));
     }
+    if (submitted) *submitted = frames;
     return true;
 }
 
 bool aql_wait(AqlProgram* p, std::string* why) {
     std::string dummy; if (!why) why = &dummy;
     if (!p || !p->pending) return true;
+    if (p->dead) { *why = "aql_wait: dead program"; return false; }
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hsa_signal_value_t v = hsa.hsa_signal_wait_scacquire(p->done, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
         if (v < 1) break;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { *why = "aql_wait: no completion within 300 s"; return false; }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { *why = "aql_wait: no completion within 300 s"; p->dead = true; p->pending = false; return false; }
     }
     p->pending = false;
     return true;

@@ -2542,19 +2542,33 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
     if (use_graph && !s->aql && !s->aql_tried) {
         s->aql_tried = true;
         const char* e = getenv("Q3_AQL");
-        const int mode = e ? atoi(e) : 0;
+        int mode = e ? atoi(e) : 0;
+        // Packets without boundary fences give WRONG codes with the product kernels (plain loads and stores): mode 2
+        // and the fence halves are probes and need an explicit opt-in, so that a stray environment variable cannot silently
+        // corrupt a server's output.
+        const bool unsafe_ok = getenv("Q3_AQL_UNSAFE") && atoi(getenv("Q3_AQL_UNSAFE")) == 1;
+        const bool wants_unsafe = mode == 2 || getenv("Q3_AQL_ACQ") || getenv("Q3_AQL_REL");
+        if (wants_unsafe && !unsafe_ok) {
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true)) fprintf(stderr, "[q3] Q3_AQL=2 / Q3_AQL_ACQ / Q3_AQL_REL drop kernel-boundary fences and produce wrong results with the product kernels; "
+                                                      "ignored without Q3_AQL_UNSAFE=1 (frames stay on %s)\n", mode == 2 ? "hipGraphLaunch" : "HIP's fence policy");
+            if (mode == 2) mode = 0;
+        }
         if (mode > 0) {
             q3::AqlPolicy pol; pol.fence = mode == 2 ? 0 : 1;
             pol.acquire = pol.release = pol.fence;
-            if (const char* a = getenv("Q3_AQL_ACQ")) pol.acquire = atoi(a);        // probes: the two fences of a boundary priced separately
-            if (const char* r = getenv("Q3_AQL_REL")) pol.release = atoi(r);
+            if (unsafe_ok) {
+                if (const char* a = getenv("Q3_AQL_ACQ")) pol.acquire = atoi(a);        // probes: the two fences of a boundary priced separately
+                if (const char* r = getenv("Q3_AQL_REL")) pol.release = atoi(r);
+                fprintf(stderr, "[q3] WARNING: Q3_AQL_UNSAFE=1: frames are submitted with acquire=%d release=%d — results are NOT valid with the product kernels\n", pol.acquire, pol.release);
+            }
             std::string why;
             s->aql = q3::aql_program_create(s->graph, s->m->device, pol, &why);
             if (s->aql) s->aql_mode = mode == 2 ? 2 : 1;
             else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
         }
     }
-    const bool on_aql = use_graph && s->aql;
+    bool on_aql = use_graph && s->aql;
     if (on_aql) HIPC(hipStreamSynchronize(s->stream));     // the queue is not ordered with the HIP stream: prefill / swaps must have landed
     bool eos_on = false;
     for (const auto& q : s->seq) eos_on = eos_on || q.req.opts.eos_token_id >= 0;
@@ -2562,9 +2576,16 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
     while (todo > 0) {
         const int burst = eos_on ? (todo < check_every ? todo : check_every) : todo;
         if (on_aql) {
-            std::string why;
-            if (!q3::aql_submit(s->aql, burst, &why) || !q3::aql_wait(s->aql, &why)) return set_err(Q3_HIP_ERROR, "AQL frame submission: %s", why.c_str());
-            s->frames_run += burst;
+            std::string why; int handed = 0;
+            const bool ok = q3::aql_submit(s->aql, burst, &why, &handed) && q3::aql_wait(s->aql, &why);
+            s->frames_run += handed;                       // frames the device was given, also when the submission failed half way
+            if (!ok) {
+                // the own queue is unusable from here on (q3_aql.cpp marks the program dead): later calls replay through
+                // hipGraphLaunch; this call reports the failure with frames_run in step with what was submitted
+                s->aql_mode = 0; q3::aql_program_destroy(s->aql); s->aql = nullptr;
+                s->codes_host_valid = false;
+                return set_err(Q3_HIP_ERROR, "AQL frame submission: %s", why.c_str());
+            }
         } else
         for (int i = 0; i < burst; ++i) {
             if (use_graph) HIPC(hipGraphLaunch(s->graph_exec, s->stream));

@@ -120,6 +120,50 @@ __device__ __forceinline__ Split3 gemv_prep(bool valid, const float4& x0, const 
     return split3(xv);
 }
 
+// HALF form of the above (M <= 8): lane (m, kg) holds only ITS four floats of the k-group — elements 0..3 in lanes m < 8,
+// elements 4..7 in lanes m + 8 — and splits just those: half the VALU work of the whole-slot form, which every one of the
+// 256 workgroups repeats on the same x on the critical path of the launch (the frame's timeline prices the split at
+// 0.4-0.7 us per node). The finished bf16 pairs, not the floats, then cross between lanes m and m + 8 (DPP row_ror:8):
+// six moves per k-step instead of eight, and a lane's B operand is [own pair 0, own pair 1, partner pair 0, partner pair 1]
+// — element order 0..7 for the columns in use (m < 8); lanes m >= 8 end up with their halves swapped, columns nobody reads.
+// Σx² is accumulated over the lane's own four elements; the caller adds the partner's sum once at the end (gemv_ss_half).
+__device__ __forceinline__ uint32_t ror8u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, false); }
+template <bool RMS>
+__device__ __forceinline__ Split3 gemv_prep_half(bool valid, const float4& x, const float4& n, float& ss) {
+#if Q3_ABLATE == 2
+    float xv[4] = {1.f, 2.f, 3.f, 4.f};
+    ss += valid ? 1.f : 0.f;
+#else
+    float xv[4] = {x.x, x.y, x.z, x.w};
+#endif
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = valid ? xv[e] : 0.0f;
+    if constexpr (RMS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss = fmaf(xv[e], xv[e], ss);
+        xv[0] *= n.x; xv[1] *= n.y; xv[2] *= n.z; xv[3] *= n.w;
+    }
+    Split3 s;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a = xv[2 * i], b = xv[2 * i + 1];
+        const uint32_t h = cvt_pk_bf16(a, b);
+#if Q3_ABLATE == 1 || Q3_ABLATE == 2
+        s.hi[i] = h; s.mid[i] = 0; s.lo[i] = 0;
+#else
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const uint32_t m = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        s.hi[i] = h; s.mid[i] = m; s.lo[i] = cvt_pk_bf16(sa, sb);
+#endif
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { s.hi[2 + i] = ror8u(s.hi[i]); s.mid[2 + i] = ror8u(s.mid[i]); s.lo[2 + i] = ror8u(s.lo[i]); }
+    return s;
+}
+// Σx² of a column = the sums of its two half-slot lanes (m and m + 8)
+__device__ __forceinline__ float gemv_ss_half(float ss) { return ss + __builtin_bit_cast(float, ror8u(__builtin_bit_cast(uint32_t, ss))); }
+
 // NWAVES waves split K; weights for up to G k-steps are requested up front (G KiB per wave in flight per
 // matrix) before any of them is consumed, so a wave's whole slice is usually one HBM round trip.
 //
@@ -207,8 +251,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
             for (int i = 0; i < G; ++i) {
                 const int s = sb + i;      // s >= s1 (ragged last group): zero operand, its MFMAs add nothing — no branch,
                 const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;   // so the group stays one scheduling region
-                if constexpr (HALF) { g.xb[i] = ror8(g.xa[i]); if constexpr (RMS) g.nb[i] = ror8(g.na[i]); }
-                sp[i] = gemv_prep<RMS>(valid, g.xa[i], g.xb[i], RMS ? g.na[i] : g.xa[i], RMS ? g.nb[i] : g.xb[i], ss);
+                if constexpr (HALF) sp[i] = gemv_prep_half<RMS>(valid, g.xa[i], RMS ? g.na[i] : g.xa[i], ss);
+                else sp[i] = gemv_prep<RMS>(valid, g.xa[i], g.xb[i], RMS ? g.na[i] : g.xa[i], RMS ? g.nb[i] : g.xb[i], ss);
             }
             __builtin_amdgcn_sched_barrier(0);      // all splits done before the first wait on a weight tile
             Q3T(1);
@@ -245,8 +289,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int s = sb + i;
-                if constexpr (HALF) { xb[i] = ror8(xa[i]); if constexpr (RMS) nb[i] = ror8(na[i]); }   // outside the branch: DPP reads all lanes
-                if (s < s1) {
+                if constexpr (HALF) {      // the split stays outside the branch: its DPP moves read all lanes
+                    const Split3 sp = gemv_prep_half<RMS>(act && s < s1 && (s * 32 + kg * 8) < a.K, xa[i], RMS ? na[i] : xa[i], ss);
+                    if (s < s1) {
+                        acc0 = mfma3(wa[i], sp, acc0);
+                        if constexpr (NW == 2) acc1 = mfma3(wb[i], sp, acc1);
+                    }
+                } else if (s < s1) {
                     const bool valid = act && (s * 32 + kg * 8) < a.K;
                     const Split3 sp = gemv_prep<RMS>(valid, xa[i], xb[i], RMS ? na[i] : xa[i], RMS ? nb[i] : xb[i], ss);
                     acc0 = mfma3(wa[i], sp, acc0);
@@ -269,7 +318,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
     // partial tile → LDS, layout [col m][row]: lane (m, kg) owns rows kg*4 .. kg*4+3
     *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = acc0;
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = acc1;
-    if constexpr (RMS) ssq[wave][kg][m] = ss;
+    if constexpr (RMS) ssq[wave][kg][m] = HALF ? gemv_ss_half(ss) : ss;
     Q3T(6);
     __syncthreads();
     Q3T(5);
@@ -373,8 +422,8 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) {
             const int s = sb + i;
             const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;
-            if constexpr (HALF) g.xb[i] = ror8(g.xa[i]);
-            sp[i] = gemv_prep<false>(valid, g.xa[i], g.xb[i], g.xa[i], g.xb[i], ss);
+            if constexpr (HALF) sp[i] = gemv_prep_half<false>(valid, g.xa[i], g.xa[i], ss);
+            else sp[i] = gemv_prep<false>(valid, g.xa[i], g.xb[i], g.xa[i], g.xb[i], ss);
         }
         __builtin_amdgcn_sched_barrier(0);
         Q3T(1);
@@ -678,8 +727,8 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const bool valid = act && (sb + i) < s1;
-            if constexpr (HALF) { xb[i] = ror8(xa[i]); nb[i] = ror8(na[i]); }
-            sp[i] = gemv_prep<true>(valid, xa[i], xb[i], na[i], nb[i], ss);
+            if constexpr (HALF) sp[i] = gemv_prep_half<true>(valid, xa[i], na[i], ss);
+            else sp[i] = gemv_prep<true>(valid, xa[i], xb[i], na[i], nb[i], ss);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -693,7 +742,7 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
     *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = aGH;
     *reinterpret_cast<f32x4_t*>(&red[wave][2][m * 16 + kg * 4]) = aUF;
     *reinterpret_cast<f32x4_t*>(&red[wave][3][m * 16 + kg * 4]) = aUH;
-    ssq[wave][kg][m] = ss;
+    ssq[wave][kg][m] = HALF ? gemv_ss_half(ss) : ss;
     __syncthreads();
     // 24 rows x 16 columns: thread (col, r24); rows 0-15 = the full tile, 16-23 = this workgroup's half of the shared tile
     if (tid < 384) {

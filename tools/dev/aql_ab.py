@@ -20,6 +20,7 @@ model = q.Qwen3TTS.from_synthetic(cfg, device=0, seed=synth.DEFAULT_SEED)
 utts = [q.Utterance(synthetic_prompt(512, i), q.Speaker.Ryan, q.Language.English, seed=42 + i) for i in range(a.batch)]
 opts = q.SynthesisOptions(max_length=a.frames, eos_token_id=None, seed=42)
 os.environ["Q3_AQL_VERBOSE"] = "1"
+os.environ["Q3_AQL_UNSAFE"] = "1"      # this tool IS the probe: fence-free modes are measured on purpose (their codes are expected to differ)
 ref = None
 for spec in a.modes.split(","):
     parts = spec.split(":"); mode = int(parts[0])
