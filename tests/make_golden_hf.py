@@ -8,6 +8,9 @@ the same published blocks:
                   Code2WavTransformerModel — the 12 Hz codec decoder of Qwen3-TTS is this architecture)
   quantiser D1    transformers.models.mimi.modeling_mimi  (MimiEuclideanCodebook: embed_sum / clamp(cluster_usage))
   talker A4/A2    ...TalkerCodePredictorDecoderLayer (Qwen3 attention: q/k RMSNorm, GQA, rotate-half RoPE, SwiGLU MLP)
+  code predictor  ...Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration (round 5): the 15-pass LOOP itself (A3) — which
+      A3 / A10    embedding table and which lm_head each pass uses, the two-token first pass, cache positions — driven by the module's
+                  own forward() with its own KV cache, greedy (`python tests/make_golden_hf.py cp_loop` -> hf_cp_loop.npz)
 
 The script loads the repo's seeded synthetic checkpoint (tiny config) into those modules, runs the chain stage by stage
 and writes tests/golden/hf_crosscheck.npz; tests/test_oracle_vs_hf.py then holds the C oracle to it.
@@ -191,6 +194,85 @@ def main():
     mimi_fixture()
 
 
+def cp_loop_fixture():
+    """A3 (code_predictor.rs:320-416) against upstream's own code-predictor module. The Qwen3-Omni talker's code predictor IS
+    this loop: forward(inputs_embeds = [last_hidden, layer-0 embed]) is the two-token first pass scored by lm_head[0]; every
+    later pass embeds the previous code with codec_embedding[generation_steps - 1], runs the layers on the module's own KV
+    cache at the next position, and scores with lm_head[generation_steps] (modeling_qwen3_omni_moe.py, forward()).
+    Differences from /root/reference handled here, explicitly:
+      * Qwen3-TTS 1.7B feeds the code predictor through `small_to_mtp_projection` (Linear 2048 -> 1024 + bias,
+        code_predictor.rs:337-345, 386-396); Qwen3-Omni has no such layer. The fixture applies it OUTSIDE the module: the two
+        prefill rows are projected with F.linear, and the 15 embedding tables handed to the module are the reference's tables
+        with every row projected (a gather followed by a Linear == a gather from the projected table, bit for bit in f32).
+      * upstream SAMPLES the sub-talker codes (docs/QWEN3_TTS_ARCHITECTURE.md:308-317); the reference takes the argmax
+        (code_predictor.rs:374-375, 407-408). The loop below is greedy — only the choice rule differs, not the data flow.
+    Written for two configurations: the tiny one and one with the production layer count (5) and a 2-way GQA."""
+    import dataclasses
+    import oracle as O
+    from common import oracle_model
+    res = {}
+    cases = {"tiny": q.tiny(), "mid": dataclasses.replace(q.tiny(), hidden=128, inter=256, n_heads=2, n_kv_heads=1, cp_hidden=64, cp_inter=192, cp_layers=5, cp_heads=4, cp_kv_heads=2)}
+    for tag, cfg in cases.items():
+        W = checkpoint(cfg, SEED)
+        ccfg = Qwen3OmniMoeTalkerCodePredictorConfig(vocab_size=cfg.cp_vocab, hidden_size=cfg.cp_hidden, intermediate_size=cfg.cp_inter, num_hidden_layers=cfg.cp_layers,
+                                                     num_attention_heads=cfg.cp_heads, num_key_value_heads=cfg.cp_kv_heads, head_dim=cfg.head_dim, hidden_act="silu",
+                                                     rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, attention_bias=False, attention_dropout=0.0,
+                                                     sliding_window=None, max_position_embeddings=64, num_code_groups=cfg.n_groups, use_cache=True)
+        ccfg._attn_implementation = "eager"
+        cp = M.Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration(ccfg).eval()
+        sd = cp.state_dict(); got = 0
+        pw = W["talker.code_predictor.small_to_mtp_projection.weight"].reshape(cfg.cp_hidden, cfg.hidden)
+        pb = W["talker.code_predictor.small_to_mtp_projection.bias"]
+        for k, v in sd.items():
+            if k.startswith("model.layers.") or k == "model.norm.weight":
+                name = "talker.code_predictor." + k
+                sd[k] = W[name].reshape(v.shape).clone(); got += 1
+            elif k.startswith("lm_head."):
+                sd[k] = W["talker.code_predictor." + k].reshape(v.shape).clone(); got += 1
+            elif k.startswith("model.codec_embedding."):
+                g = int(k.split(".")[2])
+                tab = W[f"talker.code_predictor.model.codec_embedding.{g}.weight"].reshape(cfg.cp_vocab, cfg.hidden)
+                sd[k] = F.linear(tab, pw, pb).clone(); got += 1            # every row through small_to_mtp_projection
+            else:
+                raise SystemExit(f"unexpected parameter {k}")
+        assert got == len(sd), (got, len(sd))
+        cp.load_state_dict(sd)
+        rng = np.random.default_rng(31 + len(tag))
+        B = 3
+        last_hidden = rng.standard_normal((B, cfg.hidden)).astype(np.float32)
+        sem_tok = rng.integers(0, 2048, size=B)
+        sem_embed = W["talker.model.codec_embedding.weight"].reshape(cfg.codec_vocab, cfg.hidden)[sem_tok].numpy()
+        ids = np.zeros((B, 15), np.int64); logits = np.zeros((B, 15, cfg.cp_vocab), np.float32)
+        for b in range(B):
+            x = F.linear(torch.from_numpy(np.stack([last_hidden[b], sem_embed[b]]))[None], pw, pb)       # [1, 2, cp_hidden]
+            o = cp(inputs_embeds=x, use_cache=True)
+            assert o.generation_steps == 1
+            lg = o.logits[0, -1]; tok = int(lg.argmax()); ids[b, 0] = tok; logits[b, 0] = lg.numpy()
+            past = o.past_key_values; step = o.generation_steps
+            for g in range(1, 15):
+                o = cp(input_ids=torch.tensor([[tok]]), past_key_values=past, use_cache=True, generation_steps=step)
+                lg = o.logits[0, -1]; tok = int(lg.argmax()); ids[b, g] = tok; logits[b, g] = lg.numpy()
+                past = o.past_key_values; step = o.generation_steps
+            assert step == 15
+        # the same inputs through the C oracle's q3o_session_cp_generate are compared in tests/test_oracle_vs_hf.py; here only a
+        # sanity print so that a broken fixture is noticed when it is made
+        om = oracle_model(cfg, seed=SEED, which=1)
+        osess = O.OracleSession(om, q.Utterance(synthetic_prompt(5, 1), q.Speaker.Ryan, q.Language.English, seed=1), q.SynthesisOptions(max_length=2, seed=1))
+        agree = 0
+        for b in range(B):
+            oc, ol = osess.cp_generate(last_hidden[b], sem_embed[b])
+            agree += int((np.asarray(oc) == ids[b]).all())
+            print(f"[cp_loop {tag}] row {b}: ids equal {bool((np.asarray(oc) == ids[b]).all())}, max |logit diff| {np.abs(ol - logits[b]).max():.2e}")
+        osess.close(); om.close()
+        st = np.sort(logits.astype(np.float64), axis=2)
+        res.update({f"{tag}_last_hidden": last_hidden, f"{tag}_sem_embed": sem_embed, f"{tag}_ids": ids.astype(np.uint32), f"{tag}_logits": logits,
+                    f"{tag}_top2_margin": (st[..., -1] - st[..., -2]).astype(np.float32),
+                    f"{tag}_cfg": np.array([cfg.hidden, cfg.inter, cfg.n_heads, cfg.n_kv_heads, cfg.cp_hidden, cfg.cp_inter, cfg.cp_layers, cfg.cp_heads, cfg.cp_kv_heads], np.int32)})
+    path = os.path.join(os.path.dirname(OUT), "hf_cp_loop.npz")
+    np.savez_compressed(path, **res)
+    print("wrote", path, {k: v.shape for k, v in res.items()})
+
+
 def test_clip(n, seed):
     """deterministic speech-like test signal in [-0.6, 0.6]"""
     t = np.arange(n) / 24000.0
@@ -286,6 +368,8 @@ def sampling_fixture():
 if __name__ == "__main__":
     if "mimi" in sys.argv[1:]:
         mimi_fixture()
+    elif "cp_loop" in sys.argv[1:]:
+        cp_loop_fixture()
     elif "sampling" in sys.argv[1:]:
         sampling_fixture()
     else:

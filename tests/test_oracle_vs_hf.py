@@ -72,6 +72,35 @@ def test_talker_layers_match_hf_qwen3_decoder_layer():
     s.close(); om.close()
 
 
+def test_code_predictor_loop_matches_hf_code_predictor_module():
+    """A3 (code_predictor.rs:320-416): the 15-pass loop of the oracle — q3o_session_cp_generate: the two-token first pass, which
+    embedding table and which lm_head every later pass uses, the cache position of each pass — against Hugging Face's own
+    Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration driven greedily on the same seeded weights (VERDICT r4 item 3:
+    the loop was only ever compared with tests/np_reference.py, written by the same author). Two configurations (tiny; five
+    layers with 2-way GQA), three rows each: all 15 ids equal wherever upstream's own top-2 margin is not a near-tie, logits
+    of every pass within 5e-5. The two documented differences (small_to_mtp_projection applied outside the module; upstream
+    samples where the reference takes the argmax) are handled in make_golden_hf.py::cp_loop_fixture."""
+    import dataclasses
+    fx = np.load(os.path.join(os.path.dirname(FX), "hf_cp_loop.npz"))
+    for tag in ("tiny", "mid"):
+        c = [int(x) for x in fx[f"{tag}_cfg"]]
+        cfg = dataclasses.replace(q.tiny(), hidden=c[0], inter=c[1], n_heads=c[2], n_kv_heads=c[3], cp_hidden=c[4], cp_inter=c[5], cp_layers=c[6], cp_heads=c[7], cp_kv_heads=c[8])
+        om = oracle_model(cfg, seed=SEED, which=1)
+        s = O.OracleSession(om, q.Utterance(synthetic_prompt(5, 1), q.Speaker.Ryan, q.Language.English, seed=1), q.SynthesisOptions(max_length=2, seed=1))
+        for b in range(fx[f"{tag}_ids"].shape[0]):
+            codes, logits = s.cp_generate(fx[f"{tag}_last_hidden"][b], fx[f"{tag}_sem_embed"][b])
+            want = fx[f"{tag}_ids"][b]; marg = fx[f"{tag}_top2_margin"][b]
+            same = np.asarray(codes) == want
+            first_bad = int(np.argmin(same)) if not same.all() else 15
+            if first_bad < 15:          # a different greedy code changes every later pass: only an upstream near-tie may cause it
+                assert marg[first_bad] < 1e-4, (tag, b, first_bad, float(marg[first_bad]))
+            for g in range(min(first_bad + 1, 15)):
+                e = float(np.abs(logits[g] - fx[f"{tag}_logits"][b, g]).max())
+                assert e <= 5e-5 * max(1.0, float(np.abs(fx[f"{tag}_logits"][b, g]).max())), (tag, b, g, e)
+            assert first_bad >= 8, (tag, b, first_bad)             # the fixtures hold no early near-tie: most of the loop is always compared
+        s.close(); om.close()
+
+
 def _speech_oracle(scfg):
     from qwen3_tts_rs_amd.speech_encoder import SpeechEncoder, synthetic_speech_checkpoint
     enc = SpeechEncoder(scfg, device=-1)              # manifest-only handle: names / sizes (no GPU)
