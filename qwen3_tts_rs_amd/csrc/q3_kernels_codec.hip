@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
     constexpr int K = 7, T_M = 4, NT = 64 * NW, C = 32 * NW, T_WG = 128;
     constexpr int XPB = 80, NOCT = 4;                             // x staging: 32 channels per stage (as k_conv_bf16x3)
     constexpr int XP2 = C * 2 + 16;                               // mid rows: all C channels of a column, odd number of 16-byte slots
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // max(x staging [3][W][80], mid [3][64][XP2])
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // max(x staging [3][W][80], mid [3][32][XP2])
     __shared__ float s_prm[6][C];                                 // b1, mid_a, mid_ib, b2, post_a, post_ib
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -735,27 +735,30 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
         for (int pl = 0; pl < NP; ++pl)
             A[pl] = __builtin_bit_cast(cu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (tile * 3 + pl) * 1024, 0));
     };
-    constexpr unsigned plane2 = 64u * XP2;
+    // One column tile (32 columns) at a time (round 5). With both tiles of a 64-column half in flight — two accumulator tiles,
+    // their 32 residual values, six B fragments and the ring of weight fragments beside the other half's conv7 accumulators —
+    // the kernel wanted 228 VGPRs and ran at three waves per SIMD only by spilling 36 of them in this phase; a tile at a time
+    // needs 142, no spill. The parked tile is then 20 KB instead of 40, so the workgroup's LDS is the x staging's (32-44 KB)
+    // and FOUR workgroups fit a CU for the dilation-1 and -3 units: twelve waves, three on every SIMD, where three workgroups
+    // of three waves left the SIMDs at 3 / 2 / 2 / 2. The 1x1 weight fragments are fetched once per tile instead of once per
+    // pair (18 KB per wave, L2-resident). Per output element the sequence of products and sums is unchanged: same bits.
+    constexpr unsigned plane2 = 32u * XP2;
     const unsigned bfrag2 = (unsigned)(li * XP2 + lk * 16);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int tq = 0; tq < T_M; ++tq) {
         cu32x4_t A2[3][NP];
         load_A2(A2[0], 0); load_A2(A2[1], 1);                       // in flight across the barriers and the activation below
-        // the residual of this half: 32 values per lane, requested before anything waits (one batch, see the PRE note above)
-        float rs[2][16];
+        float rs[16];                                               // the residual of this tile, requested before anything waits
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int o = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-                const int t = t0 + half * 64 + tm * 32 + li;
-                rs[tm][reg] = t < a.L ? a.y[(size_t)o * a.L + t] : 0.0f;
-            }
-        __syncthreads();                                            // every wave is done reading the area (x tiles / previous half)
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const f32x16_t& ac = acc[half * 2 + tm];
-            unsigned char* row = smem + (unsigned)(tm * 32 + li) * XP2 + wave * 64 + lk * 8;
+        for (int reg = 0; reg < 16; ++reg) {
+            const int o = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+            const int t = t0 + tq * 32 + li;
+            rs[reg] = t < a.L ? a.y[(size_t)o * a.L + t] : 0.0f;
+        }
+        __syncthreads();                                            // every wave is done reading the area (x tiles / previous tile)
+        {
+            const f32x16_t& ac = acc[tq];
+            unsigned char* row = smem + (unsigned)li * XP2 + wave * 64 + lk * 8;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v[4];
@@ -772,29 +775,23 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
             }
         }
         __syncthreads();
-        f32x16_t acc2[2];
+        f32x16_t acc2;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
         auto step2 = [&](const cu32x4_t (&Af)[NP], int s) {
-            cu32x4_t B[2][NP];
+            cu32x4_t B[NP];
             const unsigned char* bp = smem + (bfrag2 + (unsigned)s * 32);
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                B[tm][0] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2));
-                B[tm][1] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2) + plane2);
-                if constexpr (NP == 3) B[tm][2] = *reinterpret_cast<const cu32x4_t*>(bp + tm * (32 * XP2) + 2 * plane2);
-            }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) acc2[tm] = mfmaP<NP>(Af, B[tm], acc2[tm]);
+            B[0] = *reinterpret_cast<const cu32x4_t*>(bp);
+            B[1] = *reinterpret_cast<const cu32x4_t*>(bp + plane2);
+            if constexpr (NP == 3) B[2] = *reinterpret_cast<const cu32x4_t*>(bp + 2 * plane2);
+            acc2 = mfmaP<NP>(Af, B, acc2);
         };
         auto fetch2 = [&](cu32x4_t (&Ad)[NP], int sp) {
             sp = sp < nc16 - 1 ? sp : nc16 - 1;
             __builtin_amdgcn_sched_barrier(0); load_A2(Ad, sp); __builtin_amdgcn_sched_barrier(0);
         };
         static_assert(nc16 % 3 == 0, "ring of three");
-        for (int s = 0; s < nc16; s += 3) {                          // two steps of prefetch: a step is only 12 MFMAs
+        for (int s = 0; s < nc16; s += 3) {                          // two steps of prefetch: a step is only 6 MFMAs
             fetch2(A2[2], s + 2); step2(A2[0], s);
             fetch2(A2[0], s + 3); step2(A2[1], s + 1);
             fetch2(A2[1], s + 4); step2(A2[2], s + 2);
@@ -803,16 +800,13 @@ __global__ __launch_bounds__(64 * NW, 3) void k_resunit_bf16x3(ResUnitDev a) {
         for (int reg = 0; reg < 16; ++reg) {
             const int pi = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
             const float bias = s_prm[3][pi], pa = s_prm[4][pi], pib = s_prm[5][pi];
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int t = t0 + half * 64 + tm * 32 + li;
-                if (t < a.L) {
-                    float v = acc2[tm][reg] + bias;
-                    v = rs[tm][reg] + v;
-                    const size_t oi = (size_t)pi * a.L + t;
-                    a.y[oi] = v;
-                    if (a.ya) a.ya[oi] = a.post_a ? snake_f(v, pa, pib) : v;
-                }
+            const int t = t0 + tq * 32 + li;
+            if (t < a.L) {
+                float v = acc2[reg] + bias;
+                v = rs[reg] + v;
+                const size_t oi = (size_t)pi * a.L + t;
+                a.y[oi] = v;
+                if (a.ya) a.ya[oi] = a.post_a ? snake_f(v, pa, pib) : v;
             }
         }
     }
@@ -833,7 +827,7 @@ hipError_t launch_resunit(const ResUnitArgs& r, hipStream_t st) {
     a.mid_a = r.mid_a; a.mid_ib = r.mid_ib; a.post_a = r.post_a; a.post_ib = r.post_ib; a.C = r.C; a.L = r.L; a.dil = r.dil;
     const int W = 128 + 6 * r.dil;
     const int np = conv_planes(r.planes);
-    const size_t lds_x = (size_t)np * W * 80, lds_mid = (size_t)np * 64 * (r.C * 2 + 16);
+    const size_t lds_x = (size_t)np * W * 80, lds_mid = (size_t)np * 32 * (r.C * 2 + 16);       // x staging | one parked 32-column tile
     const size_t lds = lds_x > lds_mid ? lds_x : lds_mid;
     const dim3 grid((r.L + 127) / 128);
     if (np == 2) {
