@@ -1822,7 +1822,8 @@ static q3_status frame_launch(q3_session* s) {
 #endif
     Q3C(cp_run(s));
     FrameEmbedArgs f{};
-    f.codec_emb = m->codec_emb; f.cp_embs = m->cp_embs_dev; f.tok = s->tok;
+    f.codec_emb = m->codec_emb; f.tok = s->tok;
+    for (int g = 0; g < 15; ++g) f.cp_embs[g] = g < (int)m->cp_emb.size() ? m->cp_emb[(size_t)g] : nullptr;
     f.cp_logits_last = s->CP_LOGITS + (size_t)14 * s->B * c.cp_vocab; f.cp_vocab = c.cp_vocab;
     f.codes = s->codes; f.frame_idx = s->frame_idx; f.max_frames = s->max_frames;
     f.text_rows = s->rows; f.trail_base = s->trail_base; f.trail_len = s->trail_len; f.pad_row = s->pad_row;
@@ -3478,7 +3479,8 @@ extern "C" q3_status q3_frame_embed(q3_model* m, uint32_t sem_token, const uint3
     HIPC(hipMemcpy(codes, frame, 64, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(one, &h_one, 4, hipMemcpyHostToDevice));
     FrameEmbedArgs f{};
-    f.codec_emb = m->codec_emb; f.cp_embs = m->cp_embs_dev; f.tok = tok; f.cp_logits_last = logits; f.cp_vocab = V;
+    f.codec_emb = m->codec_emb; f.tok = tok; f.cp_logits_last = logits; f.cp_vocab = V;
+    for (int g = 0; g < 15; ++g) f.cp_embs[g] = g < (int)m->cp_emb.size() ? m->cp_emb[(size_t)g] : nullptr;
     f.codes = codes; f.frame_idx = zero; f.max_frames = 1; f.text_rows = rows; f.trail_base = zero; f.trail_len = one; f.pad_row = zero;
     f.out = out; f.H = H; f.B = 1; f.n_acoustic = 15;
     HIPC(launch_frame_embed(f, 0));

@@ -251,7 +251,7 @@ struct CpGatherArgs {
 hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st);
 
 struct FrameEmbedArgs {
-    const uint16_t* codec_emb; const uint16_t* const* cp_embs;   // device array of 15 table pointers
+    const uint16_t* codec_emb; const uint16_t* cp_embs[15];      // the 15 acoustic tables, IN the kernel arguments (round 5: was a device array — one more dependent round trip in front of every gather)
     const uint32_t* tok; const float* cp_logits_last; int cp_vocab;  // final pass logits → code 14
     uint32_t* codes; const int* frame_idx; int max_frames;
     const float* text_rows; const int* trail_base; const int* trail_len; const int* pad_row;   // per-seq

@@ -1227,36 +1227,71 @@ hipError_t launch_cp_gather(const CpGatherArgs& a, hipStream_t st) {
 
 // lib.rs:605-622 + code_predictor.rs:497-519: record the frame's 16 codes and build the next talker
 // input = semantic_embed + ((e0+e1)+…+e14) + (trailing_text[frame] | tts_pad).
+// Three dependent memory round trips instead of five (round 5; the node was 14 us of a 2.8 ms frame): everything that does not
+// depend on anything else — the sequence's frame index, its sampled token, its text-row bookkeeping and this thread's share of
+// the last pass's logits — is requested at once; the frame's earlier codes (address needs the frame index) are requested before
+// the argmax runs, so they land under it; the table pointers come with the kernel arguments; then the 17 row gathers.
 __global__ __launch_bounds__(256) void k_frame_embed(FrameEmbedArgs a) {
     __shared__ float red_v[4]; __shared__ int red_i[4];
     __shared__ uint32_t codes_s[16];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // trip 1: independent requests
     const int f = a.frame_idx[b];
-    // a frozen sequence (SampleArgs::limit) may sit at frame_idx == max_frames: it records nothing and reads its last slot
+    const uint32_t tok = a.tok[b];
+    const int tlen = a.trail_len[b], tbase = a.trail_base[b], prow = a.pad_row[b];
+    constexpr int LPT = 16;                                   // logits per thread kept in registers (vocab <= 4096)
+    float lv[LPT];
+    const float* lg = a.cp_logits_last + (size_t)b * a.cp_vocab;
+    const bool in_regs = a.cp_vocab <= LPT * 256;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) { const int j = i * 256 + tid; lv[i] = j < a.cp_vocab ? lg[j] : -INFINITY; }
+    }
+    // trip 2 (needs f): the frame's earlier codes. A frozen sequence (SampleArgs::limit) may sit at frame_idx == max_frames: it
+    // records nothing and reads its last slot
     const bool live = f < a.max_frames;
     uint32_t* frame = a.codes + ((size_t)b * a.max_frames + (live ? f : a.max_frames - 1)) * 16;
-    const int last = block_argmax_first(a.cp_logits_last + (size_t)b * a.cp_vocab, a.cp_vocab, red_v, red_i);
-    if (threadIdx.x == 0 && blockIdx.y == 0 && live) {
-        frame[0] = a.tok[b];
+    uint32_t my_code = 0;
+    if (tid >= 1 && tid < 16 && tid != a.n_acoustic) my_code = frame[tid];
+    int last;
+    if (in_regs) {                                            // block_argmax_first over the registers: first maximum, NaN never wins
+        float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) { const int j = i * 256 + tid; const float v = lv[i]; if (j < a.cp_vocab && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; } }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { float ov = __shfl_xor(bv, off); int oi = __shfl_xor(bi, off); argmax_combine(bv, bi, ov, oi); }
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        __syncthreads();
+        bv = red_v[0]; bi = red_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, red_v[w], red_i[w]);
+        last = bi == 0x7fffffff ? 0 : bi;
+    } else {
+        last = block_argmax_first(lg, a.cp_vocab, red_v, red_i);
+    }
+    if (tid == 0 && blockIdx.y == 0 && live) {
+        frame[0] = tok;
         frame[a.n_acoustic] = (uint32_t)last;
     }
-    if (threadIdx.x < 16)
-        codes_s[threadIdx.x] = threadIdx.x == 0 ? a.tok[b] : (threadIdx.x == (unsigned)a.n_acoustic ? (uint32_t)last : frame[threadIdx.x]);
+    if (tid < 16) codes_s[tid] = tid == 0 ? tok : (tid == a.n_acoustic ? (uint32_t)last : my_code);
     __syncthreads();
+    // trip 3: the gathers
     const int H = a.H;
-    const int row = f < a.trail_len[b] ? a.trail_base[b] + f : a.pad_row[b];
+    const int row = f < tlen ? tbase + f : prow;
     const float* text = a.text_rows + (size_t)row * H;
     const uint16_t* sem = a.codec_emb + (size_t)codes_s[0] * H;
-    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int c = blockIdx.y * 256 + tid;
     if (c < H) {
         float e[15];
 #pragma unroll
         for (int g = 0; g < 15; ++g) e[g] = g < a.n_acoustic ? bf16_to_f32(a.cp_embs[g][(size_t)codes_s[1 + g] * H + c]) : 0.0f;
+        const float sv = bf16_to_f32(sem[c]), tv = text[c];
         float acc = e[0];
 #pragma unroll
         for (int g = 1; g < 15; ++g) if (g < a.n_acoustic) acc = __fadd_rn(acc, e[g]);
-        const float summed = __fadd_rn(bf16_to_f32(sem[c]), acc);
-        a.out[(size_t)b * H + c] = __fadd_rn(summed, text[c]);
+        const float summed = __fadd_rn(sv, acc);
+        a.out[(size_t)b * H + c] = __fadd_rn(summed, tv);
     }
 }
 hipError_t launch_frame_embed(const FrameEmbedArgs& a, hipStream_t st) {
@@ -1298,6 +1333,14 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
     const float* lg = a.logits + (size_t)b * a.ld;
     uint8_t* seen = a.seen ? a.seen + (size_t)b * V : nullptr;
     const int tc = a.token_count ? a.token_count[b] : a.token_count_static;
+    // (round 5) what only the last lines of the kernel need — this step's uniform draw (two dependent loads), the counters it
+    // advances — is requested NOW by the one thread that uses it: at the end of the kernel each of these was a memory round
+    // trip of its own on the frame's critical path (the read-modify-write of pos / frame_idx included)
+    float u_pre = 0.0f; int fi_pre = 0, lim_pre = 0x7fffffff, pos_pre = 0;
+    if (tid == 0) {
+        if (a.u) u_pre = a.u[(size_t)b * a.u_stride + (a.draw_idx ? a.draw_idx[b] : 0)];      // (also in greedy mode: the row options that say so are still in flight)
+        if (a.advance) { fi_pre = a.frame_idx[b]; pos_pre = a.pos[b]; if (a.limit) lim_pre = a.limit[b]; }
+    }
     int n_sort = 2; while (n_sort < V) n_sort <<= 1;
 
     if (a.logits_hist && tc < a.hist_cap) {
@@ -1466,7 +1509,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
             const float mx = s_val[0];
             float sum = 0.0f;
             for (int r = 0; r < cut; ++r) sum += expf(s_oval[r] - mx);
-            const float u = a.u[(size_t)b * a.u_stride + (a.draw_idx ? a.draw_idx[b] : 0)];
+            const float u = u_pre;
             float cdf = 0.0f; int pk = 0;
             // `first i with cdf[i] >= u` over the whole vocabulary: for u > 0 that index always has
             // non-zero probability (so scanning the kept entries is exact); for u == 0 it is index 0.
@@ -1484,9 +1527,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
     if (tid == 0) {
         a.tok[b] = (uint32_t)pick;
         if (seen && pick < V) seen[pick] = 1;
-        const bool frozen = a.advance && a.limit && a.frame_idx[b] >= a.limit[b];      // SampleArgs::limit
+        const bool frozen = a.advance && a.limit && fi_pre >= lim_pre;      // SampleArgs::limit
         if (a.token_count && !frozen) a.token_count[b] = tc + 1;
-        if (a.advance && !frozen) { a.frame_idx[b] += 1; a.pos[b] += 1; }
+        if (a.advance && !frozen) { a.frame_idx[b] = fi_pre + 1; a.pos[b] = pos_pre + 1; }
     }
 }
 
