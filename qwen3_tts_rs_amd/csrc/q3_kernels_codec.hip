@@ -1190,13 +1190,58 @@ __global__ __launch_bounds__(256) void k_norm_c(const float* __restrict__ x, con
         for (int c = cg; c < C; c += 8) y[(size_t)c * L + t] = x[(size_t)c * L + t] / den * w[c];
     }
 }
+// One memory round trip instead of sixteen (round 5): 17.5 us -> a few for the pre-transformer's 17 RMSNorms and the two ConvNeXt
+// LayerNorms of a decode. 16 columns x 16 channel groups per workgroup (twice the workgroups), and a thread requests ALL of its
+// CPT = C / 16 channels at once and keeps them in registers: the statistics, then the normalised values, come from the same
+// loads (k_norm_c read x twice, eight loads at a time). Sums run in channel order inside a thread and in group order across the
+// 16 groups — position-independent like before (the segment-exact decode relies on that), but a different order than k_norm_c's,
+// so the two kernels do not produce the same last bits: every caller goes through the launchers below, which pick by C only.
+template <bool LAYERNORM, int CPT>
+__global__ __launch_bounds__(256) void k_norm_c2(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                 float* __restrict__ y, int C, int L, float eps) {      // y never aliases x
+    __shared__ float s1[16][16], s2[16][16];
+    const int tx = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + tx;
+    const bool in = t < L;
+    float v[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) v[u] = in ? x[(size_t)(cg + 16 * u) * L + t] : 0.0f;
+    float wv[CPT], bv[LAYERNORM ? CPT : 1];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) { wv[u] = w[cg + 16 * u]; if (LAYERNORM) bv[u] = b[cg + 16 * u]; }
+    float a = 0.0f, q = 0.0f;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) { a += v[u]; q += v[u] * v[u]; }
+    s1[cg][tx] = a; s2[cg][tx] = q;
+    __syncthreads();
+    float sum = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { sum += s1[g][tx]; sq += s2[g][tx]; }
+    if (!in) return;
+    if (LAYERNORM) {
+        const float mean = sum / (float)C, var = sq / (float)C - mean * mean;
+        const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) y[(size_t)(cg + 16 * u) * L + t] = (v[u] - mean) * inv * wv[u] + bv[u];
+    } else {
+        const float den = sqrtf(sq / (float)C + eps);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) y[(size_t)(cg + 16 * u) * L + t] = v[u] / den * wv[u];
+    }
+}
 hipError_t launch_layernorm_c(const float* x, const float* w, const float* b, float* y, int C, int L, float eps,
                               hipStream_t st) {
-    hipLaunchKernelGGL(k_norm_c<true>, dim3((L + 31) / 32), dim3(256), 0, st, x, w, b, y, C, L, eps);
+    static const bool old = getenv("Q3_NORM_C_OLD") != nullptr;        // A/B aid
+    if (!old && C == 1024) hipLaunchKernelGGL((k_norm_c2<true, 64>), dim3((L + 15) / 16), dim3(256), 0, st, x, w, b, y, C, L, eps);
+    else if (!old && C == 512) hipLaunchKernelGGL((k_norm_c2<true, 32>), dim3((L + 15) / 16), dim3(256), 0, st, x, w, b, y, C, L, eps);
+    else hipLaunchKernelGGL(k_norm_c<true>, dim3((L + 31) / 32), dim3(256), 0, st, x, w, b, y, C, L, eps);
     return hipGetLastError();
 }
 hipError_t launch_rmsnorm_c(const float* x, const float* w, float* y, int C, int L, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(k_norm_c<false>, dim3((L + 31) / 32), dim3(256), 0, st, x, w, (const float*)nullptr, y, C, L, eps);
+    static const bool old = getenv("Q3_NORM_C_OLD") != nullptr;        // A/B aid
+    if (!old && C == 1024) hipLaunchKernelGGL((k_norm_c2<false, 64>), dim3((L + 15) / 16), dim3(256), 0, st, x, w, (const float*)nullptr, y, C, L, eps);
+    else if (!old && C == 512) hipLaunchKernelGGL((k_norm_c2<false, 32>), dim3((L + 15) / 16), dim3(256), 0, st, x, w, (const float*)nullptr, y, C, L, eps);
+    else hipLaunchKernelGGL(k_norm_c<false>, dim3((L + 31) / 32), dim3(256), 0, st, x, w, (const float*)nullptr, y, C, L, eps);
     return hipGetLastError();
 }
 

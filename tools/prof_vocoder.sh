@@ -22,9 +22,9 @@ for s, e, name, g, w in seg:
 print(f"{'kernel':40s} {'WGs':>8s} {'calls':>6s} {'total ms':>9s} {'avg us':>9s} {'%':>6s}")
 for (short, wgs), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{short:40s} {wgs:8d} {n:6d} {t/1e6:9.3f} {t/n/1e3:9.1f} {100*t/busy:6.2f}")
-print("\nlaunch order (launches > 40 us):")
+print("\nlaunch order (launches > 40 us; Q3_VOC_MIN_NS=0 lists all):")
 for i, (s, e, name, g, w) in enumerate(seg):
-    if e - s > 40000:
+    if e - s > int(__import__("os").environ.get("Q3_VOC_MIN_NS", "40000")):
         short = name.replace("(anonymous namespace)::", "").replace("void q3::", "").replace("q3::", "").replace("void ", "").split("(")[0]
         print(f"{i:4d} {short:60s} {g // max(w, 1):7d} WGs {(e - s)/1e3:9.1f} us  gap {((s - seg[i-1][1]) if i else 0)/1e3:6.1f}")
 PY
