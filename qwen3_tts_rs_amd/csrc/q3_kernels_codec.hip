@@ -993,6 +993,16 @@ static hipError_t launch_bf16x3_k(const ConvDev& a, int phases, hipStream_t st) 
     // 1x1 convs with a residual (second conv of every residual unit) are bound by their epilogue traffic, not by x
     // staging: the single-co-tile 64 co x 128 t geometry with batched residual loads wins at every width
     if (K == 1 && a.resid && a.cout % 64 == 0 && a.cout != 96 && big_tiles >= 192) return launch_bf16x3_v<K, 1, 2, 2, 2>(a, phases, st);
+    // wide 1x1 convs without a residual on SMALL grids (the ConvNeXt pw1: 4096 output channels at 1280 / 2560 columns = 320 / 640
+    // workgroups of 128 x 128 — barely more than one per CU, each walking all of K): 64 co x 64 t tiles fill the chip four times
+    // over instead: 136 -> < 100 us and 243 -> 174 us (round 5; Q3_CONV_PW1_GEO=0 restores the 128 x 128 tiles: A/B aid)
+    {
+        static const int pw = [] { const char* e = getenv("Q3_CONV_PW1_GEO"); return e ? atoi(e) : 2; }();
+        if (pw && K == 1 && !a.resid && a.cout % 128 == 0 && big_tiles >= 192 && big_tiles < 1024) {
+            if (pw == 1) return launch_bf16x3_v<K, 1, 2, 2, 2>(a, phases, st);      // 64 co x 128 t
+            return launch_bf16x3_v<K, 1, 1, 2, 2>(a, phases, st);                   // 64 co x 64 t
+        }
+    }
     if (a.cout % 128 == 0 && big_tiles >= 192) return launch_bf16x3_v<K, 2, 2, 2, 2>(a, phases, st);   // 128 co x 128 t (64 x 128: 5-13 % slower at k = 7)
     if (a.cout == 192) return launch_bf16x3_v<K, 1, 2, 3, 2>(a, phases, st);   // 2 x (96 co x 128 t): 1.32 ms vs 1.50 for 192 x 128 (k = 7)
     if (a.cout == 96) return launch_bf16x3_v<K, 1, 2, 3, 2>(a, phases, st);                             //  96 co x 128 t
