@@ -1,4 +1,4 @@
-// Probe of v_mfma_f32_4x4x4_16b_bf16 operand/result layout on gfx950 (development aid).
+// Probe of v_mfma_f32_4x4x4_16b_bf16 operand/result layout on gfx950 (development aid). Build: hipcc --offload-arch=gfx950 -O3 mfma4_layout.hip -o mfma4_layout
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
