@@ -318,7 +318,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
     // partial tile → LDS, layout [col m][row]: lane (m, kg) owns rows kg*4 .. kg*4+3
     *reinterpret_cast<f32x4_t*>(&red[wave][0][m * 16 + kg * 4]) = acc0;
     if constexpr (NW == 2) *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = acc1;
-    if constexpr (RMS) ssq[wave][kg][m] = HALF ? gemv_ss_half(ss) : ss;
+    if constexpr (RMS) {
+        // (round 5) a column's four k-group lanes are added inside the wave, BEFORE the barrier — work the early waves do while
+        // they wait for the last one anyway —, so the epilogue behind the barrier adds 8 partial sums per column instead of 32
+        float sc = HALF ? gemv_ss_half(ss) : ss;
+        sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
+        if (kg == 0) ssq[wave][0][m] = sc;
+    }
     Q3T(6);
     __syncthreads();
     Q3T(5);
@@ -334,9 +340,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
             if constexpr (RMS) {
                 float tot = 0.0f;
 #pragma unroll
-                for (int w = 0; w < NWAVES; ++w)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) tot += ssq[w][g][col];
+                for (int w = 0; w < NWAVES; ++w) tot += ssq[w][0][col];
                 const float den = sqrtf(tot / (float)a.K + a.eps);
                 v = v / den;
                 if constexpr (NW == 2) v2 = v2 / den;
@@ -742,7 +746,11 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
     *reinterpret_cast<f32x4_t*>(&red[wave][1][m * 16 + kg * 4]) = aGH;
     *reinterpret_cast<f32x4_t*>(&red[wave][2][m * 16 + kg * 4]) = aUF;
     *reinterpret_cast<f32x4_t*>(&red[wave][3][m * 16 + kg * 4]) = aUH;
-    ssq[wave][kg][m] = HALF ? gemv_ss_half(ss) : ss;
+    {
+        float sc = HALF ? gemv_ss_half(ss) : ss;          // see k_gemv_mfma: the four k-group lanes of a column added before the barrier
+        sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
+        if (kg == 0) ssq[wave][0][m] = sc;
+    }
     __syncthreads();
     // 24 rows x 16 columns: thread (col, r24); rows 0-15 = the full tile, 16-23 = this workgroup's half of the shared tile
     if (tid < 384) {
@@ -755,9 +763,7 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w) { g += red[w][which][idx]; u += red[w][2 + which][idx]; }
 #pragma unroll
-            for (int w = 0; w < NWAVES; ++w)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) tot += ssq[w][q][col];
+            for (int w = 0; w < NWAVES; ++w) tot += ssq[w][0][col];
             const float den = sqrtf(tot / (float)a.K + a.eps);
             g = g / den; u = u / den;
             const int n = (full ? tile_full : tile_half) * 16 + row16;
