@@ -164,6 +164,16 @@ __device__ __forceinline__ Split3 gemv_prep_half(bool valid, const float4& x, co
 // Σx² of a column = the sums of its two half-slot lanes (m and m + 8)
 __device__ __forceinline__ float gemv_ss_half(float ss) { return ss + __builtin_bit_cast(float, ror8u(__builtin_bit_cast(uint32_t, ss))); }
 
+// four floats from the lane that loaded them (row-contiguous order) to the lane whose B-operand slot they fill: LDS crossbar, no LDS memory
+__device__ __forceinline__ float4 x_to_b_order(const float4& t, int bsrc) {
+    float4 r;
+    r.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, t.x)));
+    r.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, t.y)));
+    r.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, t.z)));
+    r.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, t.w)));
+    return r;
+}
+
 // NWAVES waves split K; weights for up to G k-steps are requested up front (G KiB per wave in flight per
 // matrix) before any of them is consumed, so a wave's whole slice is usually one HBM round trip.
 //
@@ -194,6 +204,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
     const bool act = HALF ? xrow < a.M : m < a.M;
     const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
     const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 + xhalf : nullptr;
+    // COAL: x requested in row-contiguous lane order and moved to B-operand order through the LDS crossbar (see k_gemv_sk2)
+    constexpr bool COAL = HALF && NWAVES <= 8;
+    const int crow = lane >> 3, cchunk = lane & 7;
+    const bool cact = crow < a.M;
+    const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
+    const int bsrc = ((xrow * 8) + 2 * kg + (m >> 3)) * 4;
 
     // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
     float pre_b = 0.0f, pre_r = 0.0f;
@@ -227,8 +243,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
                 // lanes of unused batch columns issue no request — measured per variant: qkv 7.8 -> 7.4 us, code-predictor
                 // qkv 5.2 -> 4.6 us at M = 8, but the two-instruction SwiGLU pair loses (13.7 -> 15.7 us) and stays unmasked
                 const bool ld = (NW == 2 && !HALF) || act;
-                g.xa[i] = ld ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (!HALF) g.xb[i] = ld ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (COAL) {
+                    const int kc = (s * 32 + cchunk * 4) < a.K ? s * 32 : 0;
+                    g.xa[i] = cact ? *reinterpret_cast<const float4*>(xc + kc) : float4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    g.xa[i] = ld ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!HALF) g.xb[i] = ld ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                }
                 if constexpr (RMS) {
                     g.na[i] = *reinterpret_cast<const float4*>(nwp + ko);
                     if constexpr (!HALF) g.nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
@@ -251,6 +272,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
             for (int i = 0; i < G; ++i) {
                 const int s = sb + i;      // s >= s1 (ragged last group): zero operand, its MFMAs add nothing — no branch,
                 const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;   // so the group stays one scheduling region
+                if constexpr (COAL) g.xa[i] = x_to_b_order(g.xa[i], bsrc);
                 if constexpr (HALF) sp[i] = gemv_prep_half<RMS>(valid, g.xa[i], RMS ? g.na[i] : g.xa[i], ss);
                 else sp[i] = gemv_prep<RMS>(valid, g.xa[i], g.xb[i], RMS ? g.na[i] : g.xa[i], RMS ? g.nb[i] : g.xb[i], ss);
             }
@@ -393,6 +415,17 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     const int xrow = HALF ? (m & 7) : m, xhalf = HALF ? (m >> 3) * 4 : 0;
     const bool act = HALF ? xrow < a.M : m < a.M;
     const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
+    // COAL (round 5, HALF only): the x loads in ROW-CONTIGUOUS lane order. In B-operand order consecutive lanes belong to different
+    // batch rows (4-12 KB apart), so the four lanes of a quad never share a 64-byte sector and the CU's texture path spends a
+    // cycle per lane instead of one per quad on every x instruction — four times what the same bytes cost as weight tiles. Lane l
+    // now asks for the 16 bytes of row l / 8, chunk l % 8 (a quad = one sector, an instruction = eight full 128-byte lines) and the
+    // four floats travel to the lane that needs them — (m, kg) wants row m % 8, chunk 2 kg + m / 8 — through the LDS crossbar
+    // (four ds_bpermute_b32 per k-step, no LDS memory, no barrier).
+    constexpr bool COAL = HALF && !MB;
+    const int crow = lane >> 3, cchunk = lane & 7;
+    const bool cact = crow < a.M;
+    const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
+    const int bsrc = ((xrow * 8) + 2 * kg + (m >> 3)) * 4;
 
     float pre = 0.0f;                                // bias + residual of the k = 0 half, requested up front
     {
@@ -412,8 +445,13 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) {
             const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
             const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;
-            g.xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (!HALF) g.xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (COAL) {
+                const int kc = (s * 32 + cchunk * 4) < a.K ? s * 32 : 0;
+                g.xa[i] = cact ? *reinterpret_cast<const float4*>(xc + kc) : float4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                g.xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) g.xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -426,6 +464,9 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) {
             const int s = sb + i;
             const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;
+            if constexpr (COAL) {
+                g.xa[i] = x_to_b_order(g.xa[i], bsrc);
+            }
             if constexpr (HALF) sp[i] = gemv_prep_half<false>(valid, g.xa[i], g.xa[i], ss);
             else sp[i] = gemv_prep<false>(valid, g.xa[i], g.xb[i], g.xa[i], g.xb[i], ss);
         }
@@ -704,6 +745,11 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
     const bool act = HALF ? xrow < a.M : m < a.M;
     const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
     const float* __restrict__ nwp = a.norm_w + kg * 8 + xhalf;
+    constexpr bool COAL = HALF;                      // see k_gemv_sk2: x in row-contiguous lane order, moved by the LDS crossbar
+    const int crow = lane >> 3, cchunk = lane & 7;
+    const bool cact = crow < a.M;
+    const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
+    const int bsrc = ((xrow * 8) + 2 * kg + (m >> 3)) * 4;
     f32x4_t aGF = {0.f, 0.f, 0.f, 0.f}, aGH = aGF, aUF = aGF, aUH = aGF;
     float ss = 0.0f;
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
@@ -714,7 +760,8 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) {
             const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
             const int ko = s * 32;
-            xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (COAL) xa[i] = cact ? *reinterpret_cast<const float4*>(xc + ko) : float4{0.f, 0.f, 0.f, 0.f};
+            else xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
             if constexpr (!HALF) xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
             na[i] = *reinterpret_cast<const float4*>(nwp + ko);
             if constexpr (!HALF) nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
@@ -731,6 +778,7 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const bool valid = act && (sb + i) < s1;
+            if constexpr (COAL) xa[i] = x_to_b_order(xa[i], bsrc);
             if constexpr (HALF) sp[i] = gemv_prep_half<true>(valid, xa[i], na[i], ss);
             else sp[i] = gemv_prep<true>(valid, xa[i], xb[i], na[i], nb[i], ss);
         }
