@@ -205,11 +205,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
     const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
     const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 + xhalf : nullptr;
     // COAL: x requested in row-contiguous lane order and moved to B-operand order through the LDS crossbar (see k_gemv_sk2)
-    constexpr bool COAL = HALF && NWAVES <= 8;
-    const int crow = lane >> 3, cchunk = lane & 7;
+    constexpr bool COAL = NWAVES <= 8;               // (the 8-wave HOIST schedule; !HALF: the two-instruction form of k_gemv_sk2)
+    const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
     const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
-    const int bsrc = ((xrow * 8) + 2 * kg + (m >> 3)) * 4;
+    const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
 
     // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
     float pre_b = 0.0f, pre_r = 0.0f;
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
                 if constexpr (COAL) {
                     const int kc = (s * 32 + cchunk * 4) < a.K ? s * 32 : 0;
                     g.xa[i] = cact ? *reinterpret_cast<const float4*>(xc + kc) : float4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!HALF) g.xb[i] = cact ? *reinterpret_cast<const float4*>(xc + kc + 4) : float4{0.f, 0.f, 0.f, 0.f};
                 } else {
                     g.xa[i] = ld ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
                     if constexpr (!HALF) g.xb[i] = ld ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
             for (int i = 0; i < G; ++i) {
                 const int s = sb + i;      // s >= s1 (ragged last group): zero operand, its MFMAs add nothing — no branch,
                 const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;   // so the group stays one scheduling region
-                if constexpr (COAL) g.xa[i] = x_to_b_order(g.xa[i], bsrc);
+                if constexpr (COAL) { g.xa[i] = x_to_b_order(g.xa[i], bsrc); if constexpr (!HALF) g.xb[i] = x_to_b_order(g.xb[i], bsrc); }
                 if constexpr (HALF) sp[i] = gemv_prep_half<RMS>(valid, g.xa[i], RMS ? g.na[i] : g.xa[i], ss);
                 else sp[i] = gemv_prep<RMS>(valid, g.xa[i], g.xb[i], RMS ? g.na[i] : g.xa[i], RMS ? g.nb[i] : g.xb[i], ss);
             }
@@ -421,11 +422,14 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     // now asks for the 16 bytes of row l / 8, chunk l % 8 (a quad = one sector, an instruction = eight full 128-byte lines) and the
     // four floats travel to the lane that needs them — (m, kg) wants row m % 8, chunk 2 kg + m / 8 — through the LDS crossbar
     // (four ds_bpermute_b32 per k-step, no LDS memory, no barrier).
-    constexpr bool COAL = HALF && !MB;
-    const int crow = lane >> 3, cchunk = lane & 7;
+    // Full 16-column tiles (!HALF; M > 8 and the row blocks of wide sessions): two instructions per k-step, lane l asks for row
+    // l / 4, chunks 2 (l % 4) and 2 (l % 4) + 1 — a quad = one row's 128-byte line, two half-used sectors per instruction instead of
+    // four lanes x four sectors —, and both halves of lane (m, kg)'s slot come from lane 4 m + kg.
+    constexpr bool COAL = true;
+    const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
     const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
-    const int bsrc = ((xrow * 8) + 2 * kg + (m >> 3)) * 4;
+    const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
 
     float pre = 0.0f;                                // bias + residual of the k = 0 half, requested up front
     {
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
             if constexpr (COAL) {
                 const int kc = (s * 32 + cchunk * 4) < a.K ? s * 32 : 0;
                 g.xa[i] = cact ? *reinterpret_cast<const float4*>(xc + kc) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) g.xb[i] = cact ? *reinterpret_cast<const float4*>(xc + kc + 4) : float4{0.f, 0.f, 0.f, 0.f};
             } else {
                 g.xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (!HALF) g.xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
@@ -466,6 +471,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
             const bool valid = act && s < s1 && (s * 32 + kg * 8) < a.K;
             if constexpr (COAL) {
                 g.xa[i] = x_to_b_order(g.xa[i], bsrc);
+                if constexpr (!HALF) g.xb[i] = x_to_b_order(g.xb[i], bsrc);
             }
             if constexpr (HALF) sp[i] = gemv_prep_half<false>(valid, g.xa[i], g.xa[i], ss);
             else sp[i] = gemv_prep<false>(valid, g.xa[i], g.xb[i], g.xa[i], g.xb[i], ss);
@@ -745,11 +751,11 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
     const bool act = HALF ? xrow < a.M : m < a.M;
     const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
     const float* __restrict__ nwp = a.norm_w + kg * 8 + xhalf;
-    constexpr bool COAL = HALF;                      // see k_gemv_sk2: x in row-contiguous lane order, moved by the LDS crossbar
-    const int crow = lane >> 3, cchunk = lane & 7;
+    constexpr bool COAL = true;                      // see k_gemv_sk2: x in row-contiguous lane order, moved by the LDS crossbar
+    const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
     const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
-    const int bsrc = ((xrow * 8) + 2 * kg + (m >> 3)) * 4;
+    const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
     f32x4_t aGF = {0.f, 0.f, 0.f, 0.f}, aGH = aGF, aUF = aGF, aUH = aGF;
     float ss = 0.0f;
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
@@ -760,9 +766,8 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) {
             const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
             const int ko = s * 32;
-            if constexpr (COAL) xa[i] = cact ? *reinterpret_cast<const float4*>(xc + ko) : float4{0.f, 0.f, 0.f, 0.f};
-            else xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (!HALF) xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            xa[i] = cact ? *reinterpret_cast<const float4*>(xc + ko) : float4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!HALF) xb[i] = cact ? *reinterpret_cast<const float4*>(xc + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
             na[i] = *reinterpret_cast<const float4*>(nwp + ko);
             if constexpr (!HALF) nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
         }
@@ -778,7 +783,8 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const bool valid = act && (sb + i) < s1;
-            if constexpr (COAL) xa[i] = x_to_b_order(xa[i], bsrc);
+            xa[i] = x_to_b_order(xa[i], bsrc);
+            if constexpr (!HALF) xb[i] = x_to_b_order(xb[i], bsrc);
             if constexpr (HALF) sp[i] = gemv_prep_half<true>(valid, xa[i], na[i], ss);
             else sp[i] = gemv_prep<true>(valid, xa[i], xb[i], na[i], nb[i], ss);
         }
