@@ -182,7 +182,7 @@ __device__ __forceinline__ float4 x_to_b_order(const float4& t, int bsrc) {
 // column's 32 bytes are fetched by lanes m and m + 8 of the same 16-lane row in ONE instruction (lane m + 8 would
 // otherwise idle) and exchanged with a DPP row rotate: one x (and one norm-weight) instruction per k-step instead of two.
 // Lanes m >= 8 end up holding column m - 8 with its halves swapped — columns nobody reads.
-template <int EPI, bool RMS, int NWAVES, bool HALF>
+template <int EPI, bool RMS, int NWAVES, bool HALF, bool CO = true>      // CO: see COAL below (off for M <= 2)
 __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a_in) {
     Q3_LIN_APPLY(a, a_in);
     constexpr int NW = (EPI == EPI_SWIGLU) ? 2 : 1;
@@ -205,7 +205,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
     const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
     const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 + xhalf : nullptr;
     // COAL: x requested in row-contiguous lane order and moved to B-operand order through the LDS crossbar (see k_gemv_sk2)
-    constexpr bool COAL = NWAVES <= 8;               // (the 8-wave HOIST schedule; !HALF: the two-instruction form of k_gemv_sk2)
+    // (M <= 2 keeps the B-operand order: one or two live rows are one or two sectors per quad either way, and the four crossbar
+    // moves per k-step then only cost — B = 1 frame 2.569 -> 2.588 ms with them)
+    constexpr bool COAL = CO && NWAVES <= 8;         // (the 8-wave HOIST schedule; !HALF: the two-instruction form of k_gemv_sk2)
     const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
     const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
 // other eight A-operand rows. 8 waves split K; groups of 4 k-steps; x / norm weight first, weights second; the bf16x3
 // split shared by the four weight operands of a k-step.
 // ------------------------------------------------------------------------------------------------
-template <bool HALF>
+template <bool HALF, bool CO = true>
 __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
     Q3_LIN_APPLY(a, a_in);
     constexpr int NWAVES = 8, G = 4;
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
     const bool act = HALF ? xrow < a.M : m < a.M;
     const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
     const float* __restrict__ nwp = a.norm_w + kg * 8 + xhalf;
-    constexpr bool COAL = true;                      // see k_gemv_sk2: x in row-contiguous lane order, moved by the LDS crossbar
+    constexpr bool COAL = CO;                        // see k_gemv_sk2: x in row-contiguous lane order, moved by the LDS crossbar (off for M <= 2)
     const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
     const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
@@ -766,8 +768,13 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
         for (int i = 0; i < G; ++i) {
             const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
             const int ko = s * 32;
-            xa[i] = cact ? *reinterpret_cast<const float4*>(xc + ko) : float4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (!HALF) xb[i] = cact ? *reinterpret_cast<const float4*>(xc + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (COAL) {
+                xa[i] = cact ? *reinterpret_cast<const float4*>(xc + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) xb[i] = cact ? *reinterpret_cast<const float4*>(xc + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+            }
             na[i] = *reinterpret_cast<const float4*>(nwp + ko);
             if constexpr (!HALF) nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
         }
@@ -783,8 +790,7 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const bool valid = act && (sb + i) < s1;
-            xa[i] = x_to_b_order(xa[i], bsrc);
-            if constexpr (!HALF) xb[i] = x_to_b_order(xb[i], bsrc);
+            if constexpr (COAL) { xa[i] = x_to_b_order(xa[i], bsrc); if constexpr (!HALF) xb[i] = x_to_b_order(xb[i], bsrc); }
             if constexpr (HALF) sp[i] = gemv_prep_half<true>(valid, xa[i], na[i], ss);
             else sp[i] = gemv_prep<true>(valid, xa[i], xb[i], na[i], nb[i], ss);
         }
@@ -859,7 +865,8 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
         // 24 rows per workgroup where that is what puts one workgroup on every CU (the talker's gate/up: 384 tiles -> 256)
         static const bool no24 = getenv("Q3_GEMV_NO_GU24") != nullptr;      // A/B aid
         if (!no24 && force == 0 && tiles % 3 == 0 && tiles / 3 * 2 >= 224 && tiles / 3 * 2 <= 288 && S >= 64 && S % 8 == 0 && a.K == a.Kpad && !a.bias) {
-            if (a.M <= 8) hipLaunchKernelGGL((k_gemv_gu24<true>), dim3(tiles / 3 * 2), dim3(512), 0, st, Q3_LIN_PASS(a));
+            if (a.M <= 2) hipLaunchKernelGGL((k_gemv_gu24<true, false>), dim3(tiles / 3 * 2), dim3(512), 0, st, Q3_LIN_PASS(a));
+            else if (a.M <= 8) hipLaunchKernelGGL((k_gemv_gu24<true>), dim3(tiles / 3 * 2), dim3(512), 0, st, Q3_LIN_PASS(a));
             else hipLaunchKernelGGL((k_gemv_gu24<false>), dim3(tiles / 3 * 2), dim3(512), 0, st, Q3_LIN_PASS(a));
             return hipGetLastError();
         }
@@ -869,7 +876,8 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
     static const bool no_half = getenv("Q3_GEMV_NO_HALF") != nullptr;
     const bool half = a.M <= 8 && !no_half;
     if (four) {
-        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, true>), dim3(tiles), dim3(4 * 64), 0, st, Q3_LIN_PASS(a));
+        if (half && a.M <= 2) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, true, false>), dim3(tiles), dim3(4 * 64), 0, st, Q3_LIN_PASS(a));
+        else if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, true>), dim3(tiles), dim3(4 * 64), 0, st, Q3_LIN_PASS(a));
         else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 4, false>), dim3(tiles), dim3(4 * 64), 0, st, Q3_LIN_PASS(a));
         return hipGetLastError();
     }
@@ -877,7 +885,8 @@ static hipError_t launch_gemv_t(const LinArgs& a, hipStream_t st) {
         if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16, true>), dim3(tiles), dim3(16 * 64), 0, st, Q3_LIN_PASS(a));
         else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 16, false>), dim3(tiles), dim3(16 * 64), 0, st, Q3_LIN_PASS(a));
     } else {
-        if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, true>), dim3(tiles), dim3(8 * 64), 0, st, Q3_LIN_PASS(a));
+        if (half && a.M <= 2) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, true, false>), dim3(tiles), dim3(8 * 64), 0, st, Q3_LIN_PASS(a));
+        else if (half) hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, true>), dim3(tiles), dim3(8 * 64), 0, st, Q3_LIN_PASS(a));
         else hipLaunchKernelGGL((k_gemv_mfma<EPI, RMS, 8, false>), dim3(tiles), dim3(8 * 64), 0, st, Q3_LIN_PASS(a));
     }
     return hipGetLastError();
