@@ -571,11 +571,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             vo.f = *reinterpret_cast<const float4*>(a.vcache + base + (size_t)ps * HEAD_DIM);
         }
     };
-    KVReg kA, vA, kB, vB, kC, vC;
     const int p0 = start + grp;
-    request(p0, kA, vA);
-    request(p0 + 8, kB, vB);
-
     // folded gather (AttnArgs::g_*): this sequence's q|k|v row comes from the table row of the previous pass's argmax
     const float* qkv_row = a.qkv + (size_t)b * a.ld_qkv;
     if (a.g_logits) {
@@ -589,67 +585,81 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             if (tid == 0 && a.g_frame_idx[b] < a.g_max_frames) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
         }
     }
-    // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v)
-    for (int j = wave; j <= NREP; j += 4) {
-        const bool is_q = j < NREP;
-        const int scol = is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM;
-        const float* src = qkv_row + scol;
-        float x1, x2, pv1 = 0.f, pv2 = 0.f;
-        const bool from_slices = a.qkv_part && !a.g_logits;
-        if (from_slices) {          // the k job brings its v along: one round trip
+    // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v). The prologue's own loads go out FIRST (returns are counted in issue
+    // order: behind the K/V requests the prologue would wait for the whole stream), the K/V requests follow, then the arithmetic.
+    constexpr int NJ = (NREP + 1 + 3) / 4;
+    const bool from_slices = a.qkv_part && !a.g_logits;
+    float jx1[NJ], jx2[NJ], jv1[NJ], jv2[NJ], jn1[NJ], jn2[NJ];
+    const float rc = a.rope_cos[(size_t)pos * 64 + lane], rs = a.rope_sin[(size_t)pos * 64 + lane];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int j = wave + 4 * jj;
+        jx1[jj] = jx2[jj] = jv1[jj] = jv2[jj] = jn1[jj] = jn2[jj] = 0.0f;
+        if (j <= NREP) {
+            const bool is_q = j < NREP;
+            const int scol = is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM;
             const int vcol = QD + KD + kvh * HEAD_DIM;
-            const int cols[4] = {scol + lane, scol + lane + 64, is_q ? scol + lane : vcol + lane, is_q ? scol + lane + 64 : vcol + lane + 64};
-            float o[4]; qkv_from_slices<float, 4>(a, b, cols, o);
-            x1 = o[0]; x2 = o[1]; pv1 = o[2]; pv2 = o[3];
-        } else { x1 = src[lane]; x2 = src[lane + 64]; }
-        const float ss = wave_sum(x1 * x1 + x2 * x2);
-        const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
-        const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
-        x1 = x1 / den * nw[lane];
-        x2 = x2 / den * nw[lane + 64];
-        const float c = a.rope_cos[(size_t)pos * 64 + lane], sn = a.rope_sin[(size_t)pos * 64 + lane];
-        const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, sn));
-        const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
-        if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
-        else {
-            const float* vs = qkv_row + QD + KD + kvh * HEAD_DIM;
-            float v1, v2;
-            if (from_slices) { v1 = pv1; v2 = pv2; }
-            else { v1 = vs[lane]; v2 = vs[lane + 64]; }
-            if constexpr (KV16) {                  // the cache holds bf16: this position's K / V are what the cache will hold
-                const uint32_t b1 = bf16_rne(o1), b2 = bf16_rne(o2), c1 = bf16_rne(v1), c2 = bf16_rne(v2);
-                s_k[lane] = __uint_as_float(b1 << 16); s_k[lane + 64] = __uint_as_float(b2 << 16);
-                s_v[lane] = __uint_as_float(c1 << 16); s_v[lane + 64] = __uint_as_float(c2 << 16);
-                if (split == pos / chunk) {
-                    uint16_t* kc = reinterpret_cast<uint16_t*>(krow_paged(pos, pos, true)); uint16_t* vc = kc + pg_vd;
-                    kc[lane] = (uint16_t)b1; kc[lane + 64] = (uint16_t)b2; vc[lane] = (uint16_t)c1; vc[lane + 64] = (uint16_t)c2;
-                }
+            if (from_slices) {          // the k job brings its v along: one round trip
+                const int cols[4] = {scol + lane, scol + lane + 64, is_q ? scol + lane : vcol + lane, is_q ? scol + lane + 64 : vcol + lane + 64};
+                float o[4]; qkv_from_slices<float, 4>(a, b, cols, o);
+                jx1[jj] = o[0]; jx2[jj] = o[1]; jv1[jj] = o[2]; jv2[jj] = o[3];
             } else {
-            s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
-            if (split == pos / chunk) {
-                float* kc; float* vc;
-                if constexpr (PAGED != 0) { kc = krow_paged(pos, pos, true); vc = kc + pg_vd; }
-                else { kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM; vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM; }
-                kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
+                jx1[jj] = qkv_row[scol + lane]; jx2[jj] = qkv_row[scol + lane + 64];
+                if (!is_q) { jv1[jj] = qkv_row[vcol + lane]; jv2[jj] = qkv_row[vcol + lane + 64]; }
             }
-            }
+            const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
+            jn1[jj] = nw[lane]; jn2[jj] = nw[lane + 64];
         }
     }
-    zero_job(a.zero, a.zero_n, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z, tid, 256);
-    __syncthreads();
-    Q3T(1);
-
-    float4 q[NREP];
+    auto prologue_math = [&]() {
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) q[r] = *reinterpret_cast<const float4*>(&s_q[r][li * 4]);
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = wave + 4 * jj;
+            if (j > NREP) continue;
+            const bool is_q = j < NREP;
+            float x1 = jx1[jj], x2 = jx2[jj];
+            const float ss = wave_sum(x1 * x1 + x2 * x2);
+            const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
+            x1 = x1 / den * jn1[jj];
+            x2 = x2 / den * jn2[jj];
+            const float c = rc, sn = rs;
+            const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, sn));
+            const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
+            if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
+            else {
+                const float v1 = jv1[jj], v2 = jv2[jj];
+                if constexpr (KV16) {                  // the cache holds bf16: this position's K / V are what the cache will hold
+                    const uint32_t b1 = bf16_rne(o1), b2 = bf16_rne(o2), c1 = bf16_rne(v1), c2 = bf16_rne(v2);
+                    s_k[lane] = __uint_as_float(b1 << 16); s_k[lane + 64] = __uint_as_float(b2 << 16);
+                    s_v[lane] = __uint_as_float(c1 << 16); s_v[lane + 64] = __uint_as_float(c2 << 16);
+                    if (split == pos / chunk) {
+                        uint16_t* kc = reinterpret_cast<uint16_t*>(krow_paged(pos, pos, true)); uint16_t* vc = kc + pg_vd;
+                        kc[lane] = (uint16_t)b1; kc[lane + 64] = (uint16_t)b2; vc[lane] = (uint16_t)c1; vc[lane + 64] = (uint16_t)c2;
+                    }
+                } else {
+                    s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
+                    if (split == pos / chunk) {
+                        float* kc; float* vc;
+                        if constexpr (PAGED != 0) { kc = krow_paged(pos, pos, true); vc = kc + pg_vd; }
+                        else { kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM; vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM; }
+                        kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
+                    }
+                }
+            }
+        }
+        zero_job(a.zero, a.zero_n, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z, tid, 256);
+        __syncthreads();
+        Q3T(1);
+    };
+    float4 q[NREP];
     float m[NREP], l[NREP];
     float4 acc[NREP];
+    auto start_keys = [&]() {
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    // three register sets in rotation, the loop unrolled by three so that no set is ever copied: the rows of position
-    // p + 16 are requested before position p is consumed. (Batches of 8 keys per group all in flight at once — one round
-    // trip per batch — measured slower: 3.667 vs 3.609 ms/frame at B = 8; the 10-16 dummy requests of a short key range
-    // cost more than the round trips they save.)
+        for (int r = 0; r < NREP; ++r) q[r] = *reinterpret_cast<const float4*>(&s_q[r][li * 4]);
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    };
     auto consume = [&](int p, const KVReg& kr_, const KVReg& vr_) {
         float4 kk = kv_unpack(kr_), vv = kv_unpack(vr_);
         if (p == pos) {                                            // the new position: from LDS
@@ -669,12 +679,31 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             m[r] = mn;
         }
     };
-    for (int p = p0; p < end; p += 24) {
-        request(p + 16, kC, vC); consume(p, kA, vA);
-        if (p + 8 >= end) break;
-        request(p + 24, kA, vA); consume(p + 8, kB, vB);
-        if (p + 16 >= end) break;
-        request(p + 32, kB, vB); consume(p + 16, kC, vC);
+    {
+        // The first two cached K/V rows of this group are requested before the q/k-norm + RoPE arithmetic: they depend
+        // on nothing but `pos`, and their round trip then runs under the prologue instead of after its barrier (the new
+        // position itself comes from LDS after the barrier, never from the just-written global memory).
+        // Every request is UNCONDITIONAL (a position past the group's share, or the new position, reads row 0
+        // instead and the result is dropped): `s_waitcnt vmcnt` counts in issue order, so behind a load that sits in a
+        // conditional hipcc waits for everything in flight — with the prefetch guarded, and the three register sets rotated
+        // by copies, every key cost its own memory round trip.
+        KVReg kA, vA, kB, vB, kC, vC;
+        request(p0, kA, vA);
+        request(p0 + 8, kB, vB);
+        prologue_math();
+        start_keys();
+        // three register sets in rotation, the loop unrolled by three so that no set is ever copied: the rows of position
+        // p + 16 are requested before position p is consumed. (Batches of 8 keys per group all in flight at once — one round
+        // trip per batch — measured slower: 3.667 vs 3.609 ms/frame at B = 8; the 10-16 dummy requests of a short key range
+        // cost more than the round trips they save. Round 5, the whole range of a short session in flight at once, in exact batches
+        // of four per group and with the prologue's loads ahead of them: 2.675 vs 2.670 ms/frame at 300 frames, 2.80 vs 2.78 at 640.)
+        for (int p = p0; p < end; p += 24) {
+            request(p + 16, kC, vC); consume(p, kA, vA);
+            if (p + 8 >= end) break;
+            request(p + 24, kA, vA); consume(p + 8, kB, vB);
+            if (p + 16 >= end) break;
+            request(p + 32, kB, vB); consume(p + 16, kC, vC);
+        }
     }
     Q3T(2);
 #pragma unroll
