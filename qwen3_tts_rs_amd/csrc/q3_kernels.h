@@ -339,6 +339,22 @@ hipError_t launch_rvq_embed(const uint32_t* frames, int n_frames, const float* f
 hipError_t launch_norm_codebook(const float* esum, const float* usage, float* out, int rows, int dim, hipStream_t st);
 
 #if defined(__HIPCC__)
+// Separately rounded products / sums / differences (the reference's and the oracle's operation order: every product rounded before it is
+// added). ROCm's __fmul_rn / __fadd_rn / __fsub_rn are plain `x * y` / `x + y` / `x - y`, which hipcc is free to contract into an FMA with a
+// neighbouring operation — and did or did not from one template instance of the same source line to the next (the RoPE of k_attn_cp:
+// v_pk_fma_f32 in one instance, two roundings in the other). These carry no contract flag, so nothing fuses with them.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
 // zero side job (LinArgs::zero / AttnArgs::zero): workgroup `wg` of `nwg` clears its share with 16-byte stores
 // q|k|v columns col0 / col1 (.. +VEC-1) of activation row b from the slice sums (AttnArgs::qkv_part): the arithmetic of
 // k_wide_epilogue<EPI_NONE, RMS> — v = 0; v += slice s (ascending); v / sqrt(sum_s ssq / K + eps) — with every load of

@@ -32,7 +32,7 @@ __device__ __forceinline__ float sin_sq(float x) {
     const float s = fmaf(r * z, p, r);
     return s * s;
 }
-__device__ __forceinline__ float snake_f(float x, float a, float ib) { return __fadd_rn(x, __fmul_rn(sin_sq(x * a), ib)); }   // unfused, as the reference
+__device__ __forceinline__ float snake_f(float x, float a, float ib) { return add_rn(x, mul_rn(sin_sq(x * a), ib)); }   // unfused, as the reference
 
 // ------------------------------------------------------------------------------------------------
 // Generic causal conv1d:  y[co][t*ostride + ooff] = epi( b[co] + Σ_ci Σ_kk w[co][ci][kk] · f(x[ci][t-(k-1-kk)·dil]) )
@@ -1266,8 +1266,8 @@ __global__ __launch_bounds__(256) void k_rope_c(float* q, float* k, const float*
     float* p = blockIdx.z == 0 ? q : k;
     const size_t i1 = ((size_t)h * hd + i) * L + t, i2 = ((size_t)h * hd + i + half) * L + t;
     const float x1 = p[i1], x2 = p[i2];
-    p[i1] = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, s));
-    p[i2] = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+    p[i1] = add_rn(mul_rn(x1, c), mul_rn(-x2, s));
+    p[i2] = add_rn(mul_rn(x2, c), mul_rn(x1, s));
 }
 hipError_t launch_rope_c(float* q, float* k, const float* cs, const float* sn, int nh, int hd, int L, hipStream_t st) {
     hipLaunchKernelGGL(k_rope_c, dim3((L + 255) / 256, nh * hd / 2, 2), dim3(256), 0, st, q, k, cs, sn, hd, L);
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(256) void k_rvq_embed(const uint32_t* frames, int n
     for (int i = 0; i < 15; ++i) {
         uint32_t c = f[1 + i];
         if (c >= (uint32_t)cb_size) c = cb_size - 1;      // host validates; clamp keeps the read in-bounds
-        acc = __fadd_rn(acc, rest_cbs[i][(size_t)c * cb_dim + d]);
+        acc = add_rn(acc, rest_cbs[i][(size_t)c * cb_dim + d]);
     }
     rest_out[(size_t)d * n_frames + t] = acc;
 }

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(64) void k_qknorm_rope_kv(AttnArgs a) {
     x1 = x1 / den * nw[lane];
     x2 = x2 / den * nw[lane + 64];
     const float c = a.rope_cos[(size_t)pos * 64 + lane], s = a.rope_sin[(size_t)pos * 64 + lane];
-    const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, s));
-    const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+    const float o1 = sub_rn(mul_rn(x1, c), mul_rn(x2, s));
+    const float o2 = add_rn(mul_rn(x2, c), mul_rn(x1, s));
     if (is_q) {
         float* q = a.qbuf + ((size_t)b * a.nh + h) * HEAD_DIM;
         q[lane] = o1; q[lane + 64] = o2;
@@ -623,8 +623,8 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
             x1 = x1 / den * jn1[jj];
             x2 = x2 / den * jn2[jj];
             const float c = rc, sn = rs;
-            const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, sn));
-            const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
+            const float o1 = sub_rn(mul_rn(x1, c), mul_rn(x2, sn));
+            const float o2 = add_rn(mul_rn(x2, c), mul_rn(x1, sn));
             if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
             else {
                 const float v1 = jv1[jj], v2 = jv2[jj];
@@ -823,8 +823,8 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
         x1 = x1 / den * nw[lane];
         x2 = x2 / den * nw[lane + 64];
         const float c = a.rope_cos[(size_t)pos * 64 + lane], sn = a.rope_sin[(size_t)pos * 64 + lane];
-        const float o1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, sn));
-        const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
+        const float o1 = sub_rn(mul_rn(x1, c), mul_rn(x2, sn));
+        const float o2 = add_rn(mul_rn(x2, c), mul_rn(x1, sn));
         if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
         else {
             const float* vs = base + QD + KD + kvh * HEAD_DIM;
@@ -918,7 +918,7 @@ __device__ __forceinline__ float wave_sum_valu(float v) {                      /
 // Leading scalars = the 14 dwords every first request depends on, preloaded into SGPRs with the wave (see Q3_LIN_PRE in
 // q3_kernels_gemv.hip): K cache, q|k|v rows, this position's RoPE rows, the norm weights, V cache as a 32-bit float offset
 // from the K cache, and pos | max_seq << 8 | nh << 16 | nkv << 24.
-template <int NK>
+template <int NK, bool GATHER>      // GATHER: the folded gather of a pass's first layer (a.g_logits set)
 __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* p_qkv, const float* p_rc, const float* p_rs,
                                                 const float* p_qw, const float* p_kw, int p_vdelta, int p_pk, AttnArgs a_in) {
     AttnArgs a = a_in;
@@ -934,21 +934,26 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
     const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
     const int pos = a.pos_static;
     const size_t cache_base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM + 2 * lane;
-    // every cached row first (they depend on nothing): slot p >= pos re-reads row 0, which always exists and is finite
+    // The cached rows depend on nothing; slot p >= pos re-reads row 0, which always exists and is finite. GATHER: requested first,
+    // under the argmax chain that finds the q | k | v row. Otherwise BEHIND q | k | v: returns are counted in issue order, and ahead
+    // of them the norm + RoPE arithmetic waited for all 2 NK cache rows as well (they are not needed before the scores).
     float2 kc[NK], vc[NK];
+    auto request_cache = [&]() {
 #pragma unroll
-    for (int p = 0; p < NK; ++p) {
-        const size_t ro = cache_base + (size_t)(p < pos ? p : 0) * HEAD_DIM;
-        kc[p] = *reinterpret_cast<const float2*>(a.kcache + ro);
-        vc[p] = *reinterpret_cast<const float2*>(a.vcache + ro);
-    }
+        for (int p = 0; p < NK; ++p) {
+            const size_t ro = cache_base + (size_t)(p < pos ? p : 0) * HEAD_DIM;
+            kc[p] = *reinterpret_cast<const float2*>(a.kcache + ro);
+            vc[p] = *reinterpret_cast<const float2*>(a.vcache + ro);
+        }
+    };
+    if constexpr (GATHER) request_cache();
     const float2 qw = *reinterpret_cast<const float2*>(a.q_norm_w + 2 * lane);
     const float2 kw = *reinterpret_cast<const float2*>(a.k_norm_w + 2 * lane);
     const int ri = (2 * lane) & 63;                  // p_rc / p_rs point at this position's rows of the RoPE tables
     const float2 rc = *reinterpret_cast<const float2*>(p_rc + ri), rs = *reinterpret_cast<const float2*>(p_rs + ri);
 
     const float* qkv_row = a.qkv + (size_t)b * a.ld_qkv;
-    if (a.g_logits) {            // folded gather (AttnArgs::g_*): the row is the argmax of the previous pass's logits
+    if constexpr (GATHER) {      // folded gather (AttnArgs::g_*): the row is the argmax of the previous pass's logits
         const float* lg = a.g_logits + (size_t)b * a.g_vocab;
         float bv = -INFINITY; int bi = 0x7fffffff;
         auto take4 = [&](const float4& v, int j) {
@@ -989,7 +994,7 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         }
     }
     float2 q, k, v;
-    if (a.qkv_part && !a.g_logits) {      // wide sessions: the slice sums of the split-K GEMM (see AttnArgs::qkv_part)
+    if (!GATHER && a.qkv_part) {      // wide sessions: the slice sums of the split-K GEMM (see AttnArgs::qkv_part)
         const int cols[3] = {h * HEAD_DIM + 2 * lane, QD + kvh * HEAD_DIM + 2 * lane, QD + KD + kvh * HEAD_DIM + 2 * lane};
         float2 o[3]; qkv_from_slices<float2, 3>(a, b, cols, o);        // all 24 slice loads of the lane in flight at once
         q = o[0]; k = o[1]; v = o[2];
@@ -998,6 +1003,7 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         k = *reinterpret_cast<const float2*>(qkv_row + QD + kvh * HEAD_DIM + 2 * lane);
         v = *reinterpret_cast<const float2*>(qkv_row + QD + KD + kvh * HEAD_DIM + 2 * lane);
     }
+    if constexpr (!GATHER) request_cache();
 
     Q3T_W(1);
     // side job behind the last load (vmcnt retires in issue order: a store ahead of the loads would sit in front of every wait for them)
@@ -1005,12 +1011,14 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
     // per-head RMSNorm (x / sqrt(mean + eps) * w) and rotate-half RoPE with separately rounded products
     const bool upper = lane >= 32, odd_row = (lane & 16) != 0;
     auto norm_rope = [&](float2 x, const float2& w) {
-        const float den = sqrtf(wave_sum_valu(x.x * x.x + x.y * x.y) / (float)HEAD_DIM + a.eps);
+        // (the fused forms are written out here and below: left to the compiler, the GATHER instance took v_pk_mul + add — both products
+        // rounded — where the other took mul + fma, and the two instances of one source line disagreed in the last place)
+        const float den = sqrtf(wave_sum_valu(fmaf(x.x, x.x, x.y * x.y)) / (float)HEAD_DIM + a.eps);
         x.x = x.x / den * w.x; x.y = x.y / den * w.y;
         const float px = lane_xor32(x.x, upper), py = lane_xor32(x.y, upper);     // the d +- 64 partner
         float2 o;
-        if (upper) { o.x = __fadd_rn(__fmul_rn(x.x, rc.x), __fmul_rn(px, rs.x)); o.y = __fadd_rn(__fmul_rn(x.y, rc.y), __fmul_rn(py, rs.y)); }
-        else       { o.x = __fsub_rn(__fmul_rn(x.x, rc.x), __fmul_rn(px, rs.x)); o.y = __fsub_rn(__fmul_rn(x.y, rc.y), __fmul_rn(py, rs.y)); }
+        if (upper) { o.x = add_rn(mul_rn(x.x, rc.x), mul_rn(px, rs.x)); o.y = add_rn(mul_rn(x.y, rc.y), mul_rn(py, rs.y)); }
+        else       { o.x = sub_rn(mul_rn(x.x, rc.x), mul_rn(px, rs.x)); o.y = sub_rn(mul_rn(x.y, rc.y), mul_rn(py, rs.y)); }
         return o;
     };
     q = norm_rope(q, qw);
@@ -1025,7 +1033,7 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
 #pragma unroll
     for (int p = 0; p < NK; ++p) {
         const float2 kk = p == pos ? k : kc[p];
-        s[p] = q.x * kk.x + q.y * kk.y;
+        s[p] = fmaf(q.x, kk.x, q.y * kk.y);
     }
     // Reduce the NK per-lane partials over the 64 lanes. Across the two row pairs the butterfly TRANSPOSES while more than four
     // values are alive (a lane hands half of its values to lane ^ 32 / ^ 16 and keeps the other half), the last four are summed
@@ -1064,7 +1072,7 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         const float wp = read_lane(w4[p & 3], NK == 16 ? 16 * (p >> 2) : NK == 8 ? 32 * (p >> 2) : 0);     // the row that holds key p
         const float2 vv = p == pos ? v : vc[p];
         L += wp;
-        acc.x += wp * vv.x; acc.y += wp * vv.y;
+        acc.x = fmaf(wp, vv.x, acc.x); acc.y = fmaf(wp, vv.y, acc.y);
     }
     Q3T(2);
     *reinterpret_cast<float2*>(a.out + (size_t)b * a.ld_out + h * HEAD_DIM + 2 * lane) = make_float2(acc.x / L, acc.y / L);
@@ -1087,7 +1095,8 @@ hipError_t launch_attn_cp(const AttnArgs& a, hipStream_t st) {
     dim3 grid(a.nh, a.B);
     const float* rc = a.rope_cos + (size_t)a.pos_static * 64; const float* rs = a.rope_sin + (size_t)a.pos_static * 64;
     const int vdelta = (int)(a.vcache - a.kcache), pk = a.pos_static | (a.max_seq << 8) | (a.nh << 16) | (a.nkv << 24);
-#define Q3_ACP(NK) hipLaunchKernelGGL(k_attn_cp<NK>, grid, dim3(64), 0, st, (const float*)a.kcache, a.qkv, rc, rs, a.q_norm_w, a.k_norm_w, vdelta, pk, a)
+#define Q3_ACP(NK) if (a.g_logits) hipLaunchKernelGGL((k_attn_cp<NK, true>), grid, dim3(64), 0, st, (const float*)a.kcache, a.qkv, rc, rs, a.q_norm_w, a.k_norm_w, vdelta, pk, a); \
+                   else hipLaunchKernelGGL((k_attn_cp<NK, false>), grid, dim3(64), 0, st, (const float*)a.kcache, a.qkv, rc, rs, a.q_norm_w, a.k_norm_w, vdelta, pk, a)
     if (a.pos_static < 4) Q3_ACP(4); else if (a.pos_static < 8) Q3_ACP(8); else Q3_ACP(16);
 #undef Q3_ACP
     return hipGetLastError();
@@ -1188,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_assemble_rows(const float* rows, const 
             // ICL reference frame: codec_emb[c0] + e0[c1] + … + e14[c15], left to right (lib.rs:1239-1257)
             const uint32_t* fr = ref_codes + (size_t)(-3 - cid) * 16;
             cv = bf16_to_f32(codec_emb[(size_t)fr[0] * H + c]);
-            for (int g = 1; g < 16; ++g) cv = __fadd_rn(cv, bf16_to_f32(cp_embs[g - 1][(size_t)fr[g] * H + c]));
+            for (int g = 1; g < 16; ++g) cv = add_rn(cv, bf16_to_f32(cp_embs[g - 1][(size_t)fr[g] * H + c]));
         } else cv = 0.0f;
         if (tr >= 0 && cid != -1) v = rows[(size_t)tr * H + c] + cv;       // text.add(codec)  (talker.rs:480, 694, 706, 782)
         else if (tr >= 0) v = rows[(size_t)tr * H + c];
@@ -1318,9 +1327,9 @@ __global__ __launch_bounds__(256) void k_frame_embed(FrameEmbedArgs a) {
         const float sv = bf16_to_f32(sem[c]), tv = text[c];
         float acc = e[0];
 #pragma unroll
-        for (int g = 1; g < 15; ++g) if (g < a.n_acoustic) acc = __fadd_rn(acc, e[g]);
-        const float summed = __fadd_rn(sv, acc);
-        a.out[(size_t)b * H + c] = __fadd_rn(summed, tv);
+        for (int g = 1; g < 15; ++g) if (g < a.n_acoustic) acc = add_rn(acc, e[g]);
+        const float summed = add_rn(sv, acc);
+        a.out[(size_t)b * H + c] = add_rn(summed, tv);
     }
 }
 hipError_t launch_frame_embed(const FrameEmbedArgs& a, hipStream_t st) {
@@ -1381,10 +1390,10 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
         float v = -INFINITY;
         if (i < V) {
             v = lg[i];
-            if (a.use_rep && seen && seen[i]) v = __fmul_rn(v, v > 0.0f ? a.rep_inv : a.rep_pen);
+            if (a.use_rep && seen && seen[i]) v = mul_rn(v, v > 0.0f ? a.rep_inv : a.rep_pen);
             if (a.use_suppress && i >= V - 1024 && i != a.codec_eos) v = -INFINITY;
             if (tc < a.min_new_tokens && i == a.eos_id) v = -INFINITY;
-            if (a.apply_temp) v = __fadd_rn(__fmul_rn(v, a.inv_temp), 0.0f);
+            if (a.apply_temp) v = add_rn(mul_rn(v, a.inv_temp), 0.0f);
         }
         s_val[i] = v; s_idx[i] = (uint16_t)i;
     }

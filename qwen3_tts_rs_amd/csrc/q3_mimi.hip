@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_mimi_rvq(const float* __restrict__ proj
         for (int e = tid; e < CB; e += 256) {
             const float* ev = book + (size_t)e * CD;
             float d2 = 0.0f;
-            for (int d = 0; d < CD; ++d) { const float df = __fsub_rn(r[d], ev[d]); d2 = __fadd_rn(d2, __fmul_rn(df, df)); }
+            for (int d = 0; d < CD; ++d) { const float df = sub_rn(r[d], ev[d]); d2 = add_rn(d2, mul_rn(df, df)); }
             if (d2 < best) { best = d2; bidx = e; }            // ascending e per thread: the first minimum stays
         }
         bd[tid] = best; bi[tid] = bidx;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_mimi_rvq(const float* __restrict__ proj
         }
         const int win = bi[0];
         if (tid == 0) codes[(size_t)t * n_q + q0 + l] = (uint32_t)win;
-        if (tid < CD) r[tid] = __fsub_rn(r[tid], book[(size_t)win * CD + tid]);
+        if (tid < CD) r[tid] = sub_rn(r[tid], book[(size_t)win * CD + tid]);
         __syncthreads();
     }
 }

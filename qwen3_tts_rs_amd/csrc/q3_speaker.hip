@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_spk_stft_mel(const float* __restrict__ 
         long idx = p;
         if (p < 0) idx = (-p < n) ? -p : n - 1;                       // mel.rs:176-183
         else if (p >= n) { const long i = p - n; idx = (n >= 2 + i) ? n - 2 - i : 0; }   // mel.rs:185-192
-        buf[j] = __fmul_rn(x[idx], win[j]);
+        buf[j] = mul_rn(x[idx], win[j]);
         tc[j] = cs[j]; ts[j] = sn[j];
     }
     __syncthreads();
@@ -64,13 +64,13 @@ __global__ __launch_bounds__(256) void k_spk_stft_mel(const float* __restrict__ 
             re += v * tc[idx]; im -= v * ts[idx];
         }
         const float rf = (float)re, jf = (float)im;
-        mag[k] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rf, rf), __fmul_rn(jf, jf)), 1e-9f));
+        mag[k] = sqrtf(add_rn(add_rn(mul_rn(rf, rf), mul_rn(jf, jf)), 1e-9f));
     }
     __syncthreads();
     for (int m = tid; m < n_mels; m += 256) {
         const float* row = fb + (size_t)m * NB;
         float acc = 0.0f;
-        for (int k = 0; k < NB; ++k) acc = __fadd_rn(acc, __fmul_rn(row[k], mag[k]));
+        for (int k = 0; k < NB; ++k) acc = add_rn(acc, mul_rn(row[k], mag[k]));
         mel[(size_t)m * T + f] = logf(fmaxf(acc, 1e-5f));
     }
 }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_spk_mean(const float* __restrict__ x, f
 // h = o * g[c] + h (SE excite + the block's residual, speaker.rs:224-226, 270-271)
 __global__ __launch_bounds__(256) void k_spk_se_apply(const float* __restrict__ o, const float* __restrict__ g, float* __restrict__ h, int T) {
     const int c = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
-    if (t < T) { const size_t e = (size_t)c * T + t; h[e] = __fadd_rn(__fmul_rn(o[e], g[c]), h[e]); }
+    if (t < T) { const size_t e = (size_t)c * T + t; h[e] = add_rn(mul_rn(o[e], g[c]), h[e]); }
 }
 // attention input of the pooling (speaker.rs:303-316): rows [x ; mean ; std] with std = sqrt(mean((x-mean)²) + 1e-5)
 __global__ __launch_bounds__(256) void k_spk_asp_in(const float* __restrict__ m, float* __restrict__ ain, int C, int T) {
