@@ -41,3 +41,13 @@ for i, (s, e, name, g, w) in enumerate(seg):
 print(f"{'kernel':44s} {'WGs':>6s} {'thr':>5s} {'calls':>8s} {'/frame':>7s} {'avg us':>8s} {'gap us':>7s} {'ms/frame':>9s} {'%busy':>6s}")
 for (short, wgs, w), (n, t, gp) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{short:44s} {wgs:6d} {w:5d} {n:8d} {n/max(frames,1):7.1f} {t/n/1e3:8.2f} {gp/n/1e3:7.2f} {(t+gp)/max(frames,1)/1e6:9.4f} {100*t/busy:6.2f}")
+# Q3_PROF_SEQ=1: the launch order of ONE frame from the middle of the steady segment (duration and the gap after each launch)
+import os
+if os.environ.get("Q3_PROF_SEQ") and nsamp > 4:
+    si = [i for i, r in enumerate(seg) if "k_sample" in r[2]]
+    a0, a1 = si[len(si) // 2] , si[len(si) // 2 + 1]
+    print(f"\none frame, launch order (k_sample .. the launch before the next k_sample): {a1 - a0} launches")
+    for i in range(a0, a1):
+        s, e, name, g, w = seg[i]
+        short = name.replace("(anonymous namespace)::", "").replace("void q3::", "").replace("q3::", "").replace("void ", "").split("(")[0]
+        print(f"{i - a0:4d} {short:46s} {g // max(w, 1):5d} WGs {(e - s)/1e3:7.2f} us  gap {(seg[i + 1][0] - e)/1e3:6.2f}")
