@@ -1518,7 +1518,28 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
         __syncthreads();
         }   // !sorted
         const int n_keep = s_keep;
-        if (tid == 0) {
+        // The reference's sequential sums (softmax denominator and running probability over the sorted row, sampling.rs:229-262),
+        // in the same order. Up to 64 kept entries (top-k 50: always, ties aside) one WAVE does them: lane l computes its own
+        // exp / quotient, and the running sum walks the lanes with v_readlane — an add per entry instead of an LDS round trip + expf
+        // (+ a division) per entry behind one thread: 4 + 2.5 us of a 22 us launch. More entries: the one-thread loops.
+        if (n_keep <= 64) {
+            if (tid < 64) {
+                int cut = n_keep;
+                if (a.use_top_p) {
+                    const float mx = s_val[0];
+                    const float e = tid < n_keep ? expf(s_val[tid] - mx) : 0.0f;
+                    float sum = 0.0f;
+                    for (int i = 0; i < n_keep; ++i) sum += read_lane(e, i);
+                    const float pr = e / sum;
+                    float cum = 0.0f;
+                    for (int i = 0; i < n_keep; ++i) {
+                        cum += read_lane(pr, i);
+                        if (cum > a.top_p) { cut = i + 1; break; }
+                    }
+                }
+                if (tid == 0) s_cut = cut;
+            }
+        } else if (tid == 0) {
             int cut = n_keep;
             if (a.use_top_p) {
                 const float mx = s_val[0];
@@ -1543,7 +1564,24 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
             s_oidx[rank] = (uint16_t)me;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (cut <= 64) {      // final softmax + inverse CDF in vocabulary order (sampling.rs:264-319), the same way
+            if (tid < 64) {
+                const float mx = s_val[0];
+                const float e = tid < cut ? expf(s_oval[tid] - mx) : 0.0f;
+                float sum = 0.0f;
+                for (int r = 0; r < cut; ++r) sum += read_lane(e, r);
+                const float pr = e / sum;
+                const float u = read_lane(u_pre, 0);
+                float cdf = 0.0f; int hit = -1;
+                if (u > 0.0f) {
+                    for (int r = 0; r < cut; ++r) {
+                        cdf += read_lane(pr, r);
+                        if (cdf >= u) { hit = r; break; }
+                    }
+                }
+                if (tid == 0) s_pick = hit >= 0 ? (int)s_oidx[hit] : 0;
+            }
+        } else if (tid == 0) {
             const float mx = s_val[0];
             float sum = 0.0f;
             for (int r = 0; r < cut; ++r) sum += expf(s_oval[r] - mx);
