@@ -70,10 +70,13 @@ for i in range(N):
         dr = (d - t0) * 0.01; dr[d == 0] = np.nan
         l2 = dr[:, :, 2][dok]; r["w2"] = (float(np.nanmin(l2)), float(np.nanmedian(l2)), float(np.nanmax(l2)))
         e0 = dr[:, :, 0][dok]; r["w0x"] = float(np.nanmax(e0))
-        b5 = dr[:, :, 5][dok]; r["w5"] = float(np.nanmedian(b5)) if np.isfinite(b5).any() else np.nan
-        w6 = dr[:, :, 6][dok]; r["w6x"] = float(np.nanmax(w6)) if np.isfinite(w6).any() else np.nan
-        s3 = dr[:, 0, 3]; s5 = dr[:, 0, 5]
-        r["tail"] = float(np.nanmedian(s3 - s5)) if np.isfinite(s3 - s5).any() else np.nan
+        if meta[i][0] == 1:      # attn_cp: slots 5 / 6 hold clock64() counters (the shader-clock line below), not time stamps
+            r["w5"] = r["w6x"] = r["tail"] = np.nan
+        else:
+            b5 = dr[:, :, 5][dok]; r["w5"] = float(np.nanmedian(b5)) if np.isfinite(b5).any() else np.nan
+            w6 = dr[:, :, 6][dok]; r["w6x"] = float(np.nanmax(w6)) if np.isfinite(w6).any() else np.nan
+            s3 = dr[:, 0, 3]; s5 = dr[:, 0, 5]
+            r["tail"] = float(np.nanmedian(s3 - s5)) if np.isfinite(s3 - s5).any() else np.nan
     prev_out = t0 + int(round(out * 100))
     rows.append(r)
 
