@@ -433,12 +433,16 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
     const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
 
-    float pre = 0.0f;                                // bias + residual of the k = 0 half, requested up front
+    // bias and residual of the k = 0 half, requested up front — and NOT combined here: `resid + bias` at this point made the compiler wait
+    // (s_waitcnt vmcnt(0)) for both before the first x / weight request went out, a whole round trip at the head of waves 0-3 of every
+    // k = 0 workgroup (the residual was written two nodes ago and comes back across the XCDs). They are added behind the barrier, in
+    // the same order: (resid + bias) + sum.
+    float pre_b = 0.0f, pre_r = 0.0f;
     {
         const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
         if (half == 0 && tid < 256 && col < a.M && n < a.N) {
-            if (a.bias) pre = a.bias[n];
-            if constexpr (EPI == EPI_RESID) pre = a.resid[(size_t)col * a.ldr + n] + pre;
+            if (a.bias) pre_b = a.bias[n];
+            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
         }
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f};
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
             float v = 0.0f;
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w) v += red[w][tid];
-            if (half == 0) v = pre + v;
+            if (half == 0) { const float pre = EPI == EPI_RESID ? pre_r + pre_b : pre_b; v = pre + v; }
             unsafeAtomicAdd(&a.y[(size_t)col * a.ldy + n], v);
         }
     }
