@@ -437,12 +437,19 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     // (s_waitcnt vmcnt(0)) for both before the first x / weight request went out, a whole round trip at the head of waves 0-3 of every
     // k = 0 workgroup (the residual was written two nodes ago and comes back across the XCDs). They are added behind the barrier, in
     // the same order: (resid + bias) + sum.
+    // This kernel has no second matrix, no fused norm and its epilogue is a template parameter, so launch_gemv_sk2 sends the RESIDUAL pointer in
+    // the W2 slot, the BIAS pointer in the norm-weight slot and the residual's row pitch in the epi slot of the 14 preloaded dwords: the two
+    // requests then need nothing from the argument struct, whose scalar load otherwise stands in front of them (and of the first x request
+    // behind them) in waves 0-3 of every k = 0 workgroup.
+    const float* __restrict__ rp = reinterpret_cast<const float*>(pW2);
+    const float* __restrict__ bp = pnw;
+    const int ldr_pre = pepi;
     float pre_b = 0.0f, pre_r = 0.0f;
     {
         const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
-        if (half == 0 && tid < 256 && col < a.M && n < a.N) {
-            if (a.bias) pre_b = a.bias[n];
-            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
+        if (half == 0 && tid < 256 && col < pM - (MB ? (int)blockIdx.z * 16 : 0) && n < pN) {
+            if (bp) pre_b = bp[n];
+            if constexpr (EPI == EPI_RESID) pre_r = rp[(size_t)(col + (MB ? (int)blockIdx.z * 16 : 0)) * ldr_pre + n];
         }
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f};
@@ -514,10 +521,12 @@ static hipError_t launch_gemv_sk2(const LinArgs& a, hipStream_t st) {
     const dim3 grid(tiles, 2, (a.M + 15) / 16), blk(512);     // M > 16 (wide sessions): one grid plane per 16 rows
     const bool g6 = ((S / 2) % 48) == 0;             // a wave's slice is a multiple of 6 k-steps (K = 3072, 6144): no ragged group
     const bool half = a.M <= 8;
-#define Q3_SK2(E, GG, H) hipLaunchKernelGGL((k_gemv_sk2<E, GG, H>), grid, blk, 0, st, Q3_LIN_PASS(a))
+    // preloaded slots of this family: W2 = residual, norm weight = bias, epi = residual row pitch (see the kernel)
+#define Q3_SK2_PASS a.W, reinterpret_cast<const uint16_t*>(a.resid), a.x, a.bias, a.M, a.N, a.K, a.Kpad, a.ldx, a.ldr, a
+#define Q3_SK2(E, GG, H) hipLaunchKernelGGL((k_gemv_sk2<E, GG, H>), grid, blk, 0, st, Q3_SK2_PASS)
     if (a.M > 16) {                                  // row blocks: full 16-column tiles only
-        if (a.epi == EPI_RESID) { if (g6) hipLaunchKernelGGL((k_gemv_sk2<EPI_RESID, 6, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); else hipLaunchKernelGGL((k_gemv_sk2<EPI_RESID, 4, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); }
-        else { if (g6) hipLaunchKernelGGL((k_gemv_sk2<EPI_NONE, 6, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); else hipLaunchKernelGGL((k_gemv_sk2<EPI_NONE, 4, false, true>), grid, blk, 0, st, Q3_LIN_PASS(a)); }
+        if (a.epi == EPI_RESID) { if (g6) hipLaunchKernelGGL((k_gemv_sk2<EPI_RESID, 6, false, true>), grid, blk, 0, st, Q3_SK2_PASS); else hipLaunchKernelGGL((k_gemv_sk2<EPI_RESID, 4, false, true>), grid, blk, 0, st, Q3_SK2_PASS); }
+        else { if (g6) hipLaunchKernelGGL((k_gemv_sk2<EPI_NONE, 6, false, true>), grid, blk, 0, st, Q3_SK2_PASS); else hipLaunchKernelGGL((k_gemv_sk2<EPI_NONE, 4, false, true>), grid, blk, 0, st, Q3_SK2_PASS); }
         return hipGetLastError();
     }
     if (a.epi == EPI_RESID) {
@@ -528,6 +537,7 @@ static hipError_t launch_gemv_sk2(const LinArgs& a, hipStream_t st) {
         else    { if (half) Q3_SK2(EPI_NONE, 4, true); else Q3_SK2(EPI_NONE, 4, false); }
     }
 #undef Q3_SK2
+#undef Q3_SK2_PASS
     return hipGetLastError();
 }
 
