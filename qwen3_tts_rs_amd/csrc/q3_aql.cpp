@@ -304,10 +304,15 @@ struct AqlProgram {
     std::vector<hsa_kernel_dispatch_packet_t> pk;        // templates (header / setup filled, completion signal empty)
     void* kernargs = nullptr;                            // device memory, one block per node
     hsa_signal_t done{}; bool pending = false;
+    int n_acq_free = 0, n_rel_free = 0;                  // nodes submitted without their acquire / release fence (node_policy)
     bool dead = false;      // a submission timed out: the ring may hold a partial burst without a completion signal — never submit or wait again
 };
 
 int aql_program_nodes(const AqlProgram* p) { return p ? (int)p->pk.size() : 0; }
+void aql_program_fence_free(const AqlProgram* p, int* acquire_free, int* release_free) {
+    if (acquire_free) *acquire_free = p ? p->n_acq_free : 0;
+    if (release_free) *release_free = p ? p->n_rel_free : 0;
+}
 
 void aql_program_destroy(AqlProgram* p) {
     if (!p) return;
@@ -382,7 +387,10 @@ AqlProgram* aql_program_create(hipGraph_t graph, int device, const AqlPolicy& po
             else { *why = std::string(nm) + " uses " + k + " (not provided by this submission path)"; return nullptr; }
         }
         hsa_kernel_dispatch_packet_t pk; memset(&pk, 0, sizeof pk);
-        const int acq = pol.acquire ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, rel = pol.release ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
+        int want_acq = pol.acquire, want_rel = pol.release;
+        if (pol.node_policy) pol.node_policy(nm, &want_acq, &want_rel);
+        const int acq = want_acq ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, rel = want_rel ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
+        p->n_acq_free += want_acq ? 0 : 1; p->n_rel_free += want_rel ? 0 : 1;
         pk.header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         pk.setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
@@ -393,6 +401,12 @@ AqlProgram* aql_program_create(hipGraph_t graph, int device, const AqlPolicy& po
         p->pk.push_back(pk); arg_off.push_back(base);
     }
     if (p->pk.empty()) { *why = "graph holds no kernel node"; return nullptr; }
+    if (pol.node_policy) {
+        // frame boundary: whatever crosses frames (counters, positions, the talker's K/V, codes) moves with plain accesses
+        auto set = [](uint16_t& h, int shift) { h = (uint16_t)((h & ~(3u << shift)) | ((unsigned)HSA_FENCE_SCOPE_AGENT << shift)); };
+        set(p->pk.front().header, HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
+        set(p->pk.back().header, HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    }
     if (hipMalloc(&p->kernargs, host_args.size()) != hipSuccess) { *why = "hipMalloc(kernargs) failed"; return nullptr; }
     if (hipMemcpy(p->kernargs, host_args.data(), host_args.size(), hipMemcpyHostToDevice) != hipSuccess) { *why = "hipMemcpy(kernargs) failed"; aql_program_destroy(p.release()); return nullptr; }
     for (size_t i = 0; i < p->pk.size(); ++i) p->pk[i].kernarg_address = (char*)p->kernargs + arg_off[i];

@@ -2335,11 +2335,13 @@ static q3_status prefill_ragged(q3_session* s) {
         int S0 = 0, L = 0; request_shape(s->ragged[(size_t)b0].r, &S0, &L);
         std::vector<int> rows; std::vector<q3_request> reqs; std::vector<int> limits;
         for (int b = b0; b < B; ++b) {
-            int S = 0; request_shape(s->ragged[(size_t)b].r, &S, &L);
+            int S = 0, Lb = 0; request_shape(s->ragged[(size_t)b].r, &S, &Lb);
             if (placed[(size_t)b] || S != S0) continue;
             q3_request r = s->ragged[(size_t)b].r;
-            if (r.opts.max_length < 1 || r.opts.max_length > s->max_frames) { s->prefilled = false; return set_err(Q3_INVALID_ARG, "row %d: max_length %d outside 1..%d", b, r.opts.max_length, s->max_frames); }
-            limits.push_back(r.opts.max_length);
+            // the row's RESOLVED limit (an ICL row's max_length is capped at max(75, 6 * n_text), talker.rs:646-710 / lib.rs:897-1046) is
+            // what session_create_any sized max_frames for — the raw max_length of an ICL row may well exceed it
+            if (r.opts.max_length < 1 || Lb < 1 || Lb > s->max_frames) { s->prefilled = false; return set_err(Q3_INVALID_ARG, "row %d: max_length %d (resolved %d) outside 1..%d", b, r.opts.max_length, Lb, s->max_frames); }
+            limits.push_back(Lb);
             r.opts.max_length = s->max_frames;           // the side session draws the row's PCG stream with the host session's stride
             rows.push_back(b); reqs.push_back(r); placed[(size_t)b] = 1;
         }
@@ -2520,6 +2522,34 @@ static int session_remaining(const q3_session* s) {
     return r;
 }
 
+// Which kernels of the frame keep to the activation-transport rule of q3_kernels.h (write-through + drained stores, L1-bypassing
+// loads of everything an earlier node of the same frame wrote, nothing of it through the scalar cache): their packets go out
+// without the agent-scope acquire / release fences (q3_aql.h). Anything not named here keeps HIP's fences — a kernel added to
+// the frame later is safe by default. Development switches: Q3_AQL_T_ACQ=0 / Q3_AQL_T_REL=0 keep that half of every boundary,
+// Q3_AQL_T_ONLY=<substring+substring> restricts the rule to kernels whose name holds one of the substrings (bisecting).
+static void frame_fence_policy(const char* name, int* acquire, int* release) {
+    static const char* const families[] = {"k_gemv_mfmaI", "k_gemv_sk2I", "k_gemv_gu24I", "k_gemv_ldsI", "k_gemv_mfma4I",
+                                           "k_attn_cpI", "k_attn_fusedI", "k_attn_mergeI", "k_attn_first2I"};
+    const bool drop_acq = !(getenv("Q3_AQL_T_ACQ") && atoi(getenv("Q3_AQL_T_ACQ")) == 0);
+    const bool drop_rel = !(getenv("Q3_AQL_T_REL") && atoi(getenv("Q3_AQL_T_REL")) == 0);
+    const std::string only = getenv("Q3_AQL_T_ONLY") ? getenv("Q3_AQL_T_ONLY") : "";
+    bool conv = false;
+    for (const char* f : families) conv = conv || strstr(name, f) != nullptr;
+    if (conv && !only.empty()) {
+        bool hit = false; size_t i = 0;
+        while (i <= only.size()) {
+            const size_t j = only.find_first_of(",+", i); const std::string t = only.substr(i, j == std::string::npos ? std::string::npos : j - i);
+            if (!t.empty() && strstr(name, t.c_str())) hit = true;
+            if (j == std::string::npos) break;
+            i = j + 1;
+        }
+        conv = hit;
+    }
+    if (!conv) return;
+    if (drop_acq) *acquire = 0;
+    if (drop_rel) *release = 0;
+}
+
 extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_graph) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
@@ -2558,6 +2588,7 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         if (mode > 0) {
             q3::AqlPolicy pol; pol.fence = mode == 2 ? 0 : 1;
             pol.acquire = pol.release = pol.fence;
+            if (mode == 3) pol.node_policy = frame_fence_policy;      // fence-free boundaries between the kernels that move their data write-through
             if (unsafe_ok) {
                 if (const char* a = getenv("Q3_AQL_ACQ")) pol.acquire = atoi(a);        // probes: the two fences of a boundary priced separately
                 if (const char* r = getenv("Q3_AQL_REL")) pol.release = atoi(r);
@@ -2565,7 +2596,7 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
             }
             std::string why;
             s->aql = q3::aql_program_create(s->graph, s->m->device, pol, &why);
-            if (s->aql) s->aql_mode = mode == 2 ? 2 : 1;
+            if (s->aql) s->aql_mode = mode == 2 ? 2 : mode == 3 ? 3 : 1;
             else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
         }
     }

@@ -355,21 +355,70 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
 #pragma clang fp contract(off)
     return a - b;
 }
-// zero side job (LinArgs::zero / AttnArgs::zero): workgroup `wg` of `nwg` clears its share with 16-byte stores
+// ---- activation transport of the frame (round 6) --------------------------------------------------------------
+// Everything one kernel of a frame hands to a LATER kernel of the same frame (activations, the code predictor's K/V rows,
+// logits, partial records, zeroed split-K targets) is stored WRITE-THROUGH (sc1: the bytes leave the XCD's L2 for the fabric,
+// where the other XCDs' L2s are kept coherent) and drained (act_drain: s_waitcnt vmcnt(0) before the wave ends), and is read
+// with sc1 loads (never served by a CU's vector L1, the one cache no other CU's store ever refreshes). Between two kernels
+// that both keep to this, a packet boundary needs neither the release fence (L2 write-back) nor the acquire fence (L1 / scalar
+// cache invalidate) HIP puts on every packet — the library's own queue (q3_aql.cpp) then submits those nodes without them,
+// which is worth ~0.3 us per dependent node. The accesses are also correct WITH the fences: hipGraphLaunch replays the
+// very same kernels. A 16-byte access is a raw buffer load / store with the sc1 cache policy (aux = 16) through a descriptor of
+// the array's base pointer (a relaxed agent-scope __hip_atomic_load / store lowers to an sc1 access only up to 8 bytes).
+// What must NOT go through these: anything the scalar unit fetches (s_load is served by the scalar cache, which only the
+// acquire fence invalidates) — per-frame counters are written by the frame's last kernel and the first packet of every frame
+// keeps its acquire fence (q3_engine.hip: frame_fence_policy).
+typedef __attribute__((ext_vector_type(4))) float act_f4_t;
+typedef __attribute__((ext_vector_type(2))) float act_f2_t;
+constexpr int ACT_SC1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 act_ld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const act_f4_t v = __builtin_bit_cast(act_f4_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, ACT_SC1));
+    return float4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ float2 act_ld2(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const act_f2_t v = __builtin_bit_cast(act_f2_t, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, ACT_SC1));
+    return float2{v[0], v[1]};
+}
+__device__ __forceinline__ float act_ld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, ACT_SC1));
+}
+__device__ __forceinline__ void act_st4(__amdgpu_buffer_rsrc_t r, int byte_off, const float4& v) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    const act_f4_t f = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, f), r, byte_off, 0, ACT_SC1);
+}
+__device__ __forceinline__ void act_st2(__amdgpu_buffer_rsrc_t r, int byte_off, const float2& v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    const act_f2_t f = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, f), r, byte_off, 0, ACT_SC1);
+}
+__device__ __forceinline__ void act_st1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, ACT_SC1);
+}
+// every wave that stored: its write-through stores (and no-return atomics) have reached the fabric before it ends
+__device__ __forceinline__ void act_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // q|k|v columns col0 / col1 (.. +VEC-1) of activation row b from the slice sums (AttnArgs::qkv_part): the arithmetic of
 // k_wide_epilogue<EPI_NONE, RMS> — v = 0; v += slice s (ascending); v / sqrt(sum_s ssq / K + eps) — with every load of
 // the eight possible slices in flight at once
 template <typename V, int NC>
 __device__ __forceinline__ void qkv_from_slices(const AttnArgs& a, int b, const int (&col)[NC], V (&out)[NC]) {
-    const size_t plane = (size_t)a.B * a.ld_qkv;
-    const float* p0 = a.qkv_part + (size_t)b * a.ld_qkv;
+    // (the slices come from the GEMM launch in front of the caller: L1-bypassing loads, see "activation transport" below)
+    const int plane = a.B * a.ld_qkv;
+    const __amdgpu_buffer_rsrc_t p0 = act_rsrc(a.qkv_part + (size_t)b * a.ld_qkv), qs = act_rsrc(a.qkv_ssq);
     V x[NC][8]; float q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int s = i < a.qkv_S ? i : a.qkv_S - 1;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) x[c][i] = *reinterpret_cast<const V*>(p0 + (size_t)s * plane + col[c]);
-        q[i] = a.qkv_ssq[(size_t)s * a.B + b];
+        for (int c = 0; c < NC; ++c) {
+            if constexpr (sizeof(V) == 8) x[c][i] = act_ld2(p0, (s * plane + col[c]) * 4);
+            else x[c][i] = act_ld1(p0, (s * plane + col[c]) * 4);
+        }
+        q[i] = act_ld1(qs, (s * a.B + b) * 4);
     }
     float tot = 0.0f;
 #pragma unroll
@@ -390,11 +439,13 @@ __device__ __forceinline__ void qkv_from_slices(const AttnArgs& a, int b, const 
         }
     }
 }
+// zero side job (LinArgs::zero / AttnArgs::zero): workgroup `wg` of `nwg` clears its share with 16-byte write-through stores
 __device__ __forceinline__ void zero_job(float* z, int n, int wg, int nwg, int tid, int nthreads) {
     if (!z) return;
     const int per = (((n + nwg - 1) / nwg) + 3) & ~3;
     const int beg = wg * per, end = (beg + per) < n ? (beg + per) : n;
-    for (int i = beg + tid * 4; i < end; i += nthreads * 4) *reinterpret_cast<float4*>(z + i) = float4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t zr = act_rsrc(z);
+    for (int i = beg + tid * 4; i < end; i += nthreads * 4) act_st4(zr, i * 4, float4{0.f, 0.f, 0.f, 0.f});
 }
 #endif
 

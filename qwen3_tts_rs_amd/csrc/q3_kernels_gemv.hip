@@ -202,7 +202,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
     const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : wp;
     const int xrow = HALF ? (m & 7) : m, xhalf = HALF ? (m >> 3) * 4 : 0;
     const bool act = HALF ? xrow < a.M : m < a.M;
-    const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
+    // x (and the residual, y, the zero job) travel write-through / L1-bypassing: q3_kernels.h "activation transport"
+    const __amdgpu_buffer_rsrc_t xres = act_rsrc(a.x);
+    const int xr = ((act ? xrow : 0) * a.ldx + kg * 8 + xhalf) * 4;          // byte offsets into x
     const float* __restrict__ nwp = RMS ? a.norm_w + kg * 8 + xhalf : nullptr;
     // COAL: x requested in row-contiguous lane order and moved to B-operand order through the LDS crossbar (see k_gemv_sk2)
     // (M <= 2 keeps the B-operand order: one or two live rows are one or two sectors per quad either way, and the four crossbar
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
     constexpr bool COAL = CO && NWAVES <= 8;         // (the 8-wave HOIST schedule; !HALF: the two-instruction form of k_gemv_sk2)
     const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
-    const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
+    const int xc = ((cact ? crow : 0) * a.ldx + cchunk * 4) * 4;
     const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
 
     // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
         const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
         if (tid < 256 && col < a.M && n < a.N) {
             if (a.bias) pre_b = a.bias[n];
-            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
+            if constexpr (EPI == EPI_RESID) pre_r = act_ld1(act_rsrc(a.resid), (col * a.ldr + n) * 4);
         }
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -247,11 +249,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
                 const bool ld = (NW == 2 && !HALF) || act;
                 if constexpr (COAL) {
                     const int kc = (s * 32 + cchunk * 4) < a.K ? s * 32 : 0;
-                    g.xa[i] = cact ? *reinterpret_cast<const float4*>(xc + kc) : float4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (!HALF) g.xb[i] = cact ? *reinterpret_cast<const float4*>(xc + kc + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                    g.xa[i] = cact ? act_ld4(xres, xc + kc * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!HALF) g.xb[i] = cact ? act_ld4(xres, xc + kc * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
                 } else {
-                    g.xa[i] = ld ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (!HALF) g.xb[i] = ld ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                    g.xa[i] = ld ? act_ld4(xres, xr + ko * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!HALF) g.xb[i] = ld ? act_ld4(xres, xr + ko * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
                 }
                 if constexpr (RMS) {
                     g.na[i] = *reinterpret_cast<const float4*>(nwp + ko);
@@ -304,8 +306,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
                 if constexpr (NW == 2) wb[i] = Q3_WLOAD(wp2 + (size_t)s * 64);
                 const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;
                 // lanes of unused batch columns (m >= M) issue no request (down-proj at M = 8: 12.3 -> 11.5 us)
-                xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (!HALF) xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                xa[i] = act ? act_ld4(xres, xr + ko * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) xb[i] = act ? act_ld4(xres, xr + ko * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (RMS) {
                     na[i] = *reinterpret_cast<const float4*>(nwp + ko);
                     if constexpr (!HALF) nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
@@ -376,11 +378,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
                 if constexpr (EPI == EPI_RESID) v = pre_r + v;
                 if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
                 if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
-                a.y[(size_t)col * a.ldy + n] = v;
+                act_st1(act_rsrc(a.y), (col * a.ldy + n) * 4, v);
             }
         }
     }
-    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
+    Q3T(3); act_drain(); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,7 +419,8 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + (size_t)blockIdx.x * S * 64 + lane;
     const int xrow = HALF ? (m & 7) : m, xhalf = HALF ? (m >> 3) * 4 : 0;
     const bool act = HALF ? xrow < a.M : m < a.M;
-    const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
+    const __amdgpu_buffer_rsrc_t xres = act_rsrc(a.x);       // write-through / L1-bypassing transport: q3_kernels.h
+    const int xr = ((act ? xrow : 0) * a.ldx + kg * 8 + xhalf) * 4;          // byte offsets into x
     // COAL (round 5, HALF only): the x loads in ROW-CONTIGUOUS lane order. In B-operand order consecutive lanes belong to different
     // batch rows (4-12 KB apart), so the four lanes of a quad never share a 64-byte sector and the CU's texture path spends a
     // cycle per lane instead of one per quad on every x instruction — four times what the same bytes cost as weight tiles. Lane l
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     constexpr bool COAL = true;
     const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
-    const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
+    const int xc = ((cact ? crow : 0) * a.ldx + cchunk * 4) * 4;
     const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
 
     // bias and residual of the k = 0 half, requested up front — and NOT combined here: `resid + bias` at this point made the compiler wait
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
         const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
         if (half == 0 && tid < 256 && col < pM - (MB ? (int)blockIdx.z * 16 : 0) && n < pN) {
             if (bp) pre_b = bp[n];
-            if constexpr (EPI == EPI_RESID) pre_r = rp[(size_t)(col + (MB ? (int)blockIdx.z * 16 : 0)) * ldr_pre + n];
+            if constexpr (EPI == EPI_RESID) pre_r = act_ld1(act_rsrc(rp), ((col + (MB ? (int)blockIdx.z * 16 : 0)) * ldr_pre + n) * 4);
         }
     }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f};
@@ -464,11 +467,11 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
             const int ko = (s * 32 + kg * 8) < a.K ? s * 32 : 0;
             if constexpr (COAL) {
                 const int kc = (s * 32 + cchunk * 4) < a.K ? s * 32 : 0;
-                g.xa[i] = cact ? *reinterpret_cast<const float4*>(xc + kc) : float4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (!HALF) g.xb[i] = cact ? *reinterpret_cast<const float4*>(xc + kc + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                g.xa[i] = cact ? act_ld4(xres, xc + kc * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) g.xb[i] = cact ? act_ld4(xres, xc + kc * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
             } else {
-                g.xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (!HALF) g.xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                g.xa[i] = act ? act_ld4(xres, xr + ko * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) g.xb[i] = act ? act_ld4(xres, xr + ko * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
             unsafeAtomicAdd(&a.y[(size_t)col * a.ldy + n], v);
         }
     }
-    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
+    Q3T(3); act_drain(); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 static hipError_t launch_gemv_sk2(const LinArgs& a, hipStream_t st) {
@@ -563,7 +566,7 @@ constexpr int ZB = 16 * ZS;          // floats per wave
 struct XGroup { float4 x[8]; float4 nw; };    // rows (2r + lane/32), floats (lane%32)*4 .. +3 of the k-group
 
 template <bool RMS>
-__device__ __forceinline__ void xg_load(XGroup& g, const float* __restrict__ x, int ldx, const float* __restrict__ norm_w,
+__device__ __forceinline__ void xg_load(XGroup& g, __amdgpu_buffer_rsrc_t x, int ldx, const float* __restrict__ norm_w,
                                         int M, int K, int k0, int lane) {
     const int half = lane >> 5, c = k0 + (lane & 31) * 4;
     const bool kok = c < K;                                    // K % 4 == 0: a float4 is all in or all out
@@ -571,7 +574,7 @@ __device__ __forceinline__ void xg_load(XGroup& g, const float* __restrict__ x, 
     for (int r = 0; r < 8; ++r) {
         if (2 * r < M) {                                       // wave-uniform
             const int row = 2 * r + half;
-            g.x[r] = (kok && row < M) ? *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c) : float4{0.f, 0.f, 0.f, 0.f};
+            g.x[r] = (kok && row < M) ? act_ld4(x, (row * ldx + c) * 4) : float4{0.f, 0.f, 0.f, 0.f};
         }
     }
     if constexpr (RMS) g.nw = kok ? *reinterpret_cast<const float4*>(norm_w + c) : float4{0.f, 0.f, 0.f, 0.f};
@@ -645,6 +648,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
     float* __restrict__ zb = lds + wave * ZB;
     const float* __restrict__ zrow = zb + m * ZS + kg * 8;
     float* __restrict__ ssq = lds + NWAVES * ZB;      // [NWAVES][16], outside the area `red` aliases
+    const __amdgpu_buffer_rsrc_t xres = act_rsrc(a.x);       // write-through / L1-bypassing transport: q3_kernels.h
 
     // epilogue operands (bias, residual) are requested up front so their round trip hides under the weight stream
     float pre_b = 0.0f, pre_r = 0.0f;
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
         const int col = tid >> 4, n = blockIdx.x * 16 + (tid & 15);
         if (tid < 256 && col < a.M && n < a.N) {
             if (a.bias) pre_b = a.bias[n];
-            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)col * a.ldr + n];
+            if constexpr (EPI == EPI_RESID) pre_r = act_ld1(act_rsrc(a.resid), (col * a.ldr + n) * 4);
         }
     }
 
@@ -663,14 +667,14 @@ __global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
     if (s0 < s1) {
         // x first, weights second: VMEM returns are counted in issue order, the staging must not wait for HBM.
         // (Requesting weights two groups ahead instead of one measured 5-10 % slower: more live registers, same latency.)
-        xg_load<RMS>(X0, a.x, a.ldx, a.norm_w, a.M, a.K, s0 * 32, lane);
+        xg_load<RMS>(X0, xres, a.ldx, a.norm_w, a.M, a.K, s0 * 32, lane);
         wg_load<NW>(wa0, wb0, wp, wp2, s0, s1);
         for (int sb = s0; sb < s1; sb += 2 * G) {
             xg_stage<RMS>(X0, zb, ss, a.M, lane);
             if (sb == s0) Q3T(1);
             const bool more1 = sb + G < s1;
             if (more1) {
-                xg_load<RMS>(X1, a.x, a.ldx, a.norm_w, a.M, a.K, (sb + G) * 32, lane);
+                xg_load<RMS>(X1, xres, a.ldx, a.norm_w, a.M, a.K, (sb + G) * 32, lane);
                 wg_load<NW>(wa1, wb1, wp, wp2, sb + G, s1);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
             if (!more1) break;
             xg_stage<RMS>(X1, zb, ss, a.M, lane);
             if (sb + 2 * G < s1) {
-                xg_load<RMS>(X0, a.x, a.ldx, a.norm_w, a.M, a.K, (sb + 2 * G) * 32, lane);
+                xg_load<RMS>(X0, xres, a.ldx, a.norm_w, a.M, a.K, (sb + 2 * G) * 32, lane);
                 wg_load<NW>(wa0, wb0, wp, wp2, sb + 2 * G, s1);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -726,11 +730,11 @@ __global__ __launch_bounds__(512) void k_gemv_lds(Q3_LIN_PRE, LinArgs a_in) {
                 if constexpr (EPI == EPI_RESID) v = pre_r + v;
                 if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
                 if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
-                a.y[(size_t)col * a.ldy + n] = v;
+                act_st1(act_rsrc(a.y), (col * a.ldy + n) * 4, v);
             }
         }
     }
-    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
+    Q3T(3); act_drain(); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,12 +769,13 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
     const u32x4_t* __restrict__ uH = reinterpret_cast<const u32x4_t*>(a.W2) + (size_t)tile_half * S * 64 + lane;
     const int xrow = HALF ? (m & 7) : m, xhalf = HALF ? (m >> 3) * 4 : 0;
     const bool act = HALF ? xrow < a.M : m < a.M;
-    const float* __restrict__ xr = a.x + (size_t)(act ? xrow : 0) * a.ldx + kg * 8 + xhalf;
+    const __amdgpu_buffer_rsrc_t xres = act_rsrc(a.x);       // write-through / L1-bypassing transport: q3_kernels.h
+    const int xr = ((act ? xrow : 0) * a.ldx + kg * 8 + xhalf) * 4;          // byte offsets into x
     const float* __restrict__ nwp = a.norm_w + kg * 8 + xhalf;
     constexpr bool COAL = CO;                        // see k_gemv_sk2: x in row-contiguous lane order, moved by the LDS crossbar (off for M <= 2)
     const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
-    const float* __restrict__ xc = a.x + (size_t)(cact ? crow : 0) * a.ldx + cchunk * 4;
+    const int xc = ((cact ? crow : 0) * a.ldx + cchunk * 4) * 4;
     const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
     f32x4_t aGF = {0.f, 0.f, 0.f, 0.f}, aGH = aGF, aUF = aGF, aUH = aGF;
     float ss = 0.0f;
@@ -783,11 +788,11 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
             const int s = (sb + i) < s1 ? (sb + i) : (s1 - 1);
             const int ko = s * 32;
             if constexpr (COAL) {
-                xa[i] = cact ? *reinterpret_cast<const float4*>(xc + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (!HALF) xb[i] = cact ? *reinterpret_cast<const float4*>(xc + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                xa[i] = cact ? act_ld4(xres, xc + ko * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) xb[i] = cact ? act_ld4(xres, xc + ko * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
             } else {
-                xa[i] = act ? *reinterpret_cast<const float4*>(xr + ko) : float4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (!HALF) xb[i] = act ? *reinterpret_cast<const float4*>(xr + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                xa[i] = act ? act_ld4(xres, xr + ko * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!HALF) xb[i] = act ? act_ld4(xres, xr + ko * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
             }
             na[i] = *reinterpret_cast<const float4*>(nwp + ko);
             if constexpr (!HALF) nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
@@ -841,9 +846,10 @@ __global__ __launch_bounds__(512) void k_gemv_gu24(Q3_LIN_PRE, LinArgs a_in) {
             const float den = sqrtf(tot / (float)a.K + a.eps);
             g = g / den; u = u / den;
             const int n = (full ? tile_full : tile_half) * 16 + row16;
-            if (n < a.N) a.y[(size_t)col * a.ldy + n] = (g / (1.0f + expf(-g))) * u;
+            if (n < a.N) act_st1(act_rsrc(a.y), (col * a.ldy + n) * 4, (g / (1.0f + expf(-g))) * u);
         }
     }
+    act_drain();
 }
 
 template <int EPI, bool RMS>
@@ -969,12 +975,13 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(Q3_LIN_PRE, LinArgs a_in) {
     const size_t tile_base = (size_t)blockIdx.x * S * 64 + lane;
     const u32x4_t* __restrict__ wp = reinterpret_cast<const u32x4_t*>(a.W) + tile_base;
     const u32x4_t* __restrict__ wp2 = NW == 2 ? reinterpret_cast<const u32x4_t*>(a.W2) + tile_base : wp;
-    const float* xr[MG]; bool act[MG];
+    const __amdgpu_buffer_rsrc_t xres = act_rsrc(a.x);       // write-through / L1-bypassing transport: q3_kernels.h
+    int xr[MG]; bool act[MG];                                 // byte offsets into x
 #pragma unroll
     for (int g = 0; g < MG; ++g) {
         const int m = g * 4 + j;
         act[g] = m < a.M;
-        xr[g] = a.x + (size_t)(act[g] ? m : 0) * a.ldx;
+        xr[g] = (act[g] ? m : 0) * a.ldx * 4;
     }
     const float* __restrict__ nwp = RMS ? a.norm_w : nullptr;
 
@@ -983,7 +990,7 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(Q3_LIN_PRE, LinArgs a_in) {
         const int m = tid >> 2, n = blockIdx.x * 4 + (tid & 3);
         if (m < a.M && n < a.N) {
             if (a.bias) pre_b = a.bias[n];
-            if constexpr (EPI == EPI_RESID) pre_r = a.resid[(size_t)m * a.ldr + n];
+            if constexpr (EPI == EPI_RESID) pre_r = act_ld1(act_rsrc(a.resid), (m * a.ldr + n) * 4);
         }
     }
     f32x4_t acc[NW][MG];
@@ -1009,8 +1016,8 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(Q3_LIN_PRE, LinArgs a_in) {
                 const int ko = (s * 128 + kb * 8) < a.K ? s * 128 + kb * 8 : 0;   // past K (K % 128 != 0): column 0, masked below — never past the row
 #pragma unroll
                 for (int g = 0; g < MG; ++g) {
-                    xa[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko) : float4{0.f, 0.f, 0.f, 0.f};     // unused columns: no request
-                    xb[i][g] = act[g] ? *reinterpret_cast<const float4*>(xr[g] + ko + 4) : float4{0.f, 0.f, 0.f, 0.f};
+                    xa[i][g] = act[g] ? act_ld4(xres, xr[g] + ko * 4) : float4{0.f, 0.f, 0.f, 0.f};     // unused columns: no request
+                    xb[i][g] = act[g] ? act_ld4(xres, xr[g] + ko * 4 + 16) : float4{0.f, 0.f, 0.f, 0.f};
                 }
                 if constexpr (RMS) {
                     na[i] = *reinterpret_cast<const float4*>(nwp + ko);
@@ -1057,8 +1064,8 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(Q3_LIN_PRE, LinArgs a_in) {
                 const int ko = (s * 128 + kb * 8) < a.K ? s * 128 + kb * 8 : 0;   // past K (K % 128 != 0): column 0, masked below — never past the row
 #pragma unroll
                 for (int g = 0; g < MG; ++g) {
-                    xa[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko);
-                    xb[i][g] = *reinterpret_cast<const float4*>(xr[g] + ko + 4);
+                    xa[i][g] = act_ld4(xres, xr[g] + ko * 4);
+                    xb[i][g] = act_ld4(xres, xr[g] + ko * 4 + 16);
                 }
                 na[i] = *reinterpret_cast<const float4*>(nwp + ko);
                 nb[i] = *reinterpret_cast<const float4*>(nwp + ko + 4);
@@ -1142,10 +1149,10 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(Q3_LIN_PRE, LinArgs a_in) {
             if constexpr (EPI == EPI_RESID) v = pre_r + v;
             if constexpr (EPI == EPI_SILU) v = v / (1.0f + expf(-v));
             if constexpr (EPI == EPI_SWIGLU) v = (v / (1.0f + expf(-v))) * v2;
-            a.y[(size_t)m * a.ldy + n] = v;
+            act_st1(act_rsrc(a.y), (m * a.ldy + n) * 4, v);
         }
     }
-    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
+    Q3T(3); act_drain(); Q3T_W(4); Q3T_FLUSH(a, blockIdx.x);
 }
 
 template <int EPI, bool RMS>

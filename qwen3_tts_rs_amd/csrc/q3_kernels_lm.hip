@@ -547,6 +547,9 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
         } else return r.f;
     };
     auto bf16_rne = [](float v) -> uint32_t { uint32_t u = __float_as_uint(v); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
+    // the new position's K / V rows: write-through like everything a fence-free node stores (q3_kernels.h "activation transport") —
+    // they are read by later FRAMES only, but nothing may stay dirty in this XCD's L2 behind a packet without a release fence
+    auto kv_st = [](auto* p, auto v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
     // The first two cached K/V rows of this group are requested NOW, before the q/k-norm + RoPE prologue: they depend
     // on nothing but `pos`, and their round trip then runs under the prologue instead of after its barrier (the new
@@ -580,15 +583,19 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
         qkv_row = a.g_qkv_tab + (size_t)row * a.ld_qkv;
         if (kvh == 0 && split == 0) {
             const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
-            float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
-            for (int c = tid; c < a.g_proj_dim / 4; c += 256) pd[c] = ps[c];
-            if (tid == 0 && a.g_frame_idx[b] < a.g_max_frames) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
+            const __amdgpu_buffer_rsrc_t pd = act_rsrc(a.g_x + (size_t)b * a.g_ldx);
+            for (int c = tid; c < a.g_proj_dim / 4; c += 256) act_st4(pd, c * 16, ps[c]);
+            if (tid == 0 && a.g_frame_idx[b] < a.g_max_frames)      // write-through: see k_attn_cp
+                __hip_atomic_store(&a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot], (uint32_t)row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // jobs 0..NREP-1: q heads; job NREP: the k head (+ raw v). The prologue's own loads go out FIRST (returns are counted in issue
     // order: behind the K/V requests the prologue would wait for the whole stream), the K/V requests follow, then the arithmetic.
     constexpr int NJ = (NREP + 1 + 3) / 4;
     const bool from_slices = a.qkv_part && !a.g_logits;
+    // q | k | v was written by the projection in front of this launch: L1-bypassing loads; partial records / the output row:
+    // write-through stores (q3_kernels.h "activation transport"). The K/V pages are cross-frame state: plain accesses.
+    const __amdgpu_buffer_rsrc_t qkv_res = act_rsrc(qkv_row);
     float jx1[NJ], jx2[NJ], jv1[NJ], jv2[NJ], jn1[NJ], jn2[NJ];
     const float rc = a.rope_cos[(size_t)pos * 64 + lane], rs = a.rope_sin[(size_t)pos * 64 + lane];
 #pragma unroll
@@ -604,8 +611,9 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
                 float o[4]; qkv_from_slices<float, 4>(a, b, cols, o);
                 jx1[jj] = o[0]; jx2[jj] = o[1]; jv1[jj] = o[2]; jv2[jj] = o[3];
             } else {
-                jx1[jj] = qkv_row[scol + lane]; jx2[jj] = qkv_row[scol + lane + 64];
-                if (!is_q) { jv1[jj] = qkv_row[vcol + lane]; jv2[jj] = qkv_row[vcol + lane + 64]; }
+                // (a table row of the folded gather is static too; one form for both keeps the prologue one code path)
+                jx1[jj] = act_ld1(qkv_res, (scol + lane) * 4); jx2[jj] = act_ld1(qkv_res, (scol + lane + 64) * 4);
+                if (!is_q) { jv1[jj] = act_ld1(qkv_res, (vcol + lane) * 4); jv2[jj] = act_ld1(qkv_res, (vcol + lane + 64) * 4); }
             }
             const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
             jn1[jj] = nw[lane]; jn2[jj] = nw[lane + 64];
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
                     s_v[lane] = __uint_as_float(c1 << 16); s_v[lane + 64] = __uint_as_float(c2 << 16);
                     if (split == pos / chunk) {
                         uint16_t* kc = reinterpret_cast<uint16_t*>(krow_paged(pos, pos, true)); uint16_t* vc = kc + pg_vd;
-                        kc[lane] = (uint16_t)b1; kc[lane + 64] = (uint16_t)b2; vc[lane] = (uint16_t)c1; vc[lane + 64] = (uint16_t)c2;
+                        kv_st(&kc[lane], (uint16_t)b1); kv_st(&kc[lane + 64], (uint16_t)b2); kv_st(&vc[lane], (uint16_t)c1); kv_st(&vc[lane + 64], (uint16_t)c2);
                     }
                 } else {
                     s_k[lane] = o1; s_k[lane + 64] = o2; s_v[lane] = v1; s_v[lane + 64] = v2;
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
                         float* kc; float* vc;
                         if constexpr (PAGED != 0) { kc = krow_paged(pos, pos, true); vc = kc + pg_vd; }
                         else { kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM; vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM; }
-                        kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
+                        kv_st(&kc[lane], o1); kv_st(&kc[lane + 64], o2); kv_st(&vc[lane], v1); kv_st(&vc[lane + 64], v2);
                     }
                 }
             }
@@ -728,14 +736,14 @@ __global__ __launch_bounds__(256) void k_attn_fused(const int* p_pos, const floa
         }
         const int h = kvh * NREP + r;
         if (a.n_splits == 1) {
-            a.out[(size_t)b * a.ld_out + h * HEAD_DIM + d] = A / L;
+            act_st1(act_rsrc(a.out), (b * a.ld_out + h * HEAD_DIM + d) * 4, A / L);
         } else {
-            float* rec = a.part + (((size_t)b * a.nh + h) * a.n_splits + split) * PART_STRIDE;
-            rec[d] = A;
-            if (d == 0) { rec[HEAD_DIM] = M; rec[HEAD_DIM + 1] = L; }
+            const __amdgpu_buffer_rsrc_t rec = act_rsrc(a.part + (((size_t)b * a.nh + h) * a.n_splits + split) * PART_STRIDE);
+            act_st1(rec, d * 4, A);
+            if (d == 0) { act_st1(rec, HEAD_DIM * 4, M); act_st1(rec, (HEAD_DIM + 1) * 4, L); }
         }
     }
-    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    Q3T(3); act_drain(); Q3T_W(4); Q3T_FLUSH(a, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 hipError_t launch_attn_fused(const AttnArgs& a, hipStream_t st) {
@@ -815,8 +823,10 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
         const int row = is_q ? 1 : j - NREP, pos = row;
         const float* base = (row == 1 && a.g_tok) ? a.g_qkv_tab + (size_t)a.g_tok[b] * a.ld_qkv        // folded pass-1 gather
                                                   : a.qkv + (size_t)(2 * b + row) * a.ld_qkv;
-        const float* src = base + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM);
-        float x1 = src[lane], x2 = src[lane + 64];
+        // rows of a.qkv were written by the projection in front of this launch: L1-bypassing loads (harmless on a table row);
+        // K/V rows, the output and the residual row are read by later launches of the frame: write-through stores (q3_kernels.h)
+        const __amdgpu_buffer_rsrc_t src = act_rsrc(base + (is_q ? (kvh * NREP + j) * HEAD_DIM : QD + kvh * HEAD_DIM));
+        float x1 = act_ld1(src, lane * 4), x2 = act_ld1(src, (lane + 64) * 4);
         const float ss = wave_sum(x1 * x1 + x2 * x2);
         const float den = sqrtf(ss / (float)HEAD_DIM + a.eps);
         const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
@@ -827,26 +837,26 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
         const float o2 = add_rn(mul_rn(x2, c), mul_rn(x1, sn));
         if (is_q) { s_q[j][lane] = o1; s_q[j][lane + 64] = o2; }
         else {
-            const float* vs = base + QD + KD + kvh * HEAD_DIM;
-            const float v1 = vs[lane], v2 = vs[lane + 64];
+            const __amdgpu_buffer_rsrc_t vs = act_rsrc(base + QD + KD + kvh * HEAD_DIM);
+            const float v1 = act_ld1(vs, lane * 4), v2 = act_ld1(vs, (lane + 64) * 4);
             s_k[row][lane] = o1; s_k[row][lane + 64] = o2; s_v[row][lane] = v1; s_v[row][lane + 64] = v2;
-            float* kc = a.kcache + cache_base + (size_t)pos * HEAD_DIM;
-            float* vc = a.vcache + cache_base + (size_t)pos * HEAD_DIM;
-            kc[lane] = o1; kc[lane + 64] = o2; vc[lane] = v1; vc[lane + 64] = v2;
+            const __amdgpu_buffer_rsrc_t kc = act_rsrc(a.kcache + cache_base + (size_t)pos * HEAD_DIM);
+            const __amdgpu_buffer_rsrc_t vc = act_rsrc(a.vcache + cache_base + (size_t)pos * HEAD_DIM);
+            act_st1(kc, lane * 4, o1); act_st1(kc, (lane + 64) * 4, o2); act_st1(vc, lane * 4, v1); act_st1(vc, (lane + 64) * 4, v2);
         }
     }
     if (a.g_tok && kvh == 0) {                                   // the semantic row of the residual stream
         const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)a.g_tok[b] * a.g_proj_dim);
-        float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
-        for (int c = tid; c < a.g_proj_dim / 4; c += 256) pd[c] = ps[c];
+        const __amdgpu_buffer_rsrc_t pd = act_rsrc(a.g_x + (size_t)b * a.g_ldx);
+        for (int c = tid; c < a.g_proj_dim / 4; c += 256) act_st4(pd, c * 16, ps[c]);
     }
     __syncthreads();
     const float scale = 0.08838834764831845f;
     for (int r = wave; r < NREP; r += 4) {
         const int h = kvh * NREP + r;
         // row 0: one key, weight exp(0) / 1
-        float* o0 = a.out + (size_t)(2 * b) * a.ld_out + h * HEAD_DIM;
-        o0[lane] = s_v[0][lane]; o0[lane + 64] = s_v[0][lane + 64];
+        const __amdgpu_buffer_rsrc_t o0 = act_rsrc(a.out + (size_t)(2 * b) * a.ld_out + h * HEAD_DIM);
+        act_st1(o0, lane * 4, s_v[0][lane]); act_st1(o0, (lane + 64) * 4, s_v[0][lane + 64]);
         // row 1: two keys
         const float q1 = s_q[r][lane], q2 = s_q[r][lane + 64];
         const float sc0 = wave_sum(q1 * s_k[0][lane] + q2 * s_k[0][lane + 64]) * scale;
@@ -854,10 +864,11 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
         const float M = fmaxf(sc0, sc1);
         const float w0 = expf(sc0 - M), w1 = expf(sc1 - M);
         const float L = w0 + w1;
-        float* o1 = a.out + (size_t)(2 * b + 1) * a.ld_out + h * HEAD_DIM;
-        o1[lane] = (s_v[0][lane] * w0 + s_v[1][lane] * w1) / L;
-        o1[lane + 64] = (s_v[0][lane + 64] * w0 + s_v[1][lane + 64] * w1) / L;
+        const __amdgpu_buffer_rsrc_t o1 = act_rsrc(a.out + (size_t)(2 * b + 1) * a.ld_out + h * HEAD_DIM);
+        act_st1(o1, lane * 4, (s_v[0][lane] * w0 + s_v[1][lane] * w1) / L);
+        act_st1(o1, (lane + 64) * 4, (s_v[0][lane + 64] * w0 + s_v[1][lane + 64] * w1) / L);
     }
+    act_drain();
 }
 
 hipError_t launch_attn_first2(const AttnArgs& a, hipStream_t st) {
@@ -933,7 +944,10 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
     const int nrep = a.nh / a.nkv, kvh = h / nrep;
     const int QD = a.nh * HEAD_DIM, KD = a.nkv * HEAD_DIM;
     const int pos = a.pos_static;
-    const size_t cache_base = ((size_t)b * a.nkv + kvh) * a.max_seq * HEAD_DIM + 2 * lane;
+    // the cache rows of a frame's earlier passes, the q | k | v row and the logits come from earlier nodes of the SAME frame: L1-bypassing
+    // loads, write-through stores (q3_kernels.h "activation transport")
+    const __amdgpu_buffer_rsrc_t kres = act_rsrc(a.kcache), vres = act_rsrc(a.vcache);
+    const int cache_base = (((b * a.nkv + kvh) * a.max_seq) * HEAD_DIM + 2 * lane) * 4;       // bytes (a <= 16-position cache: far below 2 GB)
     // The cached rows depend on nothing; slot p >= pos re-reads row 0, which always exists and is finite. GATHER: requested first,
     // under the argmax chain that finds the q | k | v row. Otherwise BEHIND q | k | v: returns are counted in issue order, and ahead
     // of them the norm + RoPE arithmetic waited for all 2 NK cache rows as well (they are not needed before the scores).
@@ -941,9 +955,9 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
     auto request_cache = [&]() {
 #pragma unroll
         for (int p = 0; p < NK; ++p) {
-            const size_t ro = cache_base + (size_t)(p < pos ? p : 0) * HEAD_DIM;
-            kc[p] = *reinterpret_cast<const float2*>(a.kcache + ro);
-            vc[p] = *reinterpret_cast<const float2*>(a.vcache + ro);
+            const int ro = cache_base + (p < pos ? p : 0) * HEAD_DIM * 4;
+            kc[p] = act_ld2(kres, ro);
+            vc[p] = act_ld2(vres, ro);
         }
     };
     if constexpr (GATHER) request_cache();
@@ -954,7 +968,7 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
 
     const float* qkv_row = a.qkv + (size_t)b * a.ld_qkv;
     if constexpr (GATHER) {      // folded gather (AttnArgs::g_*): the row is the argmax of the previous pass's logits
-        const float* lg = a.g_logits + (size_t)b * a.g_vocab;
+        const __amdgpu_buffer_rsrc_t lg = act_rsrc(a.g_logits + (size_t)b * a.g_vocab);
         float bv = -INFINITY; int bi = 0x7fffffff;
         auto take4 = [&](const float4& v, int j) {
             if (v.x > bv || (v.x == bv && j < bi)) { bv = v.x; bi = j; }
@@ -965,13 +979,13 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         if (a.g_vocab == 2048) {          // the production vocabulary: all eight 16-byte requests of a lane in flight at once
             float4 v[8];                  // (a run-time trip count kept them serial: eight round trips, 4.9 us before the first use)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(lg + lane * 4 + i * 256);
+            for (int i = 0; i < 8; ++i) v[i] = act_ld4(lg, (lane * 4 + i * 256) * 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) take4(v[i], lane * 4 + i * 256);
         } else if ((a.g_vocab & 3) == 0) {
-            for (int j = lane * 4; j < a.g_vocab; j += 256) take4(*reinterpret_cast<const float4*>(lg + j), j);
+            for (int j = lane * 4; j < a.g_vocab; j += 256) take4(act_ld4(lg, j * 4), j);
         } else {
-            for (int j = lane; j < a.g_vocab; j += 64) { const float v = lg[j]; if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; } }
+            for (int j = lane; j < a.g_vocab; j += 64) { const float v = act_ld1(lg, j * 4); if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; } }
         }
         // first-max over the wave: DPP rotations inside the rows (the combine is symmetric, so every lane of a row ends with the
         // row's winner), then the four row winners by v_readlane
@@ -988,9 +1002,13 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         {   // the residual-stream row: every head's wave copies its share (one wave copying all of it finished 2.4 us after the others)
             const int per = (((a.g_proj_dim / 4) + a.nh - 1) / a.nh), c0 = h * per, c1 = (c0 + per) < a.g_proj_dim / 4 ? (c0 + per) : a.g_proj_dim / 4;
             const float4* ps = reinterpret_cast<const float4*>(a.g_proj_tab + (size_t)row * a.g_proj_dim);
-            float4* pd = reinterpret_cast<float4*>(a.g_x + (size_t)b * a.g_ldx);
-            for (int c = c0 + lane; c < c1; c += 64) pd[c] = ps[c];
-            if (h == 0 && lane == 0 && a.g_frame_idx[b] < a.g_max_frames) a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot] = (uint32_t)row;
+            const __amdgpu_buffer_rsrc_t pd = act_rsrc(a.g_x + (size_t)b * a.g_ldx);
+            for (int c = c0 + lane; c < c1; c += 64) act_st4(pd, c * 16, ps[c]);
+            // write-through as well: the frame's 64-byte code record is completed by k_frame_embed from another XCD, and a dword left
+            // dirty in this XCD's L2 until the frame's release would meet that workgroup's copy of the line (round 6: rows 1.. of a
+            // release-free code predictor came back with clobbered records, row 0 — same XCD — never)
+            if (h == 0 && lane == 0 && a.g_frame_idx[b] < a.g_max_frames)
+                __hip_atomic_store(&a.g_codes[((size_t)b * a.g_max_frames + a.g_frame_idx[b]) * 16 + a.g_code_slot], (uint32_t)row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     float2 q, k, v;
@@ -999,9 +1017,16 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         float2 o[3]; qkv_from_slices<float2, 3>(a, b, cols, o);        // all 24 slice loads of the lane in flight at once
         q = o[0]; k = o[1]; v = o[2];
     } else {
-        q = *reinterpret_cast<const float2*>(qkv_row + h * HEAD_DIM + 2 * lane);
-        k = *reinterpret_cast<const float2*>(qkv_row + QD + kvh * HEAD_DIM + 2 * lane);
-        v = *reinterpret_cast<const float2*>(qkv_row + QD + KD + kvh * HEAD_DIM + 2 * lane);
+        if constexpr (GATHER) {      // a table row: written once at model finalize
+            q = *reinterpret_cast<const float2*>(qkv_row + h * HEAD_DIM + 2 * lane);
+            k = *reinterpret_cast<const float2*>(qkv_row + QD + kvh * HEAD_DIM + 2 * lane);
+            v = *reinterpret_cast<const float2*>(qkv_row + QD + KD + kvh * HEAD_DIM + 2 * lane);
+        } else {
+            const __amdgpu_buffer_rsrc_t qr = act_rsrc(qkv_row);
+            q = act_ld2(qr, (h * HEAD_DIM + 2 * lane) * 4);
+            k = act_ld2(qr, (QD + kvh * HEAD_DIM + 2 * lane) * 4);
+            v = act_ld2(qr, (QD + KD + kvh * HEAD_DIM + 2 * lane) * 4);
+        }
     }
     if constexpr (!GATHER) request_cache();
 
@@ -1024,9 +1049,9 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
     q = norm_rope(q, qw);
     k = norm_rope(k, kw);
     if (h == kvh * nrep) {
-        const size_t ro = cache_base + (size_t)pos * HEAD_DIM;
-        *reinterpret_cast<float2*>(a.kcache + ro) = k;
-        *reinterpret_cast<float2*>(a.vcache + ro) = v;
+        const int ro = cache_base + pos * HEAD_DIM * 4;
+        act_st2(kres, ro, k);
+        act_st2(vres, ro, v);
     }
 
     float s[NK];
@@ -1075,8 +1100,8 @@ __global__ __launch_bounds__(64) void k_attn_cp(const float* p_kc, const float* 
         acc.x = fmaf(wp, vv.x, acc.x); acc.y = fmaf(wp, vv.y, acc.y);
     }
     Q3T(2);
-    *reinterpret_cast<float2*>(a.out + (size_t)b * a.ld_out + h * HEAD_DIM + 2 * lane) = make_float2(acc.x / L, acc.y / L);
-    Q3T(3); Q3T_W(4);
+    act_st2(act_rsrc(a.out), (b * a.ld_out + h * HEAD_DIM + 2 * lane) * 4, make_float2(acc.x / L, acc.y / L));
+    Q3T(3); act_drain(); Q3T_W(4);
 #ifdef Q3_TRACE
     q3t_[6] = (unsigned long long)clock64();
 #endif
@@ -1113,16 +1138,17 @@ __global__ __launch_bounds__(128) void k_attn_merge(const float* p_part, float* 
     a.part = const_cast<float*>(p_part); a.out = p_out; a.n_splits = p_splits; a.nh = p_nh; a.ld_out = p_ld_out;
     Q3T_DECL Q3T(0);
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const float* rec = a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE;
+    // the records were written by the attention launch in front of this one: L1-bypassing loads, write-through store (q3_kernels.h)
+    const __amdgpu_buffer_rsrc_t rec = act_rsrc(a.part + ((size_t)b * a.nh + h) * a.n_splits * PART_STRIDE);
     // all loads first (fixed unroll, predicated): one memory round trip instead of 2*n_splits dependent ones
     float ms[NS], ls[NS], as[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const bool ok = s < a.n_splits;
-        const float* r = rec + (ok ? s : 0) * PART_STRIDE;
-        ms[s] = ok ? r[HEAD_DIM] : -INFINITY;
-        ls[s] = ok ? r[HEAD_DIM + 1] : 0.0f;
-        as[s] = ok ? r[d] : 0.0f;
+        const int r = (ok ? s : 0) * PART_STRIDE * 4;
+        ms[s] = ok ? act_ld1(rec, r + HEAD_DIM * 4) : -INFINITY;
+        ls[s] = ok ? act_ld1(rec, r + (HEAD_DIM + 1) * 4) : 0.0f;
+        as[s] = ok ? act_ld1(rec, r + d * 4) : 0.0f;
     }
     Q3T_W(1);
     float M = -INFINITY;
@@ -1136,8 +1162,8 @@ __global__ __launch_bounds__(128) void k_attn_merge(const float* p_part, float* 
         A += as[s] * wgt;
     }
     Q3T(2);
-    a.out[(size_t)b * a.ld_out + h * HEAD_DIM + d] = A / L;
-    Q3T(3); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
+    act_st1(act_rsrc(a.out), (b * a.ld_out + h * HEAD_DIM + d) * 4, A / L);
+    Q3T(3); act_drain(); Q3T_W(4); Q3T_FLUSH(a, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // two partials per (row, head) — the key halves of the long-prompt prefill attention, tens of thousands of records per

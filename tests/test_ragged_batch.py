@@ -107,3 +107,33 @@ def test_ragged_bad_row_fails_at_prefill(pair):
         s.prefill()
     s.close()
     assert gm.kv_pool_info()["pages_in_use"] == 0
+
+
+def test_ragged_icl_rows_above_their_cap(pair):
+    """Two ICL rows of different reference length with the default-sized max_length (far above the ICL cap max(75, 6 * n_text),
+    lib.rs:897-1046) next to an x-vector row: the session is sized from the RESOLVED limits, and so must the ragged prefill's check be
+    (round-5 advisor finding: every such batch failed with `max_length 2048 outside 1..N`)."""
+    cfg, gm, om = pair
+    rng = np.random.default_rng(6)
+    xv = rng.standard_normal(cfg.hidden).astype(np.float32)
+    ref_a = rng.integers(0, 2048, size=(4, 16)).astype(np.uint32)
+    ref_b = rng.integers(0, 2048, size=(9, 16)).astype(np.uint32)
+    utts = [
+        q.Utterance(synthetic_prompt(5, 10), language=q.Language.French, xvector=xv, ref_codes=ref_a, ref_text_ids=synthetic_prompt(3, 95), seed=50),
+        q.Utterance(synthetic_prompt(14, 11), language=q.Language.French, xvector=xv, ref_codes=ref_b, ref_text_ids=synthetic_prompt(4, 96), seed=51),
+        q.Utterance(synthetic_prompt(7, 12), language=q.Language.French, xvector=xv, seed=52),
+    ]
+    utts[0].max_length = 2048; utts[1].max_length = 2048; utts[2].max_length = 30
+    caps = [75, 84, 30]                                   # max(75, 6 * n_text) for the ICL rows
+    host = q.SynthesisOptions(max_length=2048, eos_token_id=None, seed=1)
+    s = gm.session(utts, host)
+    s.prefill()
+    s.generate(12, use_graph=True)
+    got = [s.codes(b) for b in range(3)]
+    s.close()
+    assert gm.kv_pool_info()["pages_in_use"] == 0
+    for b, u in enumerate(utts):
+        o = q.SynthesisOptions(max_length=u.max_length, eos_token_id=None, seed=1)
+        s1 = gm.session([u], o); s1.prefill(); s1.generate(12, use_graph=False)
+        assert got[b].shape == (12, 16) and caps[b] >= 12
+        np.testing.assert_array_equal(got[b], s1.codes(0), err_msg=f"row {b} vs its batch-1 run"); s1.close()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the frame submission paths on one MI355X: hipGraphLaunch vs the library's own AQL queue (Q3_AQL=1: HIP's packet
-headers, Q3_AQL=2: no boundary fences). Same session shape as bench.py (1.7B, B utterances, 512-token prompts); prints
+headers, Q3_AQL=2: no boundary fences, Q3_AQL=3: fence-free boundaries between the kernels that move their data write-through;
+a spec may carry environment settings: `3/Q3_AQL_T_REL=0/Q3_AQL_T_ONLY=sk2`). Same session shape as bench.py (1.7B, B utterances, 512-token prompts); prints
 ms/frame per path and checks that every path produces the same codes.   usage: aql_ab.py [--model 1.7b] [--batch 8] [--frames 200]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,9 +24,12 @@ os.environ["Q3_AQL_VERBOSE"] = "1"
 os.environ["Q3_AQL_UNSAFE"] = "1"      # this tool IS the probe: fence-free modes are measured on purpose (their codes are expected to differ)
 ref = None
 for spec in a.modes.split(","):
-    parts = spec.split(":"); mode = int(parts[0])
+    envs = spec.split("/")[1:]
+    parts = spec.split("/")[0].split(":"); mode = int(parts[0])
     os.environ["Q3_AQL"] = str(mode)
-    os.environ.pop("Q3_AQL_ACQ", None); os.environ.pop("Q3_AQL_REL", None)
+    for k in ("Q3_AQL_ACQ", "Q3_AQL_REL", "Q3_AQL_T_ACQ", "Q3_AQL_T_REL", "Q3_AQL_T_ONLY"): os.environ.pop(k, None)
+    for e in envs:
+        k, v = e.split("=", 1); os.environ[k] = v
     if len(parts) == 3:
         os.environ["Q3_AQL_ACQ"], os.environ["Q3_AQL_REL"] = parts[1], parts[2]
     best = 1e9
@@ -39,4 +43,9 @@ for spec in a.modes.split(","):
         best = min(best, dt)
     if ref is None: ref = codes
     same = codes.shape == ref.shape and bool((codes == ref).all())
-    print(f"Q3_AQL={spec}: path {path} ({nodes} packets/frame)  {best * 1e3 / a.frames:.3f} ms/frame  codes {'identical' if same else 'DIFFER'}", flush=True)
+    where = ""
+    if not same and codes.shape == ref.shape:
+        d = (codes != ref)                                # [B][frames][16]
+        first = [int(np.argmax(d[b].any(axis=1))) if d[b].any() else -1 for b in range(a.batch)]
+        where = f"  first differing frame per row {first}, {int(d.sum())} of {d.size} codes"
+    print(f"Q3_AQL={spec}: path {path} ({nodes} packets/frame)  {best * 1e3 / a.frames:.3f} ms/frame  codes {'identical' if same else 'DIFFER'}{where}", flush=True)
