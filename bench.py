@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Figures that cannot be taken from inside the run (rocprofv3 kernel tables, PMC passes) come from files committed under
 # profiles/ for THIS round only: an older round's profile is never substituted silently — the field is null instead.
-PROFILE_ROUND = "r5"
+PROFILE_ROUND = "r6"
 
 
 def committed_rocprof_table(avg_bytes_per_launch, model, batch):
@@ -155,6 +155,7 @@ def main():
     opts = q.SynthesisOptions(max_length=args.frames, eos_token_id=None, seed=42, **samp)
     use_graph = not args.no_graph
 
+    submit_path = [0, 0]    # (path, packets per frame) of the timed sessions: include/q3tts.h q3_session_submit_info
     phase_ms = []       # (create, run, close) wall per step: the timed step is all three
     # the samples of every utterance land in host memory inside the timed step, as `synthesize` returns them
     # (lib.rs:718-784): one pinned buffer per row, reused step after step (allocated once, outside the timing, like a
@@ -175,6 +176,10 @@ def main():
             return s.run_timing_only(use_graph=use_graph, pcm_out=pcm_out)
         finally:
             tc = time.perf_counter()
+            try:
+                submit_path[:] = list(s.submit_info())
+            except Exception:
+                pass
             s.close()
             phase_ms.append([(tb - ta) * 1e3, (tc - tb) * 1e3, (time.perf_counter() - tc) * 1e3])
 
@@ -515,7 +520,11 @@ def main():
                    "utterances_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"dp{world}",
                    "weights": "bf16", "activations_kv": "f32",
                    "kv": "f32, in place (2x the bytes of the reference GPU path's bf16 cache, kv_cache.rs:234-310: the parity contract is the CPU F32 path)",
-                   "hip_graph": use_graph, "prefill": args.workload, "sampling": args.sampling,
+                   "hip_graph": use_graph,
+                   "frame_submit": {0: "eager launches", 1: "hipGraphLaunch", 2: "own AQL queue, HIP's fences on every packet",
+                                    3: "own AQL queue, no fences (probe: invalid)",
+                                    4: "captured frame replayed on the library's own AQL queue; boundaries between write-through kernels without agent-scope fences"}.get(submit_path[0], str(submit_path[0])),
+                   "frame_packets": submit_path[1], "prefill": args.workload, "sampling": args.sampling,
                    "pcm_copy_out": True},      # every utterance's samples are copied to (pinned) host memory inside the timed step
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,

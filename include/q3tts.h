@@ -351,11 +351,13 @@ q3_status q3_bench_linear(int device, int M, int N, int K, int epi, int rms, int
                           double* avg_us);
 /* raw stream handle (hipStream_t) the session launches on */
 q3_status q3_session_stream(q3_session* s, void** stream);
-/* How this session's captured frame is replayed: *path = 0 nothing captured yet / eager launches, 1 = hipGraphLaunch, 2 = the
- * library's own AQL queue with HIP's packet headers (agent-scope fences at every kernel boundary; bit-identical to path 1), 3 =
- * own AQL queue without boundary fences — a measurement probe: the product kernels move activations with plain loads and
- * stores, so path 3 gives WRONG results and is reachable only with Q3_AQL=2 plus the explicit opt-in Q3_AQL_UNSAFE=1 (a warning
- * is printed); *nodes = dispatch packets per frame (0 on paths 0 / 1).
+/* How this session's captured frame is replayed: *path = 0 nothing captured yet / eager launches, 1 = hipGraphLaunch (Q3_AQL=0),
+ * 2 = the library's own AQL queue with HIP's packet headers (agent-scope fences at every kernel boundary; bit-identical to path
+ * 1; Q3_AQL=1), 4 = own AQL queue, the boundaries between the frame's write-through kernels without those fences (the default
+ * since round 6: same codes, ~4.5 % less time per frame; the first and last packet of every frame keep their fences), 3 = own
+ * queue without ANY boundary fence — a measurement probe that gives WRONG results (state that crosses frames moves with plain
+ * accesses), reachable only with Q3_AQL=2 plus the explicit opt-in Q3_AQL_UNSAFE=1 (a warning is printed);
+ * *nodes = dispatch packets per frame (0 on paths 0 / 1). A graph the converter cannot take stays on path 1.
  * The reference replays nothing — every op is an eager candle launch (src/lib.rs:580-652); new here (environment: Q3_AQL). */
 q3_status q3_session_submit_info(q3_session* s, int* path, int* nodes);
 /* Algorithmic HBM bytes of one frame for this session's batch at KV length L */

@@ -320,7 +320,7 @@ void aql_program_destroy(AqlProgram* p) {
     if (p->pending && !p->dead) aql_wait(p, &w);         // (a dead program's signal may never fire: do not block on it)
     if (p->kernargs && !p->dead) (void)hipFree(p->kernargs);      // dead: packets still in the ring may point at the blocks — leak them
     if (p->dead) p->kernargs = nullptr;
-    if (p->done.handle) hsa.hsa_signal_destroy(p->done);
+    if (p->done.handle && !p->dead) hsa.hsa_signal_destroy(p->done);     // dead: the burst's last packet may still name it — leaked with the blocks
     delete p;
 }
 

@@ -1420,7 +1420,8 @@ struct q3_session {
     hipGraphExec_t graph_exec = nullptr; hipGraph_t graph = nullptr;
     // the captured frame as a packet program on the library's own AQL queue (q3_aql.cpp); nullptr: frames replay through
     // hipGraphLaunch.  aql_mode: 0 = off, 1 = HIP's header policy (agent-scope fences on every packet), 2 = no fences
-    q3::AqlProgram* aql = nullptr; int aql_mode = 0; bool aql_tried = false;
+    q3::AqlProgram* aql = nullptr; int aql_mode = 0; bool aql_tried = false, aql_failed = false;
+    bool precapture = false;       // q3_session_prefill captures the frame while the prompt's kernels run (set by the callers that will replay it)
     CodecWS cws;
     // overlapped segment decode (q3_session_run): vocoder segments run on their own stream while the frame loop continues
     hipStream_t dec_stream = nullptr; hipEvent_t dec_ev = nullptr;
@@ -1452,6 +1453,16 @@ struct q3_session {
 #endif
     ~q3_session();
 };
+
+// Everything this session has in flight has landed: the frames on the library's own AQL queue (q3_aql.cpp; not ordered with any
+// HIP stream) and whatever rides the session's stream. Every host-side wait of the engine goes through here.
+static hipError_t sync_frames(q3_session* s) {
+    if (s->aql) {
+        std::string why;
+        if (!q3::aql_wait(s->aql, &why)) { s->aql_failed = true; set_err(Q3_HIP_ERROR, "AQL frame submission: %s", why.c_str()); return hipErrorUnknown; }
+    }
+    return hipStreamSynchronize(s->stream);
+}
 
 static hipError_t run_linear(q3_session* s, const LinArgs& a_in) {
     LinArgs a = a_in;
@@ -1540,7 +1551,7 @@ static q3_status kv_convert_to_bf16(q3_session* s) {
     hipError_t e = hipMemcpyAsync(s->kv_conv, src.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(s->kv_conv + (size_t)s->B * KV_MAX_PAGES, dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream);
     if (e == hipSuccess) e = launch_kv_pages_to_bf16(s->kv_conv, s->kv_conv + (size_t)s->B * KV_MAX_PAGES, n, c.n_layers, c.n_kv_heads, s->m->kv_pool.layer_stride(), s->m->kv_pool.v_delta(), s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = sync_frames(s);
     if (e != hipSuccess) { for (auto& f : fresh) if (!f.empty()) s->m->kv_pool16.give(f); return set_err(Q3_HIP_ERROR, "K/V conversion to bf16: %s", hipGetErrorString(e)); }
     for (int b = 0; b < s->B; ++b) {
         s->m->kv_pool.give(s->kv_rows[(size_t)b]);
@@ -1548,7 +1559,7 @@ static q3_status kv_convert_to_bf16(q3_session* s) {
         if (!s->kv_rows[(size_t)b].empty())
             HIPC(hipMemcpyAsync(s->kv_table + (size_t)b * KV_MAX_PAGES, s->kv_rows[(size_t)b].data(), s->kv_rows[(size_t)b].size() * 8, hipMemcpyHostToDevice, s->stream));
     }
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     s->kv_in_bf16 = true;
     return Q3_OK;
 }
@@ -2309,14 +2320,14 @@ static q3_status prefill_gemm(q3_session* s, int S_all, int S, bool with_head) {
             HIPC(split(dn)); HIPC(launch_lm_gemm(dn, s->stream));
         }
     }
-    if (!with_head) { HIPC(hipStreamSynchronize(s->stream)); return Q3_OK; }      // the caller runs the remaining positions
+    if (!with_head) { HIPC(sync_frames(s)); return Q3_OK; }      // the caller runs the remaining positions
     // head on each sequence's last position (row b*ch + ch-1 of the last chunk): final norm -> LASTH, codec_head -> LOGITS
     HIPC(launch_rmsnorm(X + (size_t)(ch - 1) * H, ch * H, m->norm, s->LASTH, H, B, H, c.rms_eps, s->stream));
     LinArgs h;
     h.N = c.codec_vocab; h.K = H; set_w(h, m->codec_head, B, h.N, h.K); h.x = s->LASTH; h.ldx = H; h.y = s->LOGITS; h.ldy = c.codec_vocab;
     h.M = B; h.epi = EPI_NONE;
     HIPC(run_linear(s, h));
-    HIPC(hipStreamSynchronize(s->stream));      // tmp buffers are freed on return
+    HIPC(sync_frames(s));      // tmp buffers are freed on return
     return Q3_OK;
 }
 
@@ -2352,7 +2363,7 @@ static q3_status prefill_ragged(q3_session* s) {
         std::vector<int> lim(rows.size(), 0);
         for (size_t j = 0; j < rows.size() && st == Q3_OK; ++j) st = transplant_check(s, side.get(), (int)j, limits[j], &lim[j]);
         if (st == Q3_OK) st = q3_session_prefill(side.get());
-        if (st == Q3_OK && hipStreamSynchronize(s->stream) != hipSuccess) st = set_err(Q3_HIP_ERROR, "ragged prefill: stream");
+        if (st == Q3_OK && sync_frames(s) != hipSuccess) st = set_err(Q3_HIP_ERROR, "ragged prefill: stream");
         for (size_t j = 0; j < rows.size() && st == Q3_OK; ++j) st = transplant_row(s, rows[j], side.get(), (int)j, lim[j]);
         if (st != Q3_OK) { s->prefilled = false; return st; }
     }
@@ -2360,6 +2371,7 @@ static q3_status prefill_ragged(q3_session* s) {
     return Q3_OK;
 }
 
+static q3_status frame_capture(q3_session* s, bool stream_busy);
 extern "C" q3_status q3_session_prefill(q3_session* s) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     if (s->prefilled) return set_err(Q3_INVALID_ARG, "session already prefilled");
@@ -2439,7 +2451,7 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
                                      s->ref_codes_dev ? s->ref_codes_dev + ref_off[b] : nullptr, m->cp_embs_dev);
         if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "prefill assembly: %s", hipGetErrorString(e));
     }
-    if (st != Q3_OK) { (void)hipStreamSynchronize(s->stream); return st; }
+    if (st != Q3_OK) { (void)sync_frames(s); return st; }
     // 2. run_prefill_layers (talker.rs:823-841): causal attention ⇒ token-by-token decode steps
     //    and the GEMV kernels take up to 16 rows for the price of one, so each weight pass carries a CHUNK of
     //    16/B consecutive positions per sequence (q3_kernels.h AttnArgs::rows_per_seq). Bit-identical to the
@@ -2476,7 +2488,11 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
     HIPC(hipMemcpyAsync(s->token_count, zero.data(), B * 4, hipMemcpyHostToDevice, s->stream));
     SampleArgs a; fill_sample_args(s, a); a.advance = 0;
     HIPC(launch_sample(a, s->stream));
-    HIPC(hipStreamSynchronize(s->stream));
+    // Callers that are going to replay the frame (q3_session_run, q3_session_next_chunk) have it captured and converted HERE, while
+    // the prompt's kernels run: ~2 ms of host work that used to sit between the prefill and the first frame (time to first audio).
+    // (bf16-KV sessions capture later: which attention kernel the frame holds depends on the conversion below.)
+    if (s->precapture && !s->kv_bf16 && !s->debug && !s->profile) Q3C(frame_capture(s, true));
+    HIPC(sync_frames(s));
     if (s->kv_bf16 && !s->kv_in_bf16) Q3C(kv_convert_to_bf16(s));       // the prompt's K/V moves into pages of the bf16 pool, once
     s->prefilled = true; s->frames_run = 0; s->codes_host_valid = false;
     return Q3_OK;
@@ -2484,7 +2500,7 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
 
 static q3_status refresh_codes(q3_session* s) {
     if (s->codes_host_valid) return Q3_OK;
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     s->codes_host.resize((size_t)s->B * s->max_frames * 16);
     for (int b = 0; b < s->B; ++b) {
         int ran = s->frames_run - s->seq[b].start_run;
@@ -2550,33 +2566,34 @@ static void frame_fence_policy(const char* name, int* acquire, int* release) {
     if (drop_rel) *release = 0;
 }
 
-extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_graph) {
-    if (!s) return set_err(Q3_INVALID_ARG, "null session");
-    if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
-    HIPC(hipSetDevice(s->m->device));
-    if (s->debug || s->profile) use_graph = 0;
-    int todo = n_frames;
-    { const int left = session_remaining(s); if (todo > left) todo = left; }
-    if (todo <= 0) return Q3_OK;
-    Q3C(kv_reserve_frames(s, todo));        // paged KV: every page these frames can reach, before the first of them is queued
-    if (use_graph && !s->graph_exec) {
-        HIPC(hipStreamSynchronize(s->stream));
-        HIPC(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+// The frame is captured ONCE per session (frame_launch under stream capture: every per-frame quantity lives in device memory, so
+// the graph is static) and turned into the packet program of the library's own AQL queue (q3_aql.cpp); only a graph the converter
+// cannot take — or Q3_AQL=0 — is instantiated for hipGraphLaunch. `stream_busy`: the caller has work queued on the session's
+// stream that must NOT be waited for here (q3_session_prefill captures while the prompt's kernels run: capture, conversion and
+// the kernarg upload are host work, ~2 ms that used to sit between the prefill and the first frame of every session).
+// Q3_AQL unset / 3 (round 6: the default; the whole -m gpu suite runs through it): boundaries between kernels that keep to the
+// activation-transport rule (q3_kernels.h) without HIP's agent-scope fences. Q3_AQL=0: hipGraphLaunch; 1: own queue with HIP's
+// fences on every packet (bit-identical to 0); 2: probe. Why a graph stayed on hipGraphLaunch: Q3_AQL_VERBOSE=1.
+static q3_status frame_capture(q3_session* s, bool stream_busy) {
+    if (!s->graph) {
+        if (!stream_busy) HIPC(sync_frames(s));
+        {
+            const hipError_t eb = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal);
+            if (eb != hipSuccess && stream_busy) { (void)hipGetLastError(); return Q3_OK; }      // not now: q3_session_generate captures on the idle stream
+            HIPC(eb);
+        }
         q3_status st = frame_launch(s);
         hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
         Q3C(st);
         if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        HIPC(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
     }
-    // Q3_AQL=1 / 2: replay the frame as packets on the library's own AQL queue (q3_aql.cpp) instead of hipGraphLaunch;
-    // Q3_AQL=0 / unset: hipGraphLaunch. A graph the converter cannot take stays on hipGraphLaunch (reason: Q3_AQL_VERBOSE=1).
-    if (use_graph && !s->aql && !s->aql_tried) {
+    if (!s->aql && !s->aql_tried) {
         s->aql_tried = true;
         const char* e = getenv("Q3_AQL");
-        int mode = e ? atoi(e) : 0;
-        // Packets without boundary fences give WRONG codes with the product kernels (plain loads and stores): mode 2
-        // and the fence halves are probes and need an explicit opt-in, so that a stray environment variable cannot silently
-        // corrupt a server's output.
+        int mode = e ? atoi(e) : 3;
+        // Packets without ANY boundary fence give WRONG codes (state that crosses frames moves with plain accesses):
+        // mode 2 and the fence halves are probes and need an explicit opt-in, so that a stray environment variable cannot
+        // silently corrupt a server's output.
         const bool unsafe_ok = getenv("Q3_AQL_UNSAFE") && atoi(getenv("Q3_AQL_UNSAFE")) == 1;
         const bool wants_unsafe = mode == 2 || getenv("Q3_AQL_ACQ") || getenv("Q3_AQL_REL");
         if (wants_unsafe && !unsafe_ok) {
@@ -2600,24 +2617,52 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
             else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
         }
     }
+    if (!s->aql && !s->graph_exec) HIPC(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
+    return Q3_OK;
+}
+// `n` replays of the captured frame enqueued WITHOUT waiting for them (streaming read-ahead): on the own queue behind whatever it
+// holds, or as graph launches on the session's stream. The caller reserved the K/V pages (kv_reserve_frames) and, on the own queue,
+// made sure everything the first frame reads has landed (the queue is not ordered with the HIP stream). sync_frames waits for both.
+static q3_status frames_enqueue(q3_session* s, int n) {
+    if (n <= 0) return Q3_OK;
+    if (s->aql) {
+        std::string why; int handed = 0;
+        const bool ok = q3::aql_submit(s->aql, n, &why, &handed);
+        s->frames_run += handed;
+        if (!ok) { s->aql_failed = true; s->codes_host_valid = false; return set_err(Q3_HIP_ERROR, "AQL frame submission: %s", why.c_str()); }
+    } else {
+        if (!s->graph_exec) return set_err(Q3_INVALID_ARG, "frames_enqueue: no captured frame");
+        for (int i = 0; i < n; ++i) HIPC(hipGraphLaunch(s->graph_exec, s->stream));
+        s->frames_run += n;
+    }
+    s->codes_host_valid = false;
+    return Q3_OK;
+}
+
+extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_graph) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    if (!s->prefilled) return set_err(Q3_INVALID_ARG, "session not prefilled");
+    if (s->aql_failed) return set_err(Q3_HIP_ERROR, "session unusable: an earlier frame submission on the AQL queue failed or timed out");
+    HIPC(hipSetDevice(s->m->device));
+    if (s->debug || s->profile) use_graph = 0;
+    int todo = n_frames;
+    { const int left = session_remaining(s); if (todo > left) todo = left; }
+    if (todo <= 0) return Q3_OK;
+    Q3C(kv_reserve_frames(s, todo));        // paged KV: every page these frames can reach, before the first of them is queued
+    if (use_graph) Q3C(frame_capture(s, false));
     bool on_aql = use_graph && s->aql;
-    if (on_aql) HIPC(hipStreamSynchronize(s->stream));     // the queue is not ordered with the HIP stream: prefill / swaps must have landed
+    if (on_aql) HIPC(sync_frames(s));     // the queue is not ordered with the HIP stream: prefill / swaps must have landed
     bool eos_on = false;
     for (const auto& q : s->seq) eos_on = eos_on || q.req.opts.eos_token_id >= 0;
     const int check_every = 32;
     while (todo > 0) {
         const int burst = eos_on ? (todo < check_every ? todo : check_every) : todo;
         if (on_aql) {
-            std::string why; int handed = 0;
-            const bool ok = q3::aql_submit(s->aql, burst, &why, &handed) && q3::aql_wait(s->aql, &why);
-            s->frames_run += handed;                       // frames the device was given, also when the submission failed half way
-            if (!ok) {
-                // the own queue is unusable from here on (q3_aql.cpp marks the program dead): later calls replay through
-                // hipGraphLaunch; this call reports the failure with frames_run in step with what was submitted
-                s->aql_mode = 0; q3::aql_program_destroy(s->aql); s->aql = nullptr;
-                s->codes_host_valid = false;
-                return set_err(Q3_HIP_ERROR, "AQL frame submission: %s", why.c_str());
-            }
+            // (a failed submission or wait marks the session failed: the ring may still hold — or run — packets that write this
+            // session's buffers, so nothing may replay behind them; frames_run stays in step with what the device was given)
+            q3_status st = frames_enqueue(s, burst);
+            if (st == Q3_OK && sync_frames(s) != hipSuccess) st = Q3_HIP_ERROR;
+            if (st != Q3_OK) { s->aql_failed = true; s->codes_host_valid = false; return st; }
         } else
         for (int i = 0; i < burst; ++i) {
             if (use_graph) HIPC(hipGraphLaunch(s->graph_exec, s->stream));
@@ -2628,7 +2673,7 @@ extern "C" q3_status q3_session_generate(q3_session* s, int n_frames, int use_gr
         s->codes_host_valid = false;
         if (eos_on) { Q3C(refresh_codes(s)); if (all_done(s)) break; }
     }
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     if (s->profile && !s->prof_events.empty()) {
         for (size_t i = 0; i < s->prof_events.size(); ++i) {
             float ms = 0; hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second);
@@ -2687,7 +2732,7 @@ static q3_status transplant_row(q3_session* s, int b, q3_session* side, int j, i
     HIPC(hipMemcpyAsync(s->limit + b, &hv[3], 4, hipMemcpyHostToDevice, s->stream));
     const SampleRow srow = sample_row(sq.req.opts);
     HIPC(hipMemcpyAsync(s->sample_rows + b, &srow, sizeof srow, hipMemcpyHostToDevice, s->stream));
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     SeqInfo nq = sq;
     nq.row_base = row0; nq.trail_base = hv[0]; nq.pad_row = hv[2];
     nq.start_run = s->frames_run; nq.limit = limit; nq.n_frames = 0; nq.done = false; nq.stream_pos = 0; nq.req.opts.max_length = limit; nq.idle = false;
@@ -2742,7 +2787,7 @@ extern "C" q3_status q3_session_replace(q3_session* s, int b, const q3_request* 
     Q3C(transplant_check(s, side.get(), 0, limit_req, &limit));
     Q3C(q3_session_prefill(side.get()));               // ends with a synchronisation of the side stream
     lap("prefill");
-    HIPC(hipStreamSynchronize(s->stream));             // no frame of the host session in flight while its row changes
+    HIPC(sync_frames(s));             // no frame of the host session in flight while its row changes
     Q3C(transplant_row(s, b, side.get(), 0, limit));
     lap("copies");
     side.reset();
@@ -2781,7 +2826,7 @@ static q3_status session_idle_row(q3_session* s, int b) {
     SeqInfo& q = s->seq[b];
     int ran = s->frames_run - q.start_run; if (ran < 0) ran = 0; if (ran > q.limit) ran = q.limit;
     q.limit = ran;
-    HIPC(hipStreamSynchronize(s->stream));          // no frame in flight while the row's limit and pages change
+    HIPC(sync_frames(s));          // no frame in flight while the row's limit and pages change
     HIPC(hipMemcpy(s->limit + b, &q.limit, sizeof(int), hipMemcpyHostToDevice));
     // A frozen row still runs through every frame (its results are dropped): it reads its keys and rewrites the K/V of its
     // frozen position, prefill_len + ran. It keeps the ONE page that position lies in and every table entry it can reach points
@@ -3044,7 +3089,7 @@ extern "C" q3_status q3_session_next_chunk_row(q3_session* s, int b, float* pcm_
         Q3C(codec_reserve(s->m, s->cws, chunk + CODEC_CTX_FRAMES, s->max_frames));
         HIPC(hipMemcpyAsync(s->cws.frames, s->codes + (size_t)b * s->max_frames * 16, (size_t)e * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
         Q3C(codec_decode_dev(s->m, s->cws, e, s->stream, nullptr, c0));
-        HIPC(hipStreamSynchronize(s->stream));
+        HIPC(sync_frames(s));
         if (n_samples) *n_samples = (size_t)avail * spf;
         if (pcm_host) {
             if (cap < (size_t)avail * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
@@ -3114,7 +3159,7 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
         HIPC(hipMemcpyAsync(s->cws.frames, q.ref_codes.data(), (size_t)n_ref * 16 * 4, hipMemcpyHostToDevice, s->stream));
         if (T > 0) HIPC(hipMemcpyAsync(s->cws.frames + (size_t)n_ref * 16, s->codes + (size_t)b * s->max_frames * 16, (size_t)T * 16 * 4, hipMemcpyDeviceToDevice, s->stream));
         Q3C(codec_decode_dev(s->m, s->cws, total, s->stream, nullptr));
-        HIPC(hipStreamSynchronize(s->stream));
+        HIPC(sync_frames(s));
         if (pcm_host) {
             if (cap < all - cut) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
             HIPC(hipMemcpy(pcm_host, s->cws.pcm + cut, (all - cut) * 4, hipMemcpyDeviceToHost));
@@ -3147,6 +3192,7 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = clk::now();
+    s->precapture = use_graph != 0;
     Q3C(q3_session_prefill(s));
     const auto t1 = clk::now();
     const int overlap_env = [] { const char* e = getenv("Q3_DECODE_OVERLAP"); return e ? atoi(e) : 0; }();     // read per call: opt-in, tests set it per test
@@ -3289,7 +3335,7 @@ extern "C" q3_status q3_session_set_stream_mode(q3_session* s, int mode) {
 extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_t cap, size_t* n_samples, int* done) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     if (s->B != 1) return set_err(Q3_UNSUPPORTED, "streaming sessions are batch 1 (StreamingSession, lib.rs:1484)");
-    if (!s->prefilled) Q3C(q3_session_prefill(s));
+    if (!s->prefilled) { s->precapture = true; Q3C(q3_session_prefill(s)); }
     Q3C(refresh_codes(s));
     SeqInfo& q = s->seq[0];
     const int chunk = s->opts.chunk_frames > 0 ? s->opts.chunk_frames : 10;
@@ -3312,18 +3358,16 @@ extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_
     // Q3_STREAM_NO_AHEAD=1 restores the serial schedule (A/B aid).
     static const bool no_ahead = getenv("Q3_STREAM_NO_AHEAD") != nullptr;
     int ahead = 0;
-    if (!no_ahead && !q.done && s->graph_exec && !s->debug && !s->profile) {
+    if (!no_ahead && !q.done && (s->aql || s->graph_exec) && !s->aql_failed && !s->debug && !s->profile) {
         ahead = chunk - (q.n_frames - (s->stream_pos + avail));
         if (ahead > session_remaining(s)) ahead = session_remaining(s);
         if (ahead < 0) ahead = 0;
     }
     const bool first = s->stream_pos == 0;
     auto launch_ahead = [&]() -> q3_status {
-        Q3C(kv_reserve_frames(s, ahead));
-        for (int i = 0; i < ahead; ++i) HIPC(hipGraphLaunch(s->graph_exec, s->stream));
-        s->frames_run += ahead;
-        s->codes_host_valid = false;                            // the next call re-reads codes / EOS state after a sync
-        return Q3_OK;
+        Q3C(kv_reserve_frames(s, ahead));                        // (its table updates ride s->stream)
+        if (s->aql) HIPC(hipStreamSynchronize(s->stream));       // the own queue is not ordered with the stream
+        return frames_enqueue(s, ahead);                         // the next call re-reads codes / EOS state after sync_frames
     };
     hipStream_t dst = s->stream;
     if (ahead > 0 && !first) {
@@ -3372,7 +3416,7 @@ extern "C" q3_status q3_session_get(q3_session* s, int what, int b, void* out, s
     if (!s || !out || b < 0 || b >= s->B) return set_err(Q3_INVALID_ARG, "bad argument");
     const q3_config& c = s->m->cfg;
     HIPC(hipSetDevice(s->m->device));
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     const void* src = nullptr; size_t need = 0;
     switch (what) {
         case Q3_GET_PREFILL_EMBEDS: src = s->embeds + (size_t)b * s->prefill_len * c.hidden; need = (size_t)s->prefill_len * c.hidden * 4; break;
@@ -3416,14 +3460,14 @@ extern "C" q3_status q3_talker_step(q3_session* s, const float* embeds_host, flo
     HIPC(hipSetDevice(s->m->device));
     // the step writes K/V at `pos`: refuse BEFORE running when that slot does not exist (a step at pos == max_seq - 1 is valid)
     std::vector<int> posv(s->B);
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     HIPC(hipMemcpy(posv.data(), s->pos, s->B * 4, hipMemcpyDeviceToHost));
     for (int p : posv) if (p >= s->max_seq) return set_err(Q3_KV_OVERFLOW, "KV cache full (%d)", s->max_seq);
     for (int b = 0; b < s->B; ++b) Q3C(kv_reserve_row(s, b, posv[(size_t)b] + 1));       // paged KV: the slot this step writes
     HIPC(hipMemcpyAsync(s->tb.X, embeds_host, (size_t)s->B * c.hidden * 4, hipMemcpyHostToDevice, s->stream));
     Q3C(talker_step(s, s->pos, 0, true));
     // advance positions by one (host-driven teacher forcing)
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     for (int& p : posv) p += 1;
     HIPC(hipMemcpy(s->pos, posv.data(), s->B * 4, hipMemcpyHostToDevice));
     if (hidden_host) HIPC(hipMemcpy(hidden_host, s->LASTH, (size_t)s->B * c.hidden * 4, hipMemcpyDeviceToHost));
@@ -3470,7 +3514,7 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
                 HIPC(launch_linear(h, s->stream));
             }
         }
-        HIPC(hipStreamSynchronize(s->stream));
+        HIPC(sync_frames(s));
         return Q3_OK;
     };
     st = run();
@@ -3606,7 +3650,7 @@ extern "C" q3_status q3_debug_trace_enable(q3_session* s, int max_nodes) {
 }
 extern "C" q3_status q3_debug_trace_read(q3_session* s, unsigned long long* stamps_host, int* meta_host, int cap_nodes, int* n_nodes) {
     if (!s || !s->trace_buf || !n_nodes) return set_err(Q3_INVALID_ARG, "q3_debug_trace_read");
-    HIPC(hipStreamSynchronize(s->stream));
+    HIPC(sync_frames(s));
     const int n = (int)s->trace_meta.size();
     *n_nodes = n;
     if (stamps_host && meta_host) {
@@ -3624,7 +3668,7 @@ extern "C" q3_status q3_debug_trace_read(q3_session* s, unsigned long long* stam
 
 extern "C" q3_status q3_session_submit_info(q3_session* s, int* path, int* nodes) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
-    if (path) *path = s->aql ? 1 + s->aql_mode : s->graph_exec ? 1 : 0;
+    if (path) *path = s->aql ? 1 + s->aql_mode : s->graph ? 1 : 0;
     if (nodes) *nodes = s->aql ? q3::aql_program_nodes(s->aql) : 0;
     return Q3_OK;
 }

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     constexpr bool COAL = true;
     const int crow = HALF ? lane >> 3 : lane >> 2, cchunk = HALF ? lane & 7 : 2 * (lane & 3);
     const bool cact = crow < a.M;
-    const int xc = ((cact ? crow : 0) * a.ldx + cchunk * 4) * 4;
+    const int xc = (__mul24(cact ? crow : 0, a.ldx) + cchunk * 4) * 4;      // (24-bit multiply-add: the 64-bit v_mad form took a pending load's register as its undefined high half and waited for it)
     const int bsrc = HALF ? ((xrow * 8) + 2 * kg + (m >> 3)) * 4 : (m * 4 + kg) * 4;
 
     // bias and residual of the k = 0 half, requested up front — and NOT combined here: `resid + bias` at this point made the compiler wait

@@ -19,8 +19,11 @@ from make_golden_bench import bench_utt, tap_indices, pcm_decimate_idx, N_FRAMES
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-MARGIN_EPS = 2e-3          # greedy decisions: tolerated only below this oracle top-2 logit margin
-LOGIT_NOISE = 2e-4         # sampled decisions: tolerated only if logit noise of this size reproduces the GPU's token
+# Round 6: the allowances follow what is MEASURED — every logit of every configuration is within 3.6e-5 of the
+# oracle (gpurun_out/bench_teacher_forced_m8.json, bench_long_context_b8.json) — instead of 2e-3 / 2e-4, which a real 1e-3 kernel
+# regression would have passed as a "near-tie".
+MARGIN_EPS = 2e-4          # greedy decisions: tolerated only below this oracle top-2 logit margin
+LOGIT_NOISE = 5e-5         # sampled decisions: tolerated only if logit noise of this size reproduces the GPU's token
 
 
 def _dump(name, obj):

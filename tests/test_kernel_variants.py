@@ -45,7 +45,7 @@ def test_variants_give_the_default_codes(tmp_path, B):
     F = 48
     base = _run(tmp_path, "default", {}, B, F)
     assert base.shape == (B, F, 16)
-    exact = {"contiguous_kv": {"Q3_KV_CONTIGUOUS": "1"}, "own_aql_queue": {"Q3_AQL": "1"}, "gather_unfolded": {"Q3_CP_NO_FOLD": "1"},
+    exact = {"contiguous_kv": {"Q3_KV_CONTIGUOUS": "1"}, "hip_graph_launch": {"Q3_AQL": "0"}, "own_aql_queue_hip_fences": {"Q3_AQL": "1"}, "gather_unfolded": {"Q3_CP_NO_FOLD": "1"},
              "two_instruction_x": {"Q3_GEMV_NO_HALF": "1"}}
     for name, env in exact.items():
         got = _run(tmp_path, name, env, B, F)
