@@ -1616,7 +1616,10 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
     // predictor o / down: 9.4 + 4.9 us -> one launch). Q3_WIDE_NO_SK2=1: off (A/B aid)
     static const bool wide_sk2 = getenv("Q3_WIDE_NO_SK2") == nullptr;
     const bool sk_rows = s->ksplit && B >= 3 && (B <= 16 || (wide_sk2 && B <= Q3_MAX_BATCH && rows_per_seq == 1)) && d.H <= 2048 && d.H % 4 == 0;
-    const bool o_sk = sk_rows && !first2 && !attn3 && w.o.t1 && QD >= 2048 && up32(QD) / 32 >= 16;
+    // (round 6: also behind the code predictor's 2-token first pass — 16 rows at B = 8 — whose o-projection ran on k_gemv_lds with
+    // 64 workgroups: 5.8 us against 3.6 as two K halves; Q3_FIRST2_NO_SK=1: the old kernel, A/B aid)
+    static const bool first2_sk = getenv("Q3_FIRST2_NO_SK") == nullptr;
+    const bool o_sk = sk_rows && (!first2 || first2_sk) && !attn3 && w.o.t1 && QD >= 2048 && up32(QD) / 32 >= 16;
     // (beyond 32 rows the 25 MB talker down-proj is re-read by every 16-row block — 32.0 us at B = 64 against 16.5 + 4.8 for
     // the GEMM pair — while the smaller matrices win: code predictor o 14.6 -> 6.8, down 15.7 -> 9.2, talker o 14.4 -> 11.7 us)
     const bool dn_big = B > 32 && (size_t)d.I * d.H * 2 > ((size_t)12 << 20);
@@ -1627,6 +1630,7 @@ static q3_status lm_layer(q3_session* s, const LmDims& d, const LayerW& w, LmBuf
             t.g_tok = fold->tok; t.g_qkv_tab = fold->qkv_tab; t.g_proj_tab = fold->proj_tab; t.g_proj_dim = fold->proj_dim;
             t.g_x = fold->out; t.g_ldx = fold->ld_out;
         }
+        if (o_sk) { t.zero = b.SUM; t.zero_n = B * d.H; }
         HIPC(launch_attn_first2(t, s->stream));    // the code predictor's 2-token first pass
     } else if (attn3) {     // rows of one sequence depend on each other's K/V: three launches
         HIPC(launch_qknorm_rope_kv(t, s->stream));
@@ -2575,17 +2579,21 @@ static void frame_fence_policy(const char* name, int* acquire, int* release) {
 // activation-transport rule (q3_kernels.h) without HIP's agent-scope fences. Q3_AQL=0: hipGraphLaunch; 1: own queue with HIP's
 // fences on every packet (bit-identical to 0); 2: probe. Why a graph stayed on hipGraphLaunch: Q3_AQL_VERBOSE=1.
 static q3_status frame_capture(q3_session* s, bool stream_busy) {
-    if (!s->graph) {
+    // (another host thread's allocations or null-stream work can invalidate a capture in progress on this HIP runtime, thread-local
+    // capture mode or not — the batcher's prefill worker, a server opening sessions on several threads: the capture is repeated)
+    for (int attempt = 0; !s->graph; ++attempt) {
         if (!stream_busy) HIPC(sync_frames(s));
         {
             const hipError_t eb = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal);
             if (eb != hipSuccess && stream_busy) { (void)hipGetLastError(); return Q3_OK; }      // not now: q3_session_generate captures on the idle stream
             HIPC(eb);
         }
-        q3_status st = frame_launch(s);
-        hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
-        Q3C(st);
-        if (e != hipSuccess) return set_err(Q3_HIP_ERROR, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        const q3_status st = frame_launch(s);
+        const hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
+        if (st == Q3_OK && e == hipSuccess && s->graph) break;
+        if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+        (void)hipGetLastError();
+        if (attempt >= 3) { Q3C(st); return set_err(Q3_HIP_ERROR, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
     }
     if (!s->aql && !s->aql_tried) {
         s->aql_tried = true;
@@ -2818,7 +2826,22 @@ struct q3_batcher {
     std::vector<int64_t> queue;                       // FIFO of waiting tickets
     std::unordered_map<int64_t, std::unique_ptr<BatTicket>> t;
     int64_t next_id = 1;
+    // Round 6: the head of the queue is prefilled AHEAD of the row it will enter. A worker thread opens its one-row side session
+    // and runs the (unchanged) prefill on a stream of its own while the captured frame keeps replaying for the live rows — the
+    // frame leaves most of the chip idle —; when a row ends, the swap is only the state copy (transplant_row) at that frame
+    // boundary. The other rows used to stand still for the whole side prefill (1.9 ms for a short prompt, 45 ms for a 4k-token
+    // one). Bits are unchanged: the same kernels on the same inputs, only on another stream. Off under a page limit
+    // (q3_model_kv_pool_limit: admission must see a row's pages when it decides) and with Q3_BAT_NO_STAGE=1 (A/B aid).
+    struct Stage {
+        int64_t id = -1; std::thread thr; q3_session* side = nullptr; q3_status st = Q3_OK; std::string err; int limit = 0;
+    } stage;
 };
+static void stage_join(q3_batcher* b) { if (b->stage.thr.joinable()) b->stage.thr.join(); }
+static void stage_drop(q3_batcher* b) {
+    stage_join(b);
+    if (b->stage.side) { q3_session_free(b->stage.side); b->stage.side = nullptr; }
+    b->stage.id = -1; b->stage.st = Q3_OK; b->stage.err.clear();
+}
 
 // a row that has nothing to do: frozen on the device from its current frame on (rows of a freshly opened session that no
 // request occupies yet)
@@ -2865,6 +2888,7 @@ extern "C" q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget,
 }
 extern "C" void q3_batcher_free(q3_batcher* b) {
     if (!b) return;
+    stage_drop(b);
     if (b->s) q3_session_free(b->s);
     delete b;
 }
@@ -2976,13 +3000,57 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
                 }
                 b->queue.erase(b->queue.begin());
                 t.req.r.opts.chunk_frames = b->chunk_frames;        // the one option a session shares
-                const q3_status st = q3_session_replace(b->s, r, &t.req.r);
+                q3_status st;
+                if (b->stage.id == id) {
+                    // prefilled ahead on the worker's stream: wait for it (normally long done), then only the state copy stands
+                    // between two frames of the live rows
+                    stage_join(b);
+                    st = b->stage.st;
+                    if (st != Q3_OK) set_err(st, "%s", b->stage.err.c_str());
+                    else {
+                        st = sync_frames(b->s) == hipSuccess ? Q3_OK : Q3_HIP_ERROR;      // no frame of the host session in flight while its row changes
+                        if (st == Q3_OK) st = transplant_row(b->s, r, b->stage.side, 0, b->stage.limit);
+                    }
+                    stage_drop(b);
+                } else
+                    st = q3_session_replace(b->s, r, &t.req.r);
                 if (st != Q3_OK) { bat_fail(t, st); finished++; continue; }     // does not fit: the ticket carries the reason; try the next one
                 t.state = Q3_TICKET_RUNNING; t.row = r; b->owner[r] = id; b->commit[r] = units;
                 break;
             }
         }
         return Q3_OK;
+    };
+    // the head of the queue starts its prefill on the worker (see q3_batcher::Stage); called with frames about to be queued
+    auto stage_begin = [&]() {
+        static const bool off = getenv("Q3_BAT_NO_STAGE") != nullptr;
+        if (off || b->stage.id >= 0 || b->queue.empty() || b->s->debug || b->s->profile) return;
+        // not while this thread may still CAPTURE the host session's frame (the first graph step): the worker's allocations and
+        // null-stream zero-fills invalidate a capture in progress on this HIP runtime, thread-local capture mode or not
+        if (use_graph ? b->s->graph == nullptr : false) return;
+        { std::lock_guard<std::mutex> g(b->m->kv_budget.mu); if (b->m->kv_budget.limit > 0) return; }
+        bool any_free = false;
+        for (int r = 0; r < b->slots; ++r) any_free = any_free || b->owner[r] < 0;
+        if (any_free) return;                        // a free row takes the head at once (fill): nothing to run ahead of
+        const int64_t id = b->queue.front();
+        BatTicket& t = *b->t[id];
+        q3_request rq = t.req.r;                     // (arrays owned by the ticket, which lives until it is fetched)
+        rq.opts.chunk_frames = b->chunk_frames;
+        const int limit_req = rq.opts.max_length;
+        if (limit_req < 1 || limit_req > b->s->max_frames) return;      // the synchronous path reports it on the ticket
+        rq.opts.max_length = b->s->max_frames;       // the side session draws the row's PCG stream with the host session's stride
+        b->stage.id = id; b->stage.st = Q3_OK; b->stage.err.clear(); b->stage.side = nullptr; b->stage.limit = 0;
+        q3_batcher* bp = b;
+        b->stage.thr = std::thread([bp, rq, limit_req]() {
+            q3_batcher::Stage& g = bp->stage;
+            q3_session* side = nullptr;
+            q3_status st = hipSetDevice(bp->m->device) == hipSuccess ? Q3_OK : set_err(Q3_HIP_ERROR, "hipSetDevice");
+            if (st == Q3_OK) st = session_create(bp->m, &rq, 1, 0, 0, &side);          // a stream of its own: runs beside the frames
+            if (st == Q3_OK) { side->kv_bf16 = bp->s->kv_bf16; st = transplant_check(bp->s, side, 0, limit_req, &g.limit); }
+            if (st == Q3_OK) st = q3_session_prefill(side);                            // ends with a synchronisation of that stream
+            g.side = side; g.st = st;
+            if (st != Q3_OK) g.err = q3_last_error();
+        });
     };
     // Run in pieces that end where the next row reaches its frame limit: that row is collected and refilled at once instead of
     // idling to the end of the step (a row that ends on EOS is noticed at q3_session_generate's 32-frame check or at the
@@ -2997,6 +3065,7 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
             if (rem > 0) { busy++; if (rem < piece) piece = rem; }
         }
         if (busy > 0) {
+            stage_begin();
             const q3_status gst = q3_session_generate(b->s, piece, use_graph);
             if (gst == Q3_KV_OVERFLOW && b->s->kv_overflow_row >= 0 && b->owner[b->s->kv_overflow_row] >= 0) {
                 // (only reachable when something outside this batcher took the pages its admission counted on) nothing ran: the
@@ -3014,6 +3083,11 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
         int collected = 0;
         for (int r = 0; r < b->slots; ++r) {
             if (b->owner[r] < 0) continue;
+            {   // a row without a live EOS id ends exactly at its frame limit, which the host knows: no device read-back (a
+                // synchronisation and nine blocking copies per step) while no row can have ended
+                const SeqInfo& q = b->s->seq[r];
+                if (q.req.opts.eos_token_id < 0 && b->s->frames_run - q.start_run < q.limit) continue;
+            }
             int n = 0, done = 0;
             Q3C(q3_session_frames(b->s, r, &n, &done));
             if (done) { Q3C(bat_collect(b, r)); finished++; collected++; }

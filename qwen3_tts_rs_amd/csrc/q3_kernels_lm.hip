@@ -850,6 +850,8 @@ __global__ __launch_bounds__(256) void k_attn_first2(AttnArgs a) {
         const __amdgpu_buffer_rsrc_t pd = act_rsrc(a.g_x + (size_t)b * a.g_ldx);
         for (int c = tid; c < a.g_proj_dim / 4; c += 256) act_st4(pd, c * 16, ps[c]);
     }
+    // side job behind the loads: the split-K o-projection that follows adds its halves onto zeros (AttnArgs::zero, as in k_attn_cp)
+    zero_job(a.zero, a.zero_n, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, 256);
     __syncthreads();
     const float scale = 0.08838834764831845f;
     for (int r = wave; r < NREP; r += 4) {

@@ -244,6 +244,48 @@ def test_native_batcher_1_7b(gm17):
     assert bad <= 1, bad
 
 
+def test_batcher_stages_a_4k_prompt_beside_running_rows_1_7b(gm17):
+    """a swap no longer stalls the session. Eight CustomVoice rows run; the head of the queue — the 4105-position
+    VoiceDesign prompt of config[4], ~45 ms of prefill — is prefilled AHEAD on the batcher's worker thread and stream while the
+    captured frame keeps replaying (q3_batcher::Stage), enters the row that ends first at a frame boundary, and a CustomVoice request
+    follows it the same way. Every request must come back with the oracle's codes: the 4k request its fixture's first 24 default-
+    sampling frames, the CustomVoice rows theirs — and the same with staging off (Q3_BAT_NO_STAGE is read once per process, so the
+    unstaged run is the batch-1 comparison of test_frames_behind_4k_prompt_1_7b)."""
+    from make_golden_bench import prefill4k_utt
+    ref = np.load(os.path.join(G, "bench_1_7b_codes.npz"))["default_codes"]
+    fx4k = np.load(os.path.join(G, "bench_1_7b_prefill4k_frames.npz"))["free_codes"]
+    limits = [32, 30, 8, 32, 31, 28, 32, 26]                # row 2 ends first: the staged 4k request enters there
+    utts = []
+    for i, L in enumerate(limits):
+        u = bench_utt(i); u.max_length = L
+        utts.append(u)
+    big = prefill4k_utt(); big.max_length = 24
+    utts.append(big)
+    tail = bench_utt(8); tail.max_length = 12                # staged behind the 4k request while that one runs
+    utts.append(tail)
+    b = q.Batcher(gm17, slots=8, frame_budget=32, prompt_budget=4105 + 8,
+                  options=q.SynthesisOptions(max_length=N_FRAMES, eos_token_id=None, seed=42))
+    res = b.run_all(utts, want_pcm=False, poll_frames=4)
+    b.close()
+    bad = 0
+    for u, (codes, _) in zip(utts, res):
+        if u.instruct_ids is not None:
+            want = fx4k[:24]
+            assert codes.shape == want.shape, codes.shape
+            if not (codes == want).all():
+                ok, rep = _adjudicate("1.7b", u, q.SynthesisOptions(max_length=24, eos_token_id=None, seed=42), codes, "1_7b_batcher_staged_4k")
+                assert ok, rep
+                bad += 1
+        else:
+            i = u.seed - 42; L = u.max_length
+            assert codes.shape == (L, 16), (i, codes.shape)
+            if not (codes == ref[i][:L]).all():
+                ok, rep = _adjudicate("1.7b", u, q.SynthesisOptions(max_length=L, eos_token_id=None, seed=42), codes, f"1_7b_batcher_staged_seq{i}")
+                assert ok, rep
+                bad += 1
+    assert bad <= 1, bad
+
+
 def test_wide_session_is_deterministic(gm17):
     """The wide-session kernels reduce through f32 atomics (two addends per element onto zeros: order-independent) and through
     slice sums added in slice order: two runs of one 64-row session must give the same codes bit for bit, graph or eager."""
