@@ -3,7 +3,7 @@
 //   * *.safetensors      → q3_model_set_tensor  (Qwen3TTS::from_pretrained / load_weights, src/lib.rs:180-262, 1390-1396)
 //   * PCM16 mono WAV     ← f32 samples          (save_wav / load_wav, src/audio/io.rs:106-165)
 //   * codes_*.bin / audio_*.bin dumps           (src/bin/generate_audio.rs:788-813)
-// Everything goes through the public C ABI of q3_engine.hip (q3_model_create / _set_tensor / _finalize): this
+// Everything goes through the public C ABI of q3_model.hip (q3_model_create / _set_tensor / _finalize): this
 // file never touches device memory itself.
 #include "../../include/q3tts.h"
 #include "q3_internal.h"

@@ -12,7 +12,7 @@ constexpr int MAX_SPLITS = 64;       // KV splits of the decode attention (16 un
 constexpr int PART_STRIDE = HEAD_DIM + 2;   // partial record: acc[128], m, l
 // Paged talker KV (replaces the reference's preallocated per-call cache, kv_cache.rs:234-310): a PAGE holds KV_PAGE_POS
 // consecutive positions of ONE sequence for every layer and KV head, K and V (29.4 MB at 28 layers x 8 KV heads; a
-// (layer, head) run is 64 KB). Pages are slots of layer-major slabs (KvPool, q3_engine.hip); a page is named by the
+// (layer, head) run is 64 KB). Pages are slots of layer-major slabs (KvPool, q3_engine.h); a page is named by the
 // address of its layer-0 K run. A sequence owns a row of KV_MAX_PAGES page pointers in device memory (64 x 128 = 8192
 // positions = the RoPE table); the K row of position p of (layer l, head h) lives at
 //   pages[p / 128] + l * layer_stride + h * 16384 + (p % 128) * 128 floats, its V row kv_vdelta floats further.
@@ -367,7 +367,7 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
 // the array's base pointer (a relaxed agent-scope __hip_atomic_load / store lowers to an sc1 access only up to 8 bytes).
 // What must NOT go through these: anything the scalar unit fetches (s_load is served by the scalar cache, which only the
 // acquire fence invalidates) — per-frame counters are written by the frame's last kernel and the first packet of every frame
-// keeps its acquire fence (q3_engine.hip: frame_fence_policy).
+// keeps its acquire fence (q3_session.hip: frame_fence_policy).
 typedef __attribute__((ext_vector_type(4))) float act_f4_t;
 typedef __attribute__((ext_vector_type(2))) float act_f2_t;
 constexpr int ACT_SC1 = 16;

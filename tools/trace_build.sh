@@ -6,7 +6,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"; SRC="$ROOT/qwen3_tts_rs_amd/csrc"; B="
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=14 -DQ3_TRACE -Wno-unused-function -Wno-unused-variable -Wno-unused-value"
 pids=()
-for f in q3_kernels_lm q3_kernels_gemv q3_kernels_wide q3_kernels_codec q3_kernels_prefill q3_engine q3_speaker q3_mimi; do
+for f in q3_kernels_lm q3_kernels_gemv q3_kernels_wide q3_kernels_codec q3_kernels_prefill q3_model q3_codec_run q3_session q3_batcher q3_testapi q3_speaker q3_mimi; do
   $HIPCC $FLAGS -c "$SRC/$f.hip" -o "$B/$f.o" & pids+=($!)
 done
 $HIPCC -O2 -std=c++17 -fPIC -c "$SRC/q3_io.cpp" -o "$B/q3_io.o" & pids+=($!)
