@@ -2,14 +2,15 @@
 //
 // A frame of generate_codes (lib.rs:580-652) is ~550 dependent kernel launches. hipGraphLaunch replays them as AQL dispatch
 // packets whose headers HIP chooses: barrier bit set, agent-scope acquire and release fences on every packet. The fences are
-// cache maintenance at every kernel boundary (L2 write-back of the producer XCD, L1 / non-local L2 invalidation for the
-// consumer) and cost ~0.25 us per dependent node on MI355X (tools/hw/aql_probe.hip, profiles/r4_aql_chain_probe.txt: 2.83 ->
-// 2.48 us per 2 MB stage). A boundary could do without them only if producer and consumer exchanged their activations
-// write-through (sc1 stores) and L1-bypassing (sc1 loads) — THE PRODUCT KERNELS DO NOT: they use plain loads and stores (the
-// sc1 conversion was built for one kernel family, measured slower than what the fence returns, and rejected: DESIGN 4.4a),
-// so packets WITHOUT fences give wrong codes. This path therefore exists to (1) price the boundary — with HIP's own header
-// policy it is bit-identical to and as fast as hipGraphLaunch, which shows that nothing in the frame time is runtime
-// overhead — and (2) carry the fence-free probes, which need an explicit unsafe opt-in (Q3_AQL_UNSAFE=1, q3_engine.hip).
+// cache maintenance at every kernel boundary (L2 write-back of the producer XCD, L1 / scalar-cache / non-local L2 invalidation for
+// the consumer) and cost ~0.3 us per dependent node on MI355X (tools/hw/aql_probe.hip, profiles/r4_aql_chain_probe.txt). A boundary
+// can do without them when producer and consumer exchange their activations write-through (sc1 stores, drained) and L1-bypassing
+// (sc1 loads): since round 6 the frame's GEMV and attention kernels do (q3_kernels.h "activation transport"), and this queue is the
+// PRODUCT path of the frame loop — the engine's per-node policy (q3_session.hip: frame_fence_policy) drops the fences between
+// those kernels and keeps them on every other node and on the first / last packet of a frame (state that crosses frames moves
+// with plain accesses). B = 8 frame 2.71 -> 2.57 ms, codes identical. With HIP's own header policy (Q3_AQL=1) the
+// path is bit-identical to and as fast as hipGraphLaunch — nothing in the frame time is runtime overhead —; packets without ANY
+// fence (Q3_AQL=2) are a probe that gives wrong codes and needs the explicit opt-in Q3_AQL_UNSAFE=1.
 // HIP offers no way to choose packet headers, so the engine converts its captured frame graph into a PACKET PROGRAM once
 // and submits the packets itself:
 //   * the kernels are the very same code objects: the .hip_fatbin section of this library is unbundled and loaded through the

@@ -158,7 +158,7 @@ static q3_status session_idle_row(q3_session* s, int b) {
     HIPC(hipMemcpy(s->limit + b, &q.limit, sizeof(int), hipMemcpyHostToDevice));
     // A frozen row still runs through every frame (its results are dropped): it reads its keys and rewrites the K/V of its
     // frozen position, prefill_len + ran. It keeps the ONE page that position lies in and every table entry it can reach points
-    // there (stale keys are as good as any for a row nobody reads); the other pages go back to the pool, and the row takes no
+    // there, zero-filled (below); the other pages go back to the pool, and the row takes no
     // more (kv_reserve_frames skips it) — a finished row must not sit on pages the queue is waiting for.
     if (s->paged && !q.idle && !s->kv_rows[(size_t)b].empty()) {
         std::vector<float*>& row = s->kv_rows[(size_t)b];
@@ -168,8 +168,17 @@ static q3_status session_idle_row(q3_session* s, int b) {
         for (size_t i = 0; i < row.size(); ++i) if (i != keep) back.push_back(row[i]);
         if (!back.empty()) (s->kv_in_bf16 ? s->m->kv_pool16 : s->m->kv_pool).give(back);
         row.assign(1, kept);
-        std::vector<unsigned long long> ent(keep + 1, (unsigned long long)kept);
+        // EVERY entry of the row's table names the kept page (none keeps the address of a page that went back to the pool), and the
+        // page is zero-filled: the frozen row goes on reading positions 0 .. pos through it, i.e. also slots this row never wrote
+        // (a previous owner's bits, possibly NaN / Inf, which would then run through the sampler and the embedding gather of a row
+        // nobody reads); zeros are finite keys. One strided memset per K and V: n_layers runs of nkv * KV_PAGE_POS * HEAD_DIM elements.
+        std::vector<unsigned long long> ent((size_t)KV_MAX_PAGES, (unsigned long long)kept);
         HIPC(hipMemcpy(s->kv_table + (size_t)b * KV_MAX_PAGES, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
+        const KvPool& pool = s->kv_in_bf16 ? s->m->kv_pool16 : s->m->kv_pool;
+        const size_t run_bytes = pool.run_floats * pool.elem_bytes, pitch = pool.layer_stride() * pool.elem_bytes;
+        HIPC(hipMemset2DAsync(kept, pitch, 0, run_bytes, (size_t)pool.n_layers, s->stream));
+        HIPC(hipMemset2DAsync((char*)kept + pool.v_delta() * pool.elem_bytes, pitch, 0, run_bytes, (size_t)pool.n_layers, s->stream));
+        HIPC(hipStreamSynchronize(s->stream));
     }
     q.idle = true;
     s->codes_host_valid = false;

@@ -195,9 +195,10 @@ struct q3_model {
     KvBudget kv_budget;    // one limit / occupancy for both pools below, in half-f32-page units
     KvPool kv_pool;
     KvPool kv_pool16;      // pages of bf16 sessions (q3_session_set_kv_dtype): the same geometry with 2-byte elements
-    // sessions hold pages, streams and weights of their model: q3_model_free with sessions still alive only marks the model,
-    // the last q3_session_free destroys it (a host that tears down in the wrong order must not crash)
-    std::atomic<int> live_sessions{0}; std::atomic<bool> zombie{false}; std::atomic<bool> claimed{false};     // claimed: someone is destroying it
+    // sessions hold pages, streams and weights of their model: the handle itself is ONE reference and every live session another;
+    // whoever drops the count to zero destroys the model (q3_model_free with sessions still alive only gives up the handle's
+    // reference — a host that tears down in the wrong order must not crash — and nobody touches *m after its own decrement)
+    std::atomic<int> refs{1};
     std::vector<Slot> slots;
     std::unordered_map<std::string, int> index;
     char* arena = nullptr; size_t arena_bytes = 0;

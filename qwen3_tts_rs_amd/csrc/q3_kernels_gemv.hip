@@ -400,6 +400,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_gemv_mfma(Q3_LIN_PRE, LinArgs a
 template <int EPI, int G, bool HALF, bool MB = false>       // MB: wide sessions, blockIdx.z = block of 16 activation rows
 __global__ __launch_bounds__(512) void k_gemv_sk2(Q3_LIN_PRE, LinArgs a_in) {
     Q3_LIN_APPLY(a, a_in);
+    a.W2 = nullptr; a.norm_w = nullptr; a.epi = EPI;      // this family's launcher sends the residual / bias / residual pitch in those preloaded slots (below): never read them as what they are named
     constexpr int NWAVES = 8;
     __shared__ __attribute__((aligned(16))) float red[NWAVES][256];
     Q3T_DECL Q3T(0); Q3T_K(7, a.Kpad);
@@ -986,11 +987,19 @@ __global__ __launch_bounds__(512) void k_gemv_mfma4(Q3_LIN_PRE, LinArgs a_in) {
     const float* __restrict__ nwp = RMS ? a.norm_w : nullptr;
 
     float pre_b = 0.0f, pre_r = 0.0f;     // epilogue operands requested up front (see k_gemv_mfma)
+    // (round 6) the +residual instances (o / down projections at M <= 2: 206 nodes of a single-utterance frame) have no second
+    // matrix and no fused norm, so their launcher sends the RESIDUAL pointer in the W2 slot, the BIAS pointer in the norm-weight slot
+    // and the residual's row pitch in the epi slot of the 14 preloaded dwords — as k_gemv_sk2 does: these two requests, and wave 0's
+    // first x request behind them, then do not wait for the argument struct's scalar load
+    const float* __restrict__ bp = EPI == EPI_RESID ? pnw : a.bias;
+    const float* __restrict__ rp = EPI == EPI_RESID ? reinterpret_cast<const float*>(pW2) : a.resid;
+    const int ldr_pre = EPI == EPI_RESID ? pepi : a.ldr;
+    if constexpr (EPI == EPI_RESID) { a.W2 = nullptr; a.norm_w = nullptr; a.epi = EPI; }      // never read the repurposed slots as what they are named
     if (tid < 16 * MG) {
         const int m = tid >> 2, n = blockIdx.x * 4 + (tid & 3);
-        if (m < a.M && n < a.N) {
-            if (a.bias) pre_b = a.bias[n];
-            if constexpr (EPI == EPI_RESID) pre_r = act_ld1(act_rsrc(a.resid), (m * a.ldr + n) * 4);
+        if (m < pM && n < pN) {
+            if (bp) pre_b = bp[n];
+            if constexpr (EPI == EPI_RESID) pre_r = act_ld1(act_rsrc(rp), (m * ldr_pre + n) * 4);
         }
     }
     f32x4_t acc[NW][MG];
@@ -1164,6 +1173,18 @@ static hipError_t launch_gemv4_t(const LinArgs& a, hipStream_t st) {
     // groups of 3 k-steps when a wave's slice is a multiple of 3 (K = 3072: 24 steps over 8 waves), so that no
     // group is ragged (a ragged group still pays its split + MFMAs on a zero operand)
     const bool g3 = (S % nwv == 0) && ((S / nwv) % 3 == 0) && !RMS && EPI != EPI_SWIGLU;
+    if constexpr (EPI == EPI_RESID && !RMS) {      // preloaded slots of the +residual instances: W2 = residual, norm weight = bias, epi = residual row pitch (see the kernel)
+#define Q3_G4R_PASS a.W, reinterpret_cast<const uint16_t*>(a.resid), a.x, a.bias, a.M, a.N, a.K, a.Kpad, a.ldx, a.ldr, a
+        if (mg <= 1) {
+            if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1, 3>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_G4R_PASS);
+            else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_G4R_PASS);
+        } else if (mg == 2) {
+            if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2, 3>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_G4R_PASS);
+            else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 2>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_G4R_PASS);
+        } else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 4>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_G4R_PASS);
+#undef Q3_G4R_PASS
+        return hipGetLastError();
+    }
     if (mg <= 1) {
         if (g3) hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1, 3>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_LIN_PASS(a));
         else hipLaunchKernelGGL((k_gemv_mfma4<EPI, RMS, 1>), dim3(tiles), dim3(nwv * 64), 0, st, Q3_LIN_PASS(a));

@@ -299,13 +299,7 @@ extern "C" q3_status q3_model_create(const q3_config* cfg, int device, q3_model*
 void model_destroy(q3_model* m);
 extern "C" void q3_model_free(q3_model* m) {
     if (!m) return;
-    // zombie first, THEN look at the count: a session freed between a check and a later store would find zombie unset, leave,
-    // and nobody would destroy the model. With this order either the last session sees zombie (its fetch_sub comes after the
-    // store) and destroys the model, or this thread sees the count at zero — `claimed` makes sure only one of them does.
-    m->zombie.store(true);
-    if (m->live_sessions.load() > 0) return;
-    if (m->claimed.exchange(true)) return;
-    model_destroy(m);
+    if (m->refs.fetch_sub(1) == 1) model_destroy(m);       // the handle's reference; the last session's ~q3_session drops the last one otherwise
 }
 void model_destroy(q3_model* m) {
     if (m->device < 0) { delete m; return; }

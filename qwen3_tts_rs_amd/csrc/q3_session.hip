@@ -483,7 +483,7 @@ q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int fra
     const q3_config& c = m->cfg;
     std::unique_ptr<q3_session> s(new q3_session());
     s->m = m; s->B = batch; s->opts = reqs[0].opts;
-    m->live_sessions.fetch_add(1);
+    m->refs.fetch_add(1);
     if (s->opts.max_length < 1) return set_err(Q3_INVALID_ARG, "max_length must be >= 1");
     s->seq.resize(batch);
     int rows = 0;
@@ -691,7 +691,7 @@ q3_session::~q3_session() {
     }
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
     pool.release_all();                                          // the model's device must still be current for these
-    if (m->live_sessions.fetch_sub(1) == 1 && m->zombie.load() && !m->claimed.exchange(true)) model_destroy(m);
+    if (m->refs.fetch_sub(1) == 1) model_destroy(m);          // the model handle was given up before its last session
 }
 
 extern "C" void q3_session_free(q3_session* s) { delete s; }
