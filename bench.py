@@ -247,6 +247,55 @@ def main():
              "generation_ms": float(np.mean([t.generation_ms for t in timings])),
              "decode_ms": float(np.mean([t.decode_ms for t in timings]))}
 
+    # (measured right behind the timed steps, ahead of the roofline replays and the 64-row / side-configuration legs: the same
+    #  leg at the end of the run read 2-3 % lower — a chip that has been streaming for minutes, a page pool scattered by 64-row sessions)
+    # ---- utterances that END AT DIFFERENT FRAMES (what EOS does to a real batch): 4 x B requests with lengths drawn from
+    # 100 .. frames go through B rows, (a) continuously — the native batcher (q3_batcher_*) refills a row that ends at the next
+    # 8-frame step (q3_session_replace) — and (b) as lockstep sessions of B, each running until its longest row is done. Useful frames / wall of the generation
+    # loop (prefills of the swapped-in requests included; no vocoder on either side). ----
+    eos_mix = None
+    if world == 1 and not args.no_other_configs and not args.headline_only and args.workload == "customvoice":
+        try:
+            rng = np.random.default_rng(2026)
+            n_req = 4 * B
+            lens = [int(x) for x in rng.integers(min(100, args.frames), args.frames + 1, size=n_req)]
+            mix = []
+            for i, L in enumerate(lens):
+                u = make_utt(i); u.max_length = L
+                mix.append(u)
+            def batcher_run(reqs, poll, want_pcm=False):            # the native serving loop (q3_batcher): queue -> rows, refilled every `poll` frames
+                bt = q.Batcher(model, slots=B, frame_budget=args.frames, prompt_budget=0, options=opts)
+                try:
+                    ta = time.perf_counter()
+                    tickets = [bt.submit(u, want_pcm=want_pcm) for u in reqs]
+                    steady = None                    # (frames, seconds) at the moment the queue ran dry: every row busy until then
+                    while True:
+                        running, queued, _ = bt.step(poll, use_graph)
+                        if queued == 0 and steady is None:
+                            steady = (sum(bt.poll(t)[1] for t in tickets), time.perf_counter() - ta)
+                        if running == 0 and queued == 0:
+                            break
+                    wall = time.perf_counter() - ta
+                    return sum(int(bt.fetch(t)[0].shape[0]) for t in tickets), wall, steady
+                finally:
+                    bt.close()
+            batcher_run(mix[:B + 2], 8)              # warm (graph, side-session shapes)
+            fr_c, wall_c, steady = batcher_run(mix, 8)
+            fr_p, wall_p, steady_p = batcher_run(mix, 8, want_pcm=True)      # every finished row vocoded before its row is refilled
+            wall_l = 0.0; fr_l = 0
+            for k in range(0, n_req, B):
+                sl = model.session(mix[k:k + B], opts)
+                ta = time.perf_counter(); sl.prefill(); sl.generate(args.frames, use_graph=use_graph); wall_l += time.perf_counter() - ta
+                fr_l += sum(sl.frames(b)[0] for b in range(len(mix[k:k + B]))); sl.close()
+            eos_mix = {"requests": n_req, "rows": B, "lengths": f"uniform {min(100, args.frames)}..{args.frames} frames (seed 2026), mean {float(np.mean(lens)):.0f}",
+                       "continuous_frames_per_s": fr_c / wall_c, "continuous_steady_frames_per_s": steady[0] / steady[1],
+                       "continuous_with_vocoder_frames_per_s": fr_p / wall_p, "continuous_with_vocoder_steady_frames_per_s": steady_p[0] / steady_p[1],
+                       "lockstep_frames_per_s": fr_l / wall_l, "frames": fr_c,
+                       "what": "generation loop only (q3_batcher with 8-frame steps; session opening and the prefill of swapped-in requests included, no vocoder except in the `with_vocoder` figures, where every finished row is decoded to PCM before it is refilled; `steady` = until the queue ran dry, i.e. without the drain of the last rows); lockstep = sessions of `rows` requests "
+                               "each running until its longest row ends"}
+        except Exception as e:
+            eos_mix = {"error": str(e)}
+
     # ---- roofline of the dominant kernel: the bf16-weight MFMA GEMV family (every projection of the frame) ----
     # The launch inventory is the ENGINE's: a profiled session runs a few frames and reports every distinct GEMV launch
     # (M, N, K, epilogue, fused input norm, tiling) with its count per frame. Each shape is then replayed
@@ -415,53 +464,6 @@ def main():
                 finally:
                     m06.close()
             guarded("0.6b_customvoice_b1", small)
-
-    # ---- utterances that END AT DIFFERENT FRAMES (what EOS does to a real batch): 4 x B requests with lengths drawn from
-    # 100 .. frames go through B rows, (a) continuously — the native batcher (q3_batcher_*) refills a row that ends at the next
-    # 8-frame step (q3_session_replace) — and (b) as lockstep sessions of B, each running until its longest row is done. Useful frames / wall of the generation
-    # loop (prefills of the swapped-in requests included; no vocoder on either side). ----
-    eos_mix = None
-    if world == 1 and not args.no_other_configs and not args.headline_only and args.workload == "customvoice":
-        try:
-            rng = np.random.default_rng(2026)
-            n_req = 4 * B
-            lens = [int(x) for x in rng.integers(min(100, args.frames), args.frames + 1, size=n_req)]
-            mix = []
-            for i, L in enumerate(lens):
-                u = make_utt(i); u.max_length = L
-                mix.append(u)
-            def batcher_run(reqs, poll, want_pcm=False):            # the native serving loop (q3_batcher): queue -> rows, refilled every `poll` frames
-                bt = q.Batcher(model, slots=B, frame_budget=args.frames, prompt_budget=0, options=opts)
-                try:
-                    ta = time.perf_counter()
-                    tickets = [bt.submit(u, want_pcm=want_pcm) for u in reqs]
-                    steady = None                    # (frames, seconds) at the moment the queue ran dry: every row busy until then
-                    while True:
-                        running, queued, _ = bt.step(poll, use_graph)
-                        if queued == 0 and steady is None:
-                            steady = (sum(bt.poll(t)[1] for t in tickets), time.perf_counter() - ta)
-                        if running == 0 and queued == 0:
-                            break
-                    wall = time.perf_counter() - ta
-                    return sum(int(bt.fetch(t)[0].shape[0]) for t in tickets), wall, steady
-                finally:
-                    bt.close()
-            batcher_run(mix[:B + 2], 8)              # warm (graph, side-session shapes)
-            fr_c, wall_c, steady = batcher_run(mix, 8)
-            fr_p, wall_p, steady_p = batcher_run(mix, 8, want_pcm=True)      # every finished row vocoded before its row is refilled
-            wall_l = 0.0; fr_l = 0
-            for k in range(0, n_req, B):
-                sl = model.session(mix[k:k + B], opts)
-                ta = time.perf_counter(); sl.prefill(); sl.generate(args.frames, use_graph=use_graph); wall_l += time.perf_counter() - ta
-                fr_l += sum(sl.frames(b)[0] for b in range(len(mix[k:k + B]))); sl.close()
-            eos_mix = {"requests": n_req, "rows": B, "lengths": f"uniform {min(100, args.frames)}..{args.frames} frames (seed 2026), mean {float(np.mean(lens)):.0f}",
-                       "continuous_frames_per_s": fr_c / wall_c, "continuous_steady_frames_per_s": steady[0] / steady[1],
-                       "continuous_with_vocoder_frames_per_s": fr_p / wall_p, "continuous_with_vocoder_steady_frames_per_s": steady_p[0] / steady_p[1],
-                       "lockstep_frames_per_s": fr_l / wall_l, "frames": fr_c,
-                       "what": "generation loop only (q3_batcher with 8-frame steps; session opening and the prefill of swapped-in requests included, no vocoder except in the `with_vocoder` figures, where every finished row is decoded to PCM before it is refilled; `steady` = until the queue ran dry, i.e. without the drain of the last rows); lockstep = sessions of `rows` requests "
-                               "each running until its longest row ends"}
-        except Exception as e:
-            eos_mix = {"error": str(e)}
 
     # ---- CPU baseline: the oracle (port of the candle-CPU F32 path) on this host, bounded sample ----
     cpu = None
