@@ -360,6 +360,11 @@ q3_status q3_session_stream(q3_session* s, void** stream);
  * *nodes = dispatch packets per frame (0 on paths 0 / 1). A graph the converter cannot take stays on path 1.
  * The reference replays nothing — every op is an eager candle launch (src/lib.rs:580-652); new here (environment: Q3_AQL). */
 q3_status q3_session_submit_info(q3_session* s, int* path, int* nodes);
+/* How many of the frame's dispatch packets go out WITHOUT their agent-scope acquire / release fence (paths 3 / 4 of
+ * q3_session_submit_info; 0 / 0 on the other paths and before the frame is captured). On path 4 these are the packets of the kernel
+ * families that move their data write-through; the first packet of a frame always acquires and the last always releases.
+ * New here (the parity tests hold the policy to it). */
+q3_status q3_session_submit_fences(q3_session* s, int* acquire_free, int* release_free);
 /* Algorithmic HBM bytes of one frame for this session's batch at KV length L */
 q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes);
 

@@ -117,6 +117,7 @@ SYMBOLS = {
     "q3_session_stream": (c_int, [c_void_p, P(c_void_p)]),
     "q3_session_frame_bytes": (c_int, [c_void_p, c_int, P(ctypes.c_double), P(ctypes.c_double)]),
     "q3_session_submit_info": (c_int, [c_void_p, P(c_int), P(c_int)]),
+    "q3_session_submit_fences": (c_int, [c_void_p, P(c_int), P(c_int)]),
     "q3_session_set_stream_mode": (c_int, [c_void_p, c_int]),
     "q3_model_config": (c_int, [c_void_p, P(CConfig)]),
     "q3_config_default": (c_int, [c_int, P(CConfig)]),

@@ -348,11 +348,18 @@ class Session:
         return [tuple(buf[i * 8:(i + 1) * 8]) for i in range(n.value)]
 
     def submit_info(self) -> Tuple[int, int]:
-        """(path, packets per frame): 0 nothing captured / eager, 1 hipGraphLaunch, 2 own AQL queue with HIP's fences, 3 own AQL
-        queue without boundary fences (include/q3tts.h: q3_session_submit_info; environment Q3_AQL)."""
+        """(path, packets per frame): 0 nothing captured / eager, 1 hipGraphLaunch, 2 own AQL queue with HIP's fences, 4 own AQL
+        queue with fence-free boundaries between the write-through kernels (the default), 3 own queue without any fence (probe)
+        (include/q3tts.h: q3_session_submit_info; environment Q3_AQL)."""
         p = ctypes.c_int(); n = ctypes.c_int()
         check(lib.q3_session_submit_info(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def submit_fences(self) -> Tuple[int, int]:
+        """(packets per frame without their acquire fence, without their release fence): q3_session_submit_fences"""
+        a = ctypes.c_int(); r = ctypes.c_int()
+        check(lib.q3_session_submit_fences(self._h, ctypes.byref(a), ctypes.byref(r)))
+        return a.value, r.value
 
     def frame_bytes(self, kv_len: int) -> Tuple[float, float]:
         w = ctypes.c_double(); k = ctypes.c_double()

@@ -222,6 +222,12 @@ extern "C" q3_status q3_session_submit_info(q3_session* s, int* path, int* nodes
     return Q3_OK;
 }
 
+extern "C" q3_status q3_session_submit_fences(q3_session* s, int* acquire_free, int* release_free) {
+    if (!s) return set_err(Q3_INVALID_ARG, "null session");
+    q3::aql_program_fence_free(s->aql, acquire_free, release_free);
+    return Q3_OK;
+}
+
 extern "C" q3_status q3_session_frame_bytes(q3_session* s, int kv_len, double* weight_bytes, double* kv_bytes) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     const q3_config& c = s->m->cfg;
