@@ -207,8 +207,9 @@ void      q3_session_free(q3_session* s);
  * (lib.rs:558-571). */
 q3_status q3_session_prefill(q3_session* s);
 /* generate_codes frame loop (lib.rs:580-652): run up to n_frames more frames for every live
- * sequence; returns when they are done on the device. use_graph != 0 replays a captured
- * hipGraph per frame. */
+ * sequence; returns when they are done on the device. use_graph != 0: the frame is captured once
+ * (hipGraph) and replayed per frame — as packets on the library's own AQL queue (the default;
+ * q3_session_submit_info) or through hipGraphLaunch; 0: eager launches. Same kernels, same bits. */
 q3_status q3_session_generate(q3_session* s, int n_frames, int use_graph);
 /* frames emitted so far for sequence b (stops at the frame whose semantic token is EOS,
  * lib.rs:581-585) and whether it hit EOS / max_length */

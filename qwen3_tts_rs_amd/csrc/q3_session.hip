@@ -1378,10 +1378,12 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
         Q3C(refresh_codes(s));
         const auto t2 = clk::now();
         int total = 0;
-        // Four utterances are vocoded at a time, each on its own stream and workspace: most of a decode saturates the
-        // chip, but its front (the pre-transformer's ~90 launches on 10-160 workgroups, ≈4 of 28 ms) is latency-bound
-        // and fills in beside the other utterance's convolutions. Q3_DECODE_PAIRS=n: n at a time (1 = serial; A/B aid).
-        static const int conc = [] { const char* e = getenv("Q3_DECODE_PAIRS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+        // Two utterances are vocoded at a time, each on its own stream and workspace: most of a decode saturates the
+        // chip, but its front (the pre-transformer's ~90 launches on 10-160 workgroups) is latency-bound and fills in beside
+        // the other utterance's convolutions. Q3_DECODE_PAIRS=n: n at a time (1 = serial; A/B aid). Re-measured in round 6
+        // (profiles/r6_decode_knobs_ab.txt): 8 x 640 frames 155.3 / 157.7 / 162.1 ms at 2 / 4 / 8 at a time, 64 x 640 frames
+        // 1261 / 1274 ms at 2 / 4 — four was the round-1 optimum, when the front was 4 of 28 ms; it is 2 of 19.8 now.
+        static const int conc = [] { const char* e = getenv("Q3_DECODE_PAIRS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
         bool any_icl = false;
         for (auto& q : s->seq) any_icl = any_icl || !q.ref_codes.empty();
         if (conc > 1 && s->B > 1 && !any_icl) {

@@ -6,6 +6,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+if os.environ.get("EOS_MIX_TORCH") == "1":
+    import torch      # bench.py loads torch first: its bundled HIP runtime then serves libq3tts.so too (tests/conftest.py)
+    torch.cuda.set_device(0)
 import qwen3_tts_rs_amd as q
 from qwen3_tts_rs_amd import synth
 from qwen3_tts_rs_amd.synth import synthetic_prompt
