@@ -155,7 +155,7 @@ def main():
     opts = q.SynthesisOptions(max_length=args.frames, eos_token_id=None, seed=42, **samp)
     use_graph = not args.no_graph
 
-    submit_path = [0, 0]    # (path, packets per frame) of the timed sessions: include/q3tts.h q3_session_submit_info
+    submit_path = [0, 0, 0, 0]    # (path, packets per frame, packets without acquire / release fence) of the timed sessions: q3_session_submit_info / _fences
     phase_ms = []       # (create, run, close) wall per step: the timed step is all three
     # the samples of every utterance land in host memory inside the timed step, as `synthesize` returns them
     # (lib.rs:718-784): one pinned buffer per row, reused step after step (allocated once, outside the timing, like a
@@ -177,7 +177,7 @@ def main():
         finally:
             tc = time.perf_counter()
             try:
-                submit_path[:] = list(s.submit_info())
+                submit_path[:] = list(s.submit_info()) + list(s.submit_fences())
             except Exception:
                 pass
             s.close()
@@ -526,7 +526,7 @@ def main():
                    "frame_submit": {0: "eager launches", 1: "hipGraphLaunch", 2: "own AQL queue, HIP's fences on every packet",
                                     3: "own AQL queue, no fences (probe: invalid)",
                                     4: "captured frame replayed on the library's own AQL queue; boundaries between write-through kernels without agent-scope fences"}.get(submit_path[0], str(submit_path[0])),
-                   "frame_packets": submit_path[1], "prefill": args.workload, "sampling": args.sampling,
+                   "frame_packets": submit_path[1], "frame_packets_without_acquire_release_fence": submit_path[2:4], "prefill": args.workload, "sampling": args.sampling,
                    "pcm_copy_out": True},      # every utterance's samples are copied to (pinned) host memory inside the timed step
         "rtf": rtf_job, "rtf_per_utterance": rtf_utt, "stage_ms": stage, "step_wall_ms": step_wall, "step_phase_ms_create_run_close": phase_ms[-args.steps:], "latency": lat,
         "weights_load_s": load_s, "weight_broadcast": {"bytes": bcast_bytes, "seconds": bcast_s,

@@ -303,7 +303,7 @@ Runtime* runtime_for(int device, std::string* why) {
 struct AqlProgram {
     Runtime* rt = nullptr;
     std::vector<hsa_kernel_dispatch_packet_t> pk;        // templates (header / setup filled, completion signal empty)
-    void* kernargs = nullptr;                            // device memory, one block per node
+    void* kernargs = nullptr; bool host_kernargs = false;     // one block per node: device memory (pinned host memory with Q3_AQL_HOST_KERNARG=1)
     hsa_signal_t done{}; bool pending = false;
     int n_acq_free = 0, n_rel_free = 0;                  // nodes submitted without their acquire / release fence (node_policy)
     bool dead = false;      // a submission timed out: the ring may hold a partial burst without a completion signal — never submit or wait again
@@ -319,7 +319,7 @@ void aql_program_destroy(AqlProgram* p) {
     if (!p) return;
     std::string w;
     if (p->pending && !p->dead) aql_wait(p, &w);         // (a dead program's signal may never fire: do not block on it)
-    if (p->kernargs && !p->dead) (void)hipFree(p->kernargs);      // dead: packets still in the ring may point at the blocks — leak them
+    if (p->kernargs && !p->dead) (void)(p->host_kernargs ? hipHostFree(p->kernargs) : hipFree(p->kernargs));      // dead: packets still in the ring may point at the blocks — leak them
     if (p->dead) p->kernargs = nullptr;
     if (p->done.handle && !p->dead) hsa.hsa_signal_destroy(p->done);     // dead: the burst's last packet may still name it — leaked with the blocks
     delete p;
@@ -408,8 +408,17 @@ AqlProgram* aql_program_create(hipGraph_t graph, int device, const AqlPolicy& po
         set(p->pk.front().header, HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
         set(p->pk.back().header, HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     }
-    if (hipMalloc(&p->kernargs, host_args.size()) != hipSuccess) { *why = "hipMalloc(kernargs) failed"; return nullptr; }
-    if (hipMemcpy(p->kernargs, host_args.data(), host_args.size(), hipMemcpyHostToDevice) != hipSuccess) { *why = "hipMemcpy(kernargs) failed"; aql_program_destroy(p.release()); return nullptr; }
+    // Kernel-argument blocks live in DEVICE memory: the dispatcher reads a node's first 14 dwords into SGPRs before its first
+    // wave starts, and that fetch sits in every node boundary — with the blocks in pinned host memory (Q3_AQL_HOST_KERNARG=1: an
+    // A/B aid) the B = 8 frame is 14 % slower (2.567 -> 2.922 ms, profiles/r6_kernarg_placement_ab.txt).
+    p->host_kernargs = getenv("Q3_AQL_HOST_KERNARG") && atoi(getenv("Q3_AQL_HOST_KERNARG")) == 1;
+    if (p->host_kernargs) {
+        if (hipHostMalloc(&p->kernargs, host_args.size(), hipHostMallocDefault) != hipSuccess) { *why = "hipHostMalloc(kernargs) failed"; return nullptr; }
+        memcpy(p->kernargs, host_args.data(), host_args.size());
+    } else {
+        if (hipMalloc(&p->kernargs, host_args.size()) != hipSuccess) { *why = "hipMalloc(kernargs) failed"; return nullptr; }
+        if (hipMemcpy(p->kernargs, host_args.data(), host_args.size(), hipMemcpyHostToDevice) != hipSuccess) { *why = "hipMemcpy(kernargs) failed"; aql_program_destroy(p.release()); return nullptr; }
+    }
     for (size_t i = 0; i < p->pk.size(); ++i) p->pk[i].kernarg_address = (char*)p->kernargs + arg_off[i];
     if ((size_t)p->pk.size() * 2 > rt->queue->size) { *why = "frame longer than half the packet ring"; aql_program_destroy(p.release()); return nullptr; }
     const hsa_status_t st = hsa.hsa_signal_create(0, 0, nullptr, &p->done);

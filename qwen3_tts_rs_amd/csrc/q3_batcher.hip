@@ -355,6 +355,7 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
         rq.opts.max_length = b->s->max_frames;       // the side session draws the row's PCG stream with the host session's stride
         b->stage.id = id; b->stage.st = Q3_OK; b->stage.err.clear(); b->stage.side = nullptr; b->stage.limit = 0;
         q3_batcher* bp = b;
+        try {
         b->stage.thr = std::thread([bp, rq, limit_req]() {
             q3_batcher::Stage& g = bp->stage;
             q3_session* side = nullptr;
@@ -365,6 +366,7 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
             g.side = side; g.st = st;
             if (st != Q3_OK) g.err = q3_last_error();
         });
+        } catch (...) { b->stage.id = -1; }          // no thread to be had: the swap prefills synchronously, as before
     };
     // Run in pieces that end where the next row reaches its frame limit: that row is collected and refilled at once instead of
     // idling to the end of the step (a row that ends on EOS is noticed at q3_session_generate's 32-frame check or at the

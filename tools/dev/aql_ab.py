@@ -27,7 +27,7 @@ for spec in a.modes.split(","):
     envs = spec.split("/")[1:]
     parts = spec.split("/")[0].split(":"); mode = int(parts[0])
     os.environ["Q3_AQL"] = str(mode)
-    for k in ("Q3_AQL_ACQ", "Q3_AQL_REL", "Q3_AQL_T_ACQ", "Q3_AQL_T_REL", "Q3_AQL_T_ONLY"): os.environ.pop(k, None)
+    for k in ("Q3_AQL_ACQ", "Q3_AQL_REL", "Q3_AQL_T_ACQ", "Q3_AQL_T_REL", "Q3_AQL_T_ONLY", "Q3_AQL_HOST_KERNARG", "Q3_KARG_PREFETCH"): os.environ.pop(k, None)
     for e in envs:
         k, v = e.split("=", 1); os.environ[k] = v
     if len(parts) == 3:
