@@ -307,6 +307,7 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
                 if (!admit(t.req.r, &units, &wait)) {
                     if (wait) return Q3_OK;          // FIFO: the head of the queue waits for running rows to end
                     b->queue.erase(b->queue.begin());
+                    if (b->stage.id == id) stage_drop(b);      // (a limit set after it was prefilled ahead) its side session goes with it
                     int S = 0, lim = 0; request_shape(t.req.r, &S, &lim);
                     bat_fail(t, set_err(Q3_KV_OVERFLOW, "KV page pool exhausted: the request's %d prompt positions + %d frames need %ld page(s) (f32 equivalents), more than the pool's limit leaves",
                                         S, lim, (units + 1) / 2));
