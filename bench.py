@@ -247,8 +247,8 @@ def main():
              "generation_ms": float(np.mean([t.generation_ms for t in timings])),
              "decode_ms": float(np.mean([t.decode_ms for t in timings]))}
 
-    # (this leg reads 2-3 % lower inside bench.py — 2496-2508 frames/s wherever it sits in the run — than from tools/dev/eos_mix_ab.py,
-    #  a process without torch, on the same box: 2558-2587; the frames cost the same in both, profiles/r6_eos_mix_staged_ab.txt)
+    # (measured right behind the timed steps; round 6 saw 2496-2578 frames/s from this leg box to box, 2558-2587 from the same loop
+    #  alone in a process, tools/dev/eos_mix_ab.py — profiles/r6_eos_mix_staged_ab.txt)
     # ---- utterances that END AT DIFFERENT FRAMES (what EOS does to a real batch): 4 x B requests with lengths drawn from
     # 100 .. frames go through B rows, (a) continuously — the native batcher (q3_batcher_*) refills a row that ends at the next
     # 8-frame step (q3_session_replace) — and (b) as lockstep sessions of B, each running until its longest row is done. Useful frames / wall of the generation
