@@ -433,16 +433,41 @@ bool aql_submit(AqlProgram* p, int frames, std::string* why, int* submitted) {
     if (p->dead) { *why = "aql_submit: this program's queue stopped draining earlier"; return false; }
     if (p->pending && !aql_wait(p, why)) return false;
     Runtime* rt = p->rt;
-    std::lock_guard<std::mutex> lk(rt->mu);
     hsa_queue_t* q = rt->queue;
     const uint32_t mask = q->size - 1; const size_t n = p->pk.size();
     auto* ring = (hsa_kernel_dispatch_packet_t*)q->base_address;
     hsa.hsa_signal_store_relaxed(p->done, 1);
     p->pending = true;
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();                 // of the last sign of life of the ring (the read index moved)
+    uint64_t last_rd = hsa.hsa_queue_load_read_index_scacquire(q);
     for (int f = 0; f < frames; ++f) {
-        // room for one frame (the ring holds at least two)
-        while (rt->write_idx + n - hsa.hsa_queue_load_read_index_scacquire(q) > q->size) {
+        // The queue is shared by every session of the process on this device: the lock is taken PER FRAME, so bursts of sessions
+        // driven from different host threads interleave at frame boundaries (a 640-frame burst used to hold it for its whole
+        // 1.6 s), and it is never held while waiting for ring space. A frame's packets are contiguous in the ring and its first /
+        // last packet keep their fences, so another session's frame in between changes nothing for this one.
+        for (;;) {
+            std::unique_lock<std::mutex> lk(rt->mu);
+            if (rt->write_idx + n - hsa.hsa_queue_load_read_index_scacquire(q) <= q->size) {      // room for one frame (the ring holds at least two)
+                for (size_t i = 0; i < n; ++i) {
+                    hsa_kernel_dispatch_packet_t pk = p->pk[i];
+                    const bool first = f == 0 && i == 0, last = f == frames - 1 && i == n - 1;
+                    uint16_t hdr = pk.header;
+                    if (first) hdr = (uint16_t)((hdr & ~(3u << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE)) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE));
+                    if (last) { hdr = (uint16_t)((hdr & ~(3u << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)); pk.completion_signal = p->done; }
+                    hsa_kernel_dispatch_packet_t* dst = ring + ((rt->write_idx + i) & mask);
+                    memcpy((char*)dst + 4, (char*)&pk + 4, sizeof pk - 4);
+                    __atomic_store_n(&dst->full_header, (uint32_t)hdr | ((uint32_t)pk.setup << 16), __ATOMIC_RELEASE);
+                }
+                rt->write_idx += n;
+                hsa.hsa_queue_store_write_index_relaxed(q, rt->write_idx);
+                hsa.hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(rt->write_idx - 1));
+                break;
+            }
+            lk.unlock();
+            {   // a long burst waits here most of its time (the ring holds ~119 frames): only a ring that has not moved for 120 s is dead
+                const uint64_t rd = hsa.hsa_queue_load_read_index_scacquire(q);
+                if (rd != last_rd) { last_rd = rd; t0 = std::chrono::steady_clock::now(); }
+            }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
                 // f whole frames are in the ring and none of them carries the completion signal (only the burst's last packet
                 // would have): the program is dead — nothing waits on its signal any more, the caller accounts for the f frames
@@ -454,19 +479,6 @@ bool aql_submit(AqlProgram* p, int frames, std::string* why, int* submitted) {
             }
             std::this_thread::yield();
         }
-        for (size_t i = 0; i < n; ++i) {
-            hsa_kernel_dispatch_packet_t pk = p->pk[i];
-            const bool first = f == 0 && i == 0, last = f == frames - 1 && i == n - 1;
-            uint16_t hdr = pk.header;
-            if (first) hdr = (uint16_t)((hdr & ~(3u << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE)) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE));
-            if (last) { hdr = (uint16_t)((hdr & ~(3u << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)); pk.completion_signal = p->done; }
-            hsa_kernel_dispatch_packet_t* dst = ring + ((rt->write_idx + i) & mask);
-            memcpy((char*)dst + 4, (char*)&pk + 4, sizeof pk - 4);
-            __atomic_store_n(&dst->full_header, (uint32_t)hdr | ((uint32_t)pk.setup << 16), __ATOMIC_RELEASE);
-        }
-        rt->write_idx += n;
-        hsa.hsa_queue_store_write_index_relaxed(q, rt->write_idx);
-        hsa.hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(rt->write_idx - 1));
     }
     if (submitted) *submitted = frames;
     return true;

@@ -113,3 +113,29 @@ def test_model_outlives_its_handle_while_sessions_run():
     got = s.codes(0).copy()
     s.close()                                    # ... the session's last: destroys the model
     np.testing.assert_array_equal(got, want)
+
+
+def test_two_sessions_on_two_threads_share_the_queue(tiny_gm):
+    """One user-mode queue per process and device carries every session's frames; bursts of sessions driven from different host
+    threads interleave at frame boundaries (the lock is per frame). Each session must still produce its own codes."""
+    import threading
+    utts = [[q.Utterance(synthetic_prompt(12, 10 * k + i), seed=100 * k + i) for i in range(3)] for k in range(2)]
+    want = [_codes(tiny_gm, u, 40, False)[0] for u in utts]
+    got = [None, None]; err = []
+
+    def run(k):
+        try:
+            s = tiny_gm.session(utts[k], q.SynthesisOptions(max_length=40, seed=42, eos_token_id=None))
+            s.prefill()
+            for _ in range(8):
+                s.generate(5, use_graph=True)
+            got[k] = np.stack([s.codes(b) for b in range(3)]); assert s.submit_info()[0] == 4
+            s.close()
+        except Exception as e:      # pragma: no cover
+            err.append(e)
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not err, err
+    for k in range(2):
+        np.testing.assert_array_equal(got[k], want[k])
