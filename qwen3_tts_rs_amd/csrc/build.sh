@@ -31,15 +31,15 @@ compile() {
 }
 API="$HERE/../../include/q3tts.h"
 for f in q3_kernels_lm q3_kernels_gemv q3_kernels_wide q3_kernels_codec q3_kernels_prefill q3_speaker q3_mimi; do
-  compile "$HERE/$f.hip" "$BUILD/$f.o" "$DEV_FLAGS" "$HERE/q3_kernels.h" "$HERE/q3_internal.h" "$API"
+  compile "$HERE/$f.hip" "$BUILD/$f.o" "$DEV_FLAGS" "$HERE/q3_kernels.h" "$HERE/q3_internal.h" "$HERE/q3_capture_lock.h" "$API"
 done
 # the engine (host side of the hot path): five units behind q3_engine.h
 for f in q3_model q3_codec_run q3_session q3_batcher q3_testapi; do
-  compile "$HERE/$f.hip" "$BUILD/$f.o" "$DEV_FLAGS" "$HERE/q3_engine.h" "$HERE/q3_kernels.h" "$HERE/q3_internal.h" "$HERE/q3_aql.h" "$API"
+  compile "$HERE/$f.hip" "$BUILD/$f.o" "$DEV_FLAGS" "$HERE/q3_engine.h" "$HERE/q3_capture_lock.h" "$HERE/q3_kernels.h" "$HERE/q3_internal.h" "$HERE/q3_aql.h" "$API"
 done
 compile "$HERE/q3_io.cpp" "$BUILD/q3_io.o" "$HOST_FLAGS" "$HERE/q3_internal.h" "$API"
 compile "$HERE/q3_dp.cpp" "$BUILD/q3_dp.o" "$HOST_FLAGS" "$HERE/q3_internal.h" "$API"
-compile "$HERE/q3_aql.cpp" "$BUILD/q3_aql.o" "$HOST_FLAGS" "$HERE/q3_aql.h"
+compile "$HERE/q3_aql.cpp" "$BUILD/q3_aql.o" "$HOST_FLAGS" "$HERE/q3_aql.h" "$HERE/q3_capture_lock.h"
 fail=0
 for p in "${pids[@]}"; do wait $p || fail=1; done
 [ $fail = 0 ] || { echo "build failed" >&2; exit 1; }

@@ -23,6 +23,7 @@
 // libhsa-runtime64 is resolved with dlopen (it is the library libamdhip64 itself sits on, so it is always present and already
 // initialised); libq3tts.so keeps linking only libamdhip64. Nothing here computes: without the HIP kernels there is no path.
 #include "q3_aql.h"
+#include "q3_capture_lock.h"
 
 #include <dlfcn.h>
 #include <hsa/hsa.h>
@@ -417,7 +418,7 @@ AqlProgram* aql_program_create(hipGraph_t graph, int device, const AqlPolicy& po
         memcpy(p->kernargs, host_args.data(), host_args.size());
     } else {
         if (hipMalloc(&p->kernargs, host_args.size()) != hipSuccess) { *why = "hipMalloc(kernargs) failed"; return nullptr; }
-        if (hipMemcpy(p->kernargs, host_args.data(), host_args.size(), hipMemcpyHostToDevice) != hipSuccess) { *why = "hipMemcpy(kernargs) failed"; aql_program_destroy(p.release()); return nullptr; }
+        if (q3_hipMemcpy(p->kernargs, host_args.data(), host_args.size(), hipMemcpyHostToDevice) != hipSuccess) { *why = "q3_hipMemcpy(kernargs) failed"; aql_program_destroy(p.release()); return nullptr; }
     }
     for (size_t i = 0; i < p->pk.size(); ++i) p->pk[i].kernarg_address = (char*)p->kernargs + arg_off[i];
     if ((size_t)p->pk.size() * 2 > rt->queue->size) { *why = "frame longer than half the packet ring"; aql_program_destroy(p.release()); return nullptr; }

@@ -155,7 +155,7 @@ static q3_status session_idle_row(q3_session* s, int b) {
     int ran = s->frames_run - q.start_run; if (ran < 0) ran = 0; if (ran > q.limit) ran = q.limit;
     q.limit = ran;
     HIPC(sync_frames(s));          // no frame in flight while the row's limit and pages change
-    HIPC(hipMemcpy(s->limit + b, &q.limit, sizeof(int), hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(s->limit + b, &q.limit, sizeof(int), hipMemcpyHostToDevice));
     // A frozen row still runs through every frame (its results are dropped): it reads its keys and rewrites the K/V of its
     // frozen position, prefill_len + ran. It keeps the ONE page that position lies in and every table entry it can reach points
     // there, zero-filled (below); the other pages go back to the pool, and the row takes no
@@ -173,7 +173,7 @@ static q3_status session_idle_row(q3_session* s, int b) {
         // (a previous owner's bits, possibly NaN / Inf, which would then run through the sampler and the embedding gather of a row
         // nobody reads); zeros are finite keys. One strided memset per K and V: n_layers runs of nkv * KV_PAGE_POS * HEAD_DIM elements.
         std::vector<unsigned long long> ent((size_t)KV_MAX_PAGES, (unsigned long long)kept);
-        HIPC(hipMemcpy(s->kv_table + (size_t)b * KV_MAX_PAGES, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
+        HIPC(q3_hipMemcpy(s->kv_table + (size_t)b * KV_MAX_PAGES, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
         const KvPool& pool = s->kv_in_bf16 ? s->m->kv_pool16 : s->m->kv_pool;
         const size_t run_bytes = pool.run_floats * pool.elem_bytes, pitch = pool.layer_stride() * pool.elem_bytes;
         HIPC(hipMemset2DAsync(kept, pitch, 0, run_bytes, (size_t)pool.n_layers, s->stream));
@@ -340,8 +340,8 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
     auto stage_begin = [&]() {
         static const bool off = getenv("Q3_BAT_NO_STAGE") != nullptr;
         if (off || b->stage.id >= 0 || b->queue.empty() || b->s->debug || b->s->profile) return;
-        // not while this thread may still CAPTURE the host session's frame (the first graph step): the worker's allocations and
-        // null-stream zero-fills invalidate a capture in progress on this HIP runtime, thread-local capture mode or not
+        // not while this thread may still CAPTURE the host session's frame (the first graph step): one thing less to go wrong
+        // (captures are in relaxed mode and repeated when invalidated: q3_session.hip frame_capture)
         if (use_graph ? b->s->graph == nullptr : false) return;
         { std::lock_guard<std::mutex> g(b->m->kv_budget.mu); if (b->m->kv_budget.limit > 0) return; }
         bool any_free = false;

@@ -80,7 +80,7 @@ q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T, int Tf) {
     if (T <= ws.cap_frames && Tf <= ws.cap_front) return Q3_OK;
     if (T < ws.cap_frames) T = ws.cap_frames;
     if (Tf < ws.cap_front) Tf = ws.cap_front;
-    if (ws.bufA) HIPC(hipDeviceSynchronize());        // growing: the old blocks go back to the cache, nothing may still be using them
+    if (ws.bufA) HIPC(q3_hipDeviceSynchronize());        // growing: the old blocks go back to the cache, nothing may still be using them
     ws.release();
     const q3_config& c = m->cfg;
     int up = 1; for (int i = 0; i < 2; ++i) up *= c.dec_up_ratios[i];
@@ -111,8 +111,8 @@ q3_status codec_reserve(const q3_model* m, CodecWS& ws, int T, int Tf) {
         const float inv = 1.0f / powf(c.dec_theta, (float)(2 * i) / (float)c.dec_head_dim);
         for (int t = 0; t < Tf; ++t) { const float f = (float)t * inv; cs[(size_t)t * 32 + i] = cosf(f); sn[(size_t)t * 32 + i] = sinf(f); }
     }
-    HIPC(hipMemcpy(ws.cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(ws.sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(ws.cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(ws.sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
     ws.cap_frames = T; ws.cap_front = Tf;
     return Q3_OK;
 }
@@ -156,7 +156,7 @@ q3_status codec_decode_dev(const q3_model* m, CodecWS& ws, int T, hipStream_t st
     const CodecPlanesScope planes_scope(NPL);
     const int CD = c.dec_cb_dim, Q = c.dec_q_dim, LAT = c.dec_latent, DH = c.dec_hidden, QD = c.dec_heads * c.dec_head_dim, DI = c.dec_inter;
     auto TAP = [&](int id, const float* dev, size_t n) -> q3_status {
-        if (taps && taps[id]) { HIPC(hipStreamSynchronize(st)); HIPC(hipMemcpy(taps[id], dev, n * 4, hipMemcpyDeviceToHost)); }
+        if (taps && taps[id]) { HIPC(hipStreamSynchronize(st)); HIPC(q3_hipMemcpy(taps[id], dev, n * 4, hipMemcpyDeviceToHost)); }
         return Q3_OK;
     };
     float *A = ws.bufA, *B = ws.bufB, *C = ws.bufC, *D = ws.bufD, *E = ws.bufE;
@@ -309,13 +309,13 @@ extern "C" q3_status q3_decode_codes(q3_model* m, const uint32_t* frames_host, i
     CodecWS ws;
     q3_status st = codec_reserve(m, ws, n_frames);
     if (st == Q3_OK) {
-        hipError_t e = hipMemcpy(ws.frames, frames_host, (size_t)n_frames * 16 * 4, hipMemcpyHostToDevice);
+        hipError_t e = q3_hipMemcpy(ws.frames, frames_host, (size_t)n_frames * 16 * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "hipMemcpy frames: %s", hipGetErrorString(e));
     }
     if (st == Q3_OK) st = codec_decode_dev(m, ws, n_frames, 0, taps_host);
     if (st == Q3_OK) {
-        hipError_t e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipMemcpy(pcm_host, ws.pcm, (size_t)n_frames * samples_per_frame(m->cfg) * 4, hipMemcpyDeviceToHost);
+        hipError_t e = q3_hipDeviceSynchronize();
+        if (e == hipSuccess) e = q3_hipMemcpy(pcm_host, ws.pcm, (size_t)n_frames * samples_per_frame(m->cfg) * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) st = set_err(Q3_HIP_ERROR, "decode: %s", hipGetErrorString(e));
     }
     ws.release();

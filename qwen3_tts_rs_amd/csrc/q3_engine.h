@@ -44,8 +44,24 @@ using namespace q3;
 // errors (q3_model.hip): thread-local message behind q3_last_error()
 // ------------------------------------------------------------------------------------------------
 Q3_HIDDEN q3_status set_err(q3_status st, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// Every host thread that calls into the engine runs its HIP calls in RELAXED stream-capture mode: a session captures its frame
+// (kernel launches only, on its own non-blocking stream) while other threads — the batcher's prefill worker, a server's other
+// sessions — allocate, hipMemcpy and synchronise; with the default (global) thread mode this HIP runtime fails THOSE calls with
+// "operation not permitted when stream is capturing" whatever mode the capture itself was begun in.
+static inline void q3_relax_capture_mode() {
+    static thread_local bool done = false;
+    if (!done) { hipStreamCaptureMode m = hipStreamCaptureModeRelaxed; (void)hipThreadExchangeStreamCaptureMode(&m); done = true; }
+}
+// ... and that is not enough on this runtime: an operation on the LEGACY (null) stream — a synchronous hipMemcpy, the zero-fills of
+// DevPool, hipDeviceSynchronize — issued by one thread while another thread's stream is capturing fails with "operation would
+// make the legacy stream depend on a capturing blocking stream" (and invalidates the capture), non-blocking capturing stream and
+// relaxed modes notwithstanding (tests/test_frame_submission.py: two sessions on two threads). So the two exclude each other:
+// a capture (q3_session.hip frame_capture: ~1 ms of kernel launches, once per session) holds this lock exclusively, every
+// legacy-stream operation of the engine holds it shared (the q3_hip* wrappers below; the engine's units call nothing else).
+#include "q3_capture_lock.h"
 #define HIPC(expr)                                                                                        \
     do {                                                                                                  \
+        q3_relax_capture_mode();                                                                          \
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess)                                                                             \
             return set_err(Q3_HIP_ERROR, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
@@ -271,7 +287,7 @@ struct DevPool {
     // uploads that may follow) and settle() waits for all of them once — a session is ~45 buffers, and a memset + a device
     // synchronisation each was 2-3 ms of every q3_session_create (the side session of a continuous-batching swap)
     bool lazy = false;
-    hipError_t settle() { return hipStreamSynchronize(nullptr); }
+    hipError_t settle() { return q3_null_stream_sync(); }
     template <typename T> hipError_t alloc(T** p, size_t count) {
         void* q = nullptr;
         hipError_t e = dev_malloc(&q, (count ? count : 1) * sizeof(T));
@@ -280,12 +296,10 @@ struct DevPool {
         // zero-fill on the null stream and WAIT for it: the users launch on non-blocking streams, which the null stream
         // does not order against — a memset still in flight would wipe what their first kernels write (seen once the
         // blocks started coming from the cache instead of a slow hipMalloc)
-        hipError_t m = hipMemsetAsync(q, 0, (count ? count : 1) * sizeof(T), nullptr);
-        if (m != hipSuccess) return m;
-        return lazy ? hipSuccess : hipStreamSynchronize(nullptr);
+        return q3_null_stream_memset(q, (count ? count : 1) * sizeof(T), !lazy);
     }
     void release_all() {
-        if (lazy) (void)hipStreamSynchronize(nullptr);      // a creation that failed midway: no zero-fill may outlive its block's ownership
+        if (lazy) (void)q3_null_stream_sync();      // a creation that failed midway: no zero-fill may outlive its block's ownership
         for (void* p : ptrs) dev_free(p);
         ptrs.clear(); lazy = false;
     }

@@ -15,6 +15,7 @@
 //   * k_mimi_rvq: one workgroup per frame walks the quantiser layers (distance to 2048 entries, first minimum, subtract).
 #include "../../include/q3tts.h"
 #include "q3_kernels.h"
+#include "q3_capture_lock.h"
 #include "q3_internal.h"
 
 #include <math.h>
@@ -277,7 +278,7 @@ extern "C" q3_status q3_mimi_set_tensor(q3_speech_encoder* e, const char* name, 
                         f[(((size_t)co * cin + ci) * r + p) * 2 + j] = tmp[((size_t)co * cin + ci) * 2 * r + (size_t)j * r + p];
         tmp.swap(f);
     }
-    M_HIP(hipMemcpy(e->arena + s.offset, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    M_HIP(q3_hipMemcpy(e->arena + s.offset, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     s.loaded = true; e->finalized = false;
     return Q3_OK;
 }
@@ -404,7 +405,7 @@ extern "C" q3_status q3_mimi_encode(q3_speech_encoder* e, const float* samples, 
             for (int t = 0; t < cap; ++t) { const float f = (float)t * inv; cs[(size_t)t * 32 + i] = cosf(f); sn[(size_t)t * 32 + i] = sinf(f); }
         }
         M_HIP(hipMalloc((void**)&e->cs, cs.size() * 4)); M_HIP(hipMalloc((void**)&e->sn, sn.size() * 4));
-        M_HIP(hipMemcpy(e->cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice)); M_HIP(hipMemcpy(e->sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+        M_HIP(q3_hipMemcpy(e->cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice)); M_HIP(q3_hipMemcpy(e->sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
         e->rope_T = cap;
     }
     if (T > e->codes_cap) {
@@ -416,7 +417,7 @@ extern "C" q3_status q3_mimi_encode(q3_speech_encoder* e, const float* samples, 
     float* A = e->ws; float* B = A + big; float* C = B + big; float* tr = C + big;
     hipStream_t st = e->st;
     auto TAP = [&](int id, const float* dev, size_t cnt) -> q3_status {
-        if (taps_host && taps_host[id]) { M_HIP(hipStreamSynchronize(st)); M_HIP(hipMemcpy(taps_host[id], dev, cnt * 4, hipMemcpyDeviceToHost)); }
+        if (taps_host && taps_host[id]) { M_HIP(hipStreamSynchronize(st)); M_HIP(q3_hipMemcpy(taps_host[id], dev, cnt * 4, hipMemcpyDeviceToHost)); }
         return Q3_OK;
     };
     // ---- SEANet ----
@@ -474,6 +475,6 @@ extern "C" q3_status q3_mimi_encode(q3_speech_encoder* e, const float* samples, 
     }
     M_HIP(hipGetLastError());
     M_HIP(hipStreamSynchronize(st));
-    M_HIP(hipMemcpy(codes_host, e->codes_dev, (size_t)T * c.n_q * 4, hipMemcpyDeviceToHost));
+    M_HIP(q3_hipMemcpy(codes_host, e->codes_dev, (size_t)T * c.n_q * 4, hipMemcpyDeviceToHost));
     return Q3_OK;
 }

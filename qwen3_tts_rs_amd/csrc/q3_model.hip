@@ -418,7 +418,7 @@ extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtyp
         if (s.dual) {
             std::vector<uint16_t> t2(tiled_elems(2, s.rows, s.cols));
             retile_bf16(w.data(), s.rows, s.cols, t2.data(), 2);
-            HIPC(hipMemcpy(m->arena + s.offset2, t2.data(), t2.size() * 2, hipMemcpyHostToDevice));
+            HIPC(q3_hipMemcpy(m->arena + s.offset2, t2.data(), t2.size() * 2, hipMemcpyHostToDevice));
         }
     } else if (s.kind == SK_TRANSCONV) {
         // [cin][cout][k] → per-phase causal-conv weights [stride][cout][cin][taps]
@@ -450,7 +450,7 @@ extern "C" q3_status q3_model_set_tensor(q3_model* m, const char* name, int dtyp
     } else if (dtype != Q3_DTYPE_F32 && dtype != Q3_DTYPE_BF16) {
         return set_err(Q3_INVALID_ARG, "unsupported source dtype %d", dtype);
     }
-    HIPC(hipMemcpy(m->arena + s.offset, src, up_bytes, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(m->arena + s.offset, src, up_bytes, hipMemcpyHostToDevice));
     s.loaded = true;
     m->finalized = false;
     return Q3_OK;
@@ -522,7 +522,7 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
         m->cp_head[g] = PT(m, fmt("talker.code_predictor.lm_head.%d.weight", g));
     }
     if (!m->cp_embs_dev) HIPC(hipMalloc((void**)&m->cp_embs_dev, 15 * sizeof(void*)));
-    HIPC(hipMemcpy((void*)m->cp_embs_dev, m->cp_emb.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy((void*)m->cp_embs_dev, m->cp_emb.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
     if (m->mtp_w.t1) {
         // Pre-projected embedding tables (1.7B): 15 x [cp_vocab][CH] + [codec_vocab][CH] f32 (138 MB). Built with the very
         // GEMV launches the frame loop would use (8 gathered rows per launch), so a table row is exactly what the
@@ -604,8 +604,8 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
         }
         HIPC(hipMalloc((void**)&m->rope_cos, cs.size() * 4));
         HIPC(hipMalloc((void**)&m->rope_sin, sn.size() * 4));
-        HIPC(hipMemcpy(m->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(m->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+        HIPC(q3_hipMemcpy(m->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+        HIPC(q3_hipMemcpy(m->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
     }
 
     // decoder pointers + derived tensors (normalised codebooks, snake tables)
@@ -624,7 +624,7 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
     m->first_cb = CBOOK("decoder.quantizer.rvq_first.vq.layers.0");
     for (int i = 0; i < 15; ++i) rest[i] = CBOOK(fmt("decoder.quantizer.rvq_rest.vq.layers.%d", i));
     if (!m->rest_cbs_dev) HIPC(hipMalloc((void**)&m->rest_cbs_dev, 15 * sizeof(void*)));
-    HIPC(hipMemcpy((void*)m->rest_cbs_dev, rest.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy((void*)m->rest_cbs_dev, rest.data(), 15 * sizeof(void*), hipMemcpyHostToDevice));
     auto SNAKE = [&](const std::string& pa, const std::string& pb, int C, const float*& a, const float*& ib) {
         float* da = cursor; cursor += C; float* di = cursor; cursor += C;
         launch_snake_tables(P<float>(m, pa), P<float>(m, pb), da, di, C, 0);
@@ -719,7 +719,7 @@ extern "C" q3_status q3_model_finalize(q3_model* m) {
         }
     }
     HIPC(hipGetLastError());
-    HIPC(hipDeviceSynchronize());
+    HIPC(q3_hipDeviceSynchronize());
     // the f32 page pool's first slab now, not inside the first session's prefill (its ~1 GB hipMalloc sat on the first request's
     // time to first audio); a failure here is not fatal — the first session will report it. Q3_KV_NO_PREWARM=1: lazily, as before
     if (!getenv("Q3_KV_NO_PREWARM")) { if (m->kv_pool.prewarm() != hipSuccess) (void)hipGetLastError(); }

@@ -636,8 +636,8 @@ q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int fra
     {
         std::vector<int> lim(B); std::vector<SampleRow> sr(B);
         for (int b = 0; b < B; ++b) { lim[b] = s->seq[b].limit; sr[b] = sample_row(s->seq[b].req.opts); }
-        HIPC(hipMemcpy(s->limit, lim.data(), B * 4, hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(s->sample_rows, sr.data(), B * sizeof(SampleRow), hipMemcpyHostToDevice));
+        HIPC(q3_hipMemcpy(s->limit, lim.data(), B * 4, hipMemcpyHostToDevice));
+        HIPC(q3_hipMemcpy(s->sample_rows, sr.data(), B * sizeof(SampleRow), hipMemcpyHostToDevice));
     }
     HIPC(s->pool.alloc(&s->embeds, (size_t)B * s->prefill_len * H));
     HIPC(s->pool.alloc(&s->xvec, (size_t)B * H));
@@ -658,7 +658,7 @@ q3_status session_create(q3_model* m, const q3_request* reqs, int batch, int fra
         q3_rng_seed(seed, &st);
         for (int i = 0; i <= s->max_frames; ++i) U[(size_t)b * (s->max_frames + 2) + i] = q3_rng_next(&st);
     }
-    HIPC(hipMemcpy(s->U, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(s->U, U.data(), U.size() * 4, hipMemcpyHostToDevice));
     HIPC(s->pool.settle());                 // every zero-fill has landed before a kernel on the session's own stream can run
     s->pool.lazy = false;
     *out = s.release();
@@ -980,7 +980,7 @@ extern "C" q3_status q3_session_prefill(q3_session* s) {
         HIPC(s->pool.alloc(&s->ref_codes_dev, ref_total));
         for (int b = 0; b < B; ++b)
             if (!s->seq[b].ref_codes.empty())
-                HIPC(hipMemcpy(s->ref_codes_dev + ref_off[b], s->seq[b].ref_codes.data(), s->seq[b].ref_codes.size() * 4, hipMemcpyHostToDevice));
+                HIPC(q3_hipMemcpy(s->ref_codes_dev + ref_off[b], s->seq[b].ref_codes.data(), s->seq[b].ref_codes.size() * 4, hipMemcpyHostToDevice));
     }
     // uploads ride the session stream (the host vectors live until the synchronisation that ends this function)
     HIPC(hipMemcpyAsync(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s->stream));
@@ -1054,11 +1054,11 @@ static q3_status refresh_codes(q3_session* s) {
         int ran = s->frames_run - s->seq[b].start_run;
         if (ran > s->seq[b].limit) ran = s->seq[b].limit;
         if (ran > 0)
-            HIPC(hipMemcpy(&s->codes_host[(size_t)b * s->max_frames * 16], s->codes + (size_t)b * s->max_frames * 16,
+            HIPC(q3_hipMemcpy(&s->codes_host[(size_t)b * s->max_frames * 16], s->codes + (size_t)b * s->max_frames * 16,
                            (size_t)ran * 16 * 4, hipMemcpyDeviceToHost));
     }
     std::vector<uint32_t> tok(s->B);
-    HIPC(hipMemcpy(tok.data(), s->tok, s->B * 4, hipMemcpyDeviceToHost));
+    HIPC(q3_hipMemcpy(tok.data(), s->tok, s->B * 4, hipMemcpyDeviceToHost));
     for (int b = 0; b < s->B; ++b) {
         SeqInfo& q = s->seq[b];
         int n = s->frames_run - q.start_run; bool done = false;      // frames this row has run (rows swapped in later started later)
@@ -1123,12 +1123,16 @@ static void frame_fence_policy(const char* name, int* acquire, int* release) {
 // activation-transport rule (q3_kernels.h) without HIP's agent-scope fences. Q3_AQL=0: hipGraphLaunch; 1: own queue with HIP's
 // fences on every packet (bit-identical to 0); 2: probe. Why a graph stayed on hipGraphLaunch: Q3_AQL_VERBOSE=1.
 static q3_status frame_capture(q3_session* s, bool stream_busy) {
-    // (another host thread's allocations or null-stream work can invalidate a capture in progress on this HIP runtime, thread-local
-    // capture mode or not — the batcher's prefill worker, a server opening sessions on several threads: the capture is repeated)
+    // RELAXED capture mode: the captured region is nothing but kernel launches on the session's own non-blocking stream, while OTHER
+    // host threads — the batcher's prefill worker, a server opening sessions on several threads — allocate, hipMemcpy and touch the
+    // null stream as they please: in thread-local (or global) mode this HIP runtime fails THEIR calls ("operation not permitted
+    // when stream is capturing") and invalidates the capture (tests/test_frame_submission.py: two sessions on two threads). An
+    // invalidated capture is repeated all the same.
     for (int attempt = 0; !s->graph; ++attempt) {
         if (!stream_busy) HIPC(sync_frames(s));
+        std::unique_lock<std::shared_mutex> cap(q3_capture_mu());      // no legacy-stream operation of any thread while the capture is open (q3_engine.h)
         {
-            const hipError_t eb = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal);
+            const hipError_t eb = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed);
             if (eb != hipSuccess && stream_busy) { (void)hipGetLastError(); return Q3_OK; }      // not now: q3_session_generate captures on the idle stream
             HIPC(eb);
         }
@@ -1266,7 +1270,7 @@ extern "C" q3_status q3_session_next_chunk_row(q3_session* s, int b, float* pcm_
         if (n_samples) *n_samples = (size_t)avail * spf;
         if (pcm_host) {
             if (cap < (size_t)avail * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
-            HIPC(hipMemcpy(pcm_host, s->cws.pcm + (size_t)(a0 - c0) * spf, (size_t)avail * spf * 4, hipMemcpyDeviceToHost));
+            HIPC(q3_hipMemcpy(pcm_host, s->cws.pcm + (size_t)(a0 - c0) * spf, (size_t)avail * spf * 4, hipMemcpyDeviceToHost));
         }
     } else {
         Q3C(decode_range_on(s, b, q.stream_pos, q.stream_pos + avail, s->stream, pcm_host, cap, n_samples));
@@ -1309,7 +1313,7 @@ static q3_status decode_range_on(q3_session* s, int b, int f0, int f1, hipStream
     HIPC(hipStreamSynchronize(st));
     if (pcm_host) {
         if (cap < (size_t)T * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
-        HIPC(hipMemcpy(pcm_host, s->cws.pcm, (size_t)T * spf * 4, hipMemcpyDeviceToHost));
+        HIPC(q3_hipMemcpy(pcm_host, s->cws.pcm, (size_t)T * spf * 4, hipMemcpyDeviceToHost));
     }
     return Q3_OK;
 }
@@ -1335,7 +1339,7 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
         HIPC(sync_frames(s));
         if (pcm_host) {
             if (cap < all - cut) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
-            HIPC(hipMemcpy(pcm_host, s->cws.pcm + cut, (all - cut) * 4, hipMemcpyDeviceToHost));
+            HIPC(q3_hipMemcpy(pcm_host, s->cws.pcm + cut, (all - cut) * 4, hipMemcpyDeviceToHost));
         }
         return Q3_OK;
     }
@@ -1492,7 +1496,7 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
         if (n_samples) n_samples[b] = n;
         if (pcm_host && pcm_host[b] && n) {
             if (!cap || cap[b] < n) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
-            HIPC(hipMemcpy(pcm_host[b], s->pcm_all + (size_t)b * s->max_frames * spf, n * 4, hipMemcpyDeviceToHost));
+            HIPC(q3_hipMemcpy(pcm_host[b], s->pcm_all + (size_t)b * s->max_frames * spf, n * 4, hipMemcpyDeviceToHost));
         }
         total += s->seq[b].n_frames;
     }
@@ -1580,7 +1584,7 @@ extern "C" q3_status q3_session_next_chunk(q3_session* s, float* pcm_host, size_
     if (n_samples) *n_samples = (size_t)avail * spf;
     if (pcm_host) {
         if (cap < (size_t)avail * spf) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
-        HIPC(hipMemcpy(pcm_host, src, (size_t)avail * spf * 4, hipMemcpyDeviceToHost));
+        HIPC(q3_hipMemcpy(pcm_host, src, (size_t)avail * spf * 4, hipMemcpyDeviceToHost));
     }
     s->stream_pos += avail;
     if (done) *done = chunk_done ? 1 : 0;
@@ -1608,7 +1612,7 @@ extern "C" q3_status q3_session_get(q3_session* s, int what, int b, void* out, s
             need = (size_t)15 * c.cp_vocab * 4;
             if (bytes < need) return set_err(Q3_INVALID_ARG, "buffer too small");
             for (int g = 0; g < 15; ++g)
-                HIPC(hipMemcpy((char*)out + (size_t)g * c.cp_vocab * 4, s->CP_LOGITS + ((size_t)g * s->B + b) * c.cp_vocab, (size_t)c.cp_vocab * 4, hipMemcpyDeviceToHost));
+                HIPC(q3_hipMemcpy((char*)out + (size_t)g * c.cp_vocab * 4, s->CP_LOGITS + ((size_t)g * s->B + b) * c.cp_vocab, (size_t)c.cp_vocab * 4, hipMemcpyDeviceToHost));
             return Q3_OK;
         }
         case Q3_GET_CP_LOGITS_HIST: {
@@ -1617,14 +1621,14 @@ extern "C" q3_status q3_session_get(q3_session* s, int what, int b, void* out, s
             if (bytes < need) return set_err(Q3_INVALID_ARG, "buffer too small");
             for (int f = 0; f < s->frames_run; ++f)
                 for (int g = 0; g < 15; ++g)
-                    HIPC(hipMemcpy((char*)out + ((size_t)f * 15 + g) * c.cp_vocab * 4,
+                    HIPC(q3_hipMemcpy((char*)out + ((size_t)f * 15 + g) * c.cp_vocab * 4,
                                    s->cp_logits_hist + (((size_t)f * 15 + g) * s->B + b) * c.cp_vocab, (size_t)c.cp_vocab * 4, hipMemcpyDeviceToHost));
             return Q3_OK;
         }
         default: return set_err(Q3_INVALID_ARG, "unknown item %d", what);
     }
     if (bytes < need) return set_err(Q3_INVALID_ARG, "buffer too small (%zu < %zu)", bytes, need);
-    HIPC(hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
+    HIPC(q3_hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
     return Q3_OK;
 }
 

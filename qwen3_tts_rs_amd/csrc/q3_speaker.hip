@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "q3_internal.h"
+#include "q3_capture_lock.h"
 #include "q3_kernels.h"
 
 namespace q3 {
@@ -269,12 +270,12 @@ extern "C" q3_status q3_spk_set_tensor(q3_speaker_encoder* e, const char* name, 
     if (s.n != n) return q3i_set_err(Q3_INVALID_ARG, "tensor %s: expected %lld elements, got %lld", name, (long long)s.n, (long long)n);
     SPK_HIP(hipSetDevice(e->device));
     if (src_dtype == Q3_DTYPE_F32) {
-        SPK_HIP(hipMemcpy(e->arena + s.offset, data, (size_t)n * 4, hipMemcpyHostToDevice));
+        SPK_HIP(q3_hipMemcpy(e->arena + s.offset, data, (size_t)n * 4, hipMemcpyHostToDevice));
     } else if (src_dtype == Q3_DTYPE_BF16) {
         std::vector<float> tmp((size_t)n);
         const uint16_t* h = (const uint16_t*)data;
         for (int64_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)h[i] << 16; memcpy(&tmp[(size_t)i], &u, 4); }
-        SPK_HIP(hipMemcpy(e->arena + s.offset, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        SPK_HIP(q3_hipMemcpy(e->arena + s.offset, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     } else {
         return q3i_set_err(Q3_INVALID_ARG, "q3_spk_set_tensor: unsupported source dtype %d", src_dtype);
     }
@@ -373,10 +374,10 @@ extern "C" q3_status q3_spk_finalize(q3_speaker_encoder* e) {
         SPK_HIP(hipMalloc((void**)&e->win, NF * 4)); SPK_HIP(hipMalloc((void**)&e->dft_cs, NF * 8)); SPK_HIP(hipMalloc((void**)&e->dft_sn, NF * 8));
         SPK_HIP(hipMalloc((void**)&e->fb, fb.size() * 4));
     }
-    SPK_HIP(hipMemcpy(e->win, win.data(), NF * 4, hipMemcpyHostToDevice));
-    SPK_HIP(hipMemcpy(e->dft_cs, cs.data(), NF * 8, hipMemcpyHostToDevice));
-    SPK_HIP(hipMemcpy(e->dft_sn, sn.data(), NF * 8, hipMemcpyHostToDevice));
-    SPK_HIP(hipMemcpy(e->fb, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
+    SPK_HIP(q3_hipMemcpy(e->win, win.data(), NF * 4, hipMemcpyHostToDevice));
+    SPK_HIP(q3_hipMemcpy(e->dft_cs, cs.data(), NF * 8, hipMemcpyHostToDevice));
+    SPK_HIP(q3_hipMemcpy(e->dft_sn, sn.data(), NF * 8, hipMemcpyHostToDevice));
+    SPK_HIP(q3_hipMemcpy(e->fb, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
     SPK_HIP(hipStreamSynchronize(e->st));
     e->finalized = true;
     return Q3_OK;

@@ -10,7 +10,7 @@ extern "C" q3_status q3_talker_step(q3_session* s, const float* embeds_host, flo
     // the step writes K/V at `pos`: refuse BEFORE running when that slot does not exist (a step at pos == max_seq - 1 is valid)
     std::vector<int> posv(s->B);
     HIPC(sync_frames(s));
-    HIPC(hipMemcpy(posv.data(), s->pos, s->B * 4, hipMemcpyDeviceToHost));
+    HIPC(q3_hipMemcpy(posv.data(), s->pos, s->B * 4, hipMemcpyDeviceToHost));
     for (int p : posv) if (p >= s->max_seq) return set_err(Q3_KV_OVERFLOW, "KV cache full (%d)", s->max_seq);
     for (int b = 0; b < s->B; ++b) Q3C(kv_reserve_row(s, b, posv[(size_t)b] + 1));       // paged KV: the slot this step writes
     HIPC(hipMemcpyAsync(s->tb.X, embeds_host, (size_t)s->B * c.hidden * 4, hipMemcpyHostToDevice, s->stream));
@@ -18,9 +18,9 @@ extern "C" q3_status q3_talker_step(q3_session* s, const float* embeds_host, flo
     // advance positions by one (host-driven teacher forcing)
     HIPC(sync_frames(s));
     for (int& p : posv) p += 1;
-    HIPC(hipMemcpy(s->pos, posv.data(), s->B * 4, hipMemcpyHostToDevice));
-    if (hidden_host) HIPC(hipMemcpy(hidden_host, s->LASTH, (size_t)s->B * c.hidden * 4, hipMemcpyDeviceToHost));
-    if (logits_host) HIPC(hipMemcpy(logits_host, s->LOGITS, (size_t)s->B * c.codec_vocab * 4, hipMemcpyDeviceToHost));
+    HIPC(q3_hipMemcpy(s->pos, posv.data(), s->B * 4, hipMemcpyHostToDevice));
+    if (hidden_host) HIPC(q3_hipMemcpy(hidden_host, s->LASTH, (size_t)s->B * c.hidden * 4, hipMemcpyDeviceToHost));
+    if (logits_host) HIPC(q3_hipMemcpy(logits_host, s->LOGITS, (size_t)s->B * c.codec_vocab * 4, hipMemcpyDeviceToHost));
     return Q3_OK;
 }
 
@@ -35,7 +35,7 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
     HIPC(hipMemcpyAsync(s->LASTH, last_hidden_host, (size_t)B * H * 4, hipMemcpyHostToDevice, s->stream));
     const LmDims d = cp_dims(c);
     float* sem_dev = nullptr;
-    if (sem_embed_host) { HIPC(hipMalloc((void**)&sem_dev, (size_t)B * H * 4)); HIPC(hipMemcpy(sem_dev, sem_embed_host, (size_t)B * H * 4, hipMemcpyHostToDevice)); }
+    if (sem_embed_host) { HIPC(hipMalloc((void**)&sem_dev, (size_t)B * H * 4)); HIPC(q3_hipMemcpy(sem_dev, sem_embed_host, (size_t)B * H * 4, hipMemcpyHostToDevice)); }
     q3_status st = Q3_OK;
     auto run = [&]() -> q3_status {
         for (int p = 0; p < c.n_groups; ++p) {
@@ -70,7 +70,7 @@ extern "C" q3_status q3_cp_generate(q3_session* s, const float* last_hidden_host
     if (sem_dev) hipFree(sem_dev);
     Q3C(st);
     std::vector<float> lg((size_t)15 * B * V);
-    HIPC(hipMemcpy(lg.data(), s->CP_LOGITS, lg.size() * 4, hipMemcpyDeviceToHost));
+    HIPC(q3_hipMemcpy(lg.data(), s->CP_LOGITS, lg.size() * 4, hipMemcpyDeviceToHost));
     for (int b = 0; b < B; ++b)
         for (int g = 0; g < 15; ++g) {
             const float* row = &lg[((size_t)g * B + b) * V];
@@ -97,19 +97,19 @@ extern "C" q3_status q3_frame_embed(q3_model* m, uint32_t sem_token, const uint3
     if (codes15[14] >= (uint32_t)V) return set_err(Q3_INVALID_ARG, "code out of range");
     std::vector<float> lg((size_t)V, 0.0f); lg[codes15[14]] = 1.0f;
     const int h_one = 1;
-    HIPC(hipMemcpy(rows, text_add_host, (size_t)H * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(logits, lg.data(), (size_t)V * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(tok, &sem_token, 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(codes, frame, 64, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(one, &h_one, 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(rows, text_add_host, (size_t)H * 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(logits, lg.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(tok, &sem_token, 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(codes, frame, 64, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(one, &h_one, 4, hipMemcpyHostToDevice));
     FrameEmbedArgs f{};
     f.codec_emb = m->codec_emb; f.tok = tok; f.cp_logits_last = logits; f.cp_vocab = V;
     for (int g = 0; g < 15; ++g) f.cp_embs[g] = g < (int)m->cp_emb.size() ? m->cp_emb[(size_t)g] : nullptr;
     f.codes = codes; f.frame_idx = zero; f.max_frames = 1; f.text_rows = rows; f.trail_base = zero; f.trail_len = one; f.pad_row = zero;
     f.out = out; f.H = H; f.B = 1; f.n_acoustic = 15;
     HIPC(launch_frame_embed(f, 0));
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(out_host, out, (size_t)H * 4, hipMemcpyDeviceToHost));
+    HIPC(q3_hipDeviceSynchronize());
+    HIPC(q3_hipMemcpy(out_host, out, (size_t)H * 4, hipMemcpyDeviceToHost));
     return Q3_OK;
 }
 
@@ -121,9 +121,9 @@ extern "C" q3_status q3_sample(int device, const float* logits_host, const uint8
     DevPool pool;
     float *lg, *u; uint8_t* seen = nullptr; uint32_t* tok;
     HIPC(pool.alloc(&lg, (size_t)rows * vocab)); HIPC(pool.alloc(&u, (size_t)rows)); HIPC(pool.alloc(&tok, (size_t)rows));
-    HIPC(hipMemcpy(lg, logits_host, (size_t)rows * vocab * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(u, u_host, (size_t)rows * 4, hipMemcpyHostToDevice));
-    if (seen_host) { HIPC(pool.alloc(&seen, (size_t)rows * vocab)); HIPC(hipMemcpy(seen, seen_host, (size_t)rows * vocab, hipMemcpyHostToDevice)); }
+    HIPC(q3_hipMemcpy(lg, logits_host, (size_t)rows * vocab * 4, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(u, u_host, (size_t)rows * 4, hipMemcpyHostToDevice));
+    if (seen_host) { HIPC(pool.alloc(&seen, (size_t)rows * vocab)); HIPC(q3_hipMemcpy(seen, seen_host, (size_t)rows * vocab, hipMemcpyHostToDevice)); }
     SampleArgs a; memset(&a, 0, sizeof a);
     a.logits = lg; a.ld = vocab; a.seen = seen; a.u = u; a.u_stride = 1; a.tok = tok; a.token_count_static = token_count < 0 ? 0 : token_count;
     a.vocab = vocab; a.B = rows;
@@ -136,8 +136,8 @@ extern "C" q3_status q3_sample(int device, const float* logits_host, const uint8
     a.rep_pen = (float)o->repetition_penalty; a.rep_inv = 1.0f / (float)o->repetition_penalty;
     a.eos_id = pen ? o->eos_token_id : -1; a.min_new_tokens = pen ? o->min_new_tokens : 0; a.codec_eos = CODEC_EOS; a.use_suppress = pen ? 1 : 0;
     HIPC(launch_sample(a, 0));
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(tokens_host, tok, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    HIPC(q3_hipDeviceSynchronize());
+    HIPC(q3_hipMemcpy(tokens_host, tok, (size_t)rows * 4, hipMemcpyDeviceToHost));
     return Q3_OK;
 }
 
@@ -150,12 +150,12 @@ extern "C" q3_status q3_fused_residual_rmsnorm(int device, int dtype, const void
     DevPool pool;
     char *x, *r, *w, *nm, *sm;
     HIPC(pool.alloc(&x, n * es)); HIPC(pool.alloc(&r, n * es)); HIPC(pool.alloc(&w, (size_t)cols * es)); HIPC(pool.alloc(&nm, n * es)); HIPC(pool.alloc(&sm, n * es));
-    HIPC(hipMemcpy(x, x_host, n * es, hipMemcpyHostToDevice)); HIPC(hipMemcpy(r, res_host, n * es, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(w, w_host, (size_t)cols * es, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(x, x_host, n * es, hipMemcpyHostToDevice)); HIPC(q3_hipMemcpy(r, res_host, n * es, hipMemcpyHostToDevice));
+    HIPC(q3_hipMemcpy(w, w_host, (size_t)cols * es, hipMemcpyHostToDevice));
     if (dtype == Q3_DTYPE_F32) HIPC(launch_fused_residual_rmsnorm_f32((float*)x, (float*)r, (float*)w, (float*)nm, (float*)sm, rows, cols, eps, 0));
     else HIPC(launch_fused_residual_rmsnorm_bf16((uint16_t*)x, (uint16_t*)r, (uint16_t*)w, (uint16_t*)nm, (uint16_t*)sm, rows, cols, eps, 0));
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(normed_host, nm, n * es, hipMemcpyDeviceToHost)); HIPC(hipMemcpy(sum_host, sm, n * es, hipMemcpyDeviceToHost));
+    HIPC(q3_hipDeviceSynchronize());
+    HIPC(q3_hipMemcpy(normed_host, nm, n * es, hipMemcpyDeviceToHost)); HIPC(q3_hipMemcpy(sum_host, sm, n * es, hipMemcpyDeviceToHost));
     return Q3_OK;
 }
 
@@ -170,8 +170,8 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
     std::vector<uint16_t> wt(wt_elems);
     retile_bf16(w_host, N, K, wt.data(), mode);
     HIPC(pool.alloc(&x, (size_t)M * K)); HIPC(pool.alloc(&y, (size_t)M * N)); HIPC(pool.alloc(&w, wt_elems));
-    HIPC(hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(w, wt.data(), wt_elems * 2, hipMemcpyHostToDevice));
-    if (bias_host) { HIPC(pool.alloc(&b, (size_t)N)); HIPC(hipMemcpy(b, bias_host, (size_t)N * 4, hipMemcpyHostToDevice)); }
+    HIPC(q3_hipMemcpy(x, x_host, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIPC(q3_hipMemcpy(w, wt.data(), wt_elems * 2, hipMemcpyHostToDevice));
+    if (bias_host) { HIPC(pool.alloc(&b, (size_t)N)); HIPC(q3_hipMemcpy(b, bias_host, (size_t)N * 4, hipMemcpyHostToDevice)); }
     const int step = mode == 1 ? Q3_MAX_BATCH : 16;          // up to 64 rows per launch on the 16-row tiles (wide-session kernels beyond 16)
     float* ws = nullptr; size_t ws_bytes = 0;
     if (M > 16 && N % 128 == 0 && K % 128 == 0) { ws_bytes = gemm_wide_ws_bytes(M < step ? M : step, N, K, EPI_NONE); HIPC(pool.alloc(&ws, ws_bytes / 4)); }
@@ -181,8 +181,8 @@ extern "C" q3_status q3_linear(int device, const float* x_host, const uint16_t* 
         a.tiled = mode; a.Kpad = kpad_for(mode, K); a.ws = ws; a.ws_bytes = ws_bytes;
         HIPC(launch_linear(a, 0));
     }
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(y_host, y, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    HIPC(q3_hipDeviceSynchronize());
+    HIPC(q3_hipMemcpy(y_host, y, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return Q3_OK;
 }
 
@@ -204,7 +204,7 @@ extern "C" q3_status q3_debug_trace_read(q3_session* s, unsigned long long* stam
     *n_nodes = n;
     if (stamps_host && meta_host) {
         if (cap_nodes < n) return set_err(Q3_INVALID_ARG, "trace buffer too small");
-        HIPC(hipMemcpy(stamps_host, s->trace_buf, (size_t)n * TRACE_NODE * 8, hipMemcpyDeviceToHost));
+        HIPC(q3_hipMemcpy(stamps_host, s->trace_buf, (size_t)n * TRACE_NODE * 8, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) {
             const auto& t = s->trace_meta[i];
             const int v[7] = {t.kind, t.a, t.b, t.c, t.d, t.e, t.f};
@@ -294,11 +294,11 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
     {   // random-ish bf16 weights / f32 activations (never zeros: DVFS, guide §5.4 rule 25)
         std::vector<uint16_t> hw(welems);
         q3_synth_fill(1, "bench.w", Q3_DTYPE_BF16, 0.02f, 0.0f, (int64_t)welems, hw.data());
-        for (int c = 0; c < nmat * n_copies; ++c) HIPC(hipMemcpy(w + (size_t)c * welems, hw.data(), welems * 2, hipMemcpyHostToDevice));
+        for (int c = 0; c < nmat * n_copies; ++c) HIPC(q3_hipMemcpy(w + (size_t)c * welems, hw.data(), welems * 2, hipMemcpyHostToDevice));
         std::vector<float> hx((size_t)Q3_MAX_BATCH * K), hn((size_t)K, 1.0f);
         q3_synth_fill(2, "bench.x", Q3_DTYPE_F32, 1.0f, 0.0f, (int64_t)hx.size(), hx.data());
-        HIPC(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(nw, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
+        HIPC(q3_hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        HIPC(q3_hipMemcpy(nw, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
     }
     hipStream_t st; HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     float* ws = nullptr; size_t ws_bytes = 0;
@@ -317,7 +317,7 @@ extern "C" q3_status q3_bench_linear(int device, int M, int N, int K, int epi, i
     for (int i = 0; i < 4; ++i) HIPC(one(i));
     HIPC(hipStreamSynchronize(st));
     hipGraph_t g; hipGraphExec_t ge;
-    HIPC(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    HIPC(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     hipError_t e = hipSuccess;
     for (int i = 0; i < iters && e == hipSuccess; ++i) e = one(i);
     hipError_t e2 = hipStreamEndCapture(st, &g);

@@ -132,10 +132,10 @@ def test_two_sessions_on_two_threads_share_the_queue(tiny_gm):
             got[k] = np.stack([s.codes(b) for b in range(3)]); assert s.submit_info()[0] == 4
             s.close()
         except Exception as e:      # pragma: no cover
-            err.append(e)
+            err.append(f"thread {k}: {e}")
     ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
     for t in ts: t.start()
     for t in ts: t.join()
-    assert not err, err
+    assert not err, "\n".join(err)
     for k in range(2):
         np.testing.assert_array_equal(got[k], want[k])
