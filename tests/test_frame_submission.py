@@ -139,3 +139,39 @@ def test_two_sessions_on_two_threads_share_the_queue(tiny_gm):
     assert not err, "\n".join(err)
     for k in range(2):
         np.testing.assert_array_equal(got[k], want[k])
+
+
+def test_concurrent_synthesize_calls(tiny_gm):
+    """What a server built on the reference API does (one synthesize call per request, lib.rs:718-784, from several threads): four host
+    threads each open, prefill, generate (every session captures its own frame), vocode and close sessions in a loop on ONE model.
+    Captures, the shared packet queue, the device-block cache, the KV page pool and the vocoder's per-thread state all meet here;
+    every call must return the codes and the samples of its serial run."""
+    import threading
+    reqs = [[q.Utterance(synthetic_prompt(8 + (3 * t + j) % 7, 100 * t + j), seed=1000 * t + j) for j in range(5)] for t in range(4)]
+    opts = q.SynthesisOptions(max_length=14, seed=42, eos_token_id=None)
+
+    def one(u):
+        s = tiny_gm.session([u], opts)
+        s.run_timing_only(use_graph=True)
+        out = (s.codes(0).copy(), s.decode(0).copy())
+        s.close()
+        return out
+    want = [[one(u) for u in row] for row in reqs]
+    got = [[None] * 5 for _ in range(4)]; err = []
+
+    def run(t):
+        try:
+            for j, u in enumerate(reqs[t]):
+                got[t][j] = one(u)
+        except Exception as e:      # pragma: no cover
+            err.append(f"thread {t}: {e}")
+    ts = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in ts: th.start()
+    for th in ts: th.join()
+    assert not err, "\n".join(err)
+    for t in range(4):
+        for j in range(5):
+            np.testing.assert_array_equal(got[t][j][0], want[t][j][0])
+            np.testing.assert_array_equal(got[t][j][1], want[t][j][1])
+    info = tiny_gm.kv_pool_info()
+    assert info["pages_in_use"] == 0, info
