@@ -275,13 +275,14 @@ def main():
                             steady = (sum(bt.poll(t)[1] for t in tickets), time.perf_counter() - ta)
                         if running == 0 and queued == 0:
                             break
+                    frames = sum(int(bt.fetch(t)[0].shape[0]) for t in tickets)      # (a finished row's vocoder runs on the batcher's worker: fetch waits for the last samples)
                     wall = time.perf_counter() - ta
-                    return sum(int(bt.fetch(t)[0].shape[0]) for t in tickets), wall, steady
+                    return frames, wall, steady
                 finally:
                     bt.close()
             batcher_run(mix[:B + 2], 8)              # warm (graph, side-session shapes)
             fr_c, wall_c, steady = batcher_run(mix, 8)
-            fr_p, wall_p, steady_p = batcher_run(mix, 8, want_pcm=True)      # every finished row vocoded before its row is refilled
+            fr_p, wall_p, steady_p = batcher_run(mix, 8, want_pcm=True)      # every finished row vocoded (decode worker)
             wall_l = 0.0; fr_l = 0
             for k in range(0, n_req, B):
                 sl = model.session(mix[k:k + B], opts)
@@ -291,7 +292,7 @@ def main():
                        "continuous_frames_per_s": fr_c / wall_c, "continuous_steady_frames_per_s": steady[0] / steady[1],
                        "continuous_with_vocoder_frames_per_s": fr_p / wall_p, "continuous_with_vocoder_steady_frames_per_s": steady_p[0] / steady_p[1],
                        "lockstep_frames_per_s": fr_l / wall_l, "frames": fr_c,
-                       "what": "generation loop only (q3_batcher with 8-frame steps; session opening and the prefill of swapped-in requests included, no vocoder except in the `with_vocoder` figures, where every finished row is decoded to PCM before it is refilled; `steady` = until the queue ran dry, i.e. without the drain of the last rows); lockstep = sessions of `rows` requests "
+                       "what": "generation loop only (q3_batcher with 8-frame steps; session opening and the prefill of swapped-in requests included, no vocoder except in the `with_vocoder` figures, where every finished row is decoded to PCM (on the batcher's decode worker, beside the frames) and the wall clock stops after the last fetch; `steady` = until the queue ran dry, i.e. without the drain of the last rows); lockstep = sessions of `rows` requests "
                                "each running until its longest row ends"}
         except Exception as e:
             eos_mix = {"error": str(e)}

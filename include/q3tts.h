@@ -257,10 +257,14 @@ enum { Q3_TICKET_QUEUED = 0, Q3_TICKET_RUNNING = 1, Q3_TICKET_DONE = 2, Q3_TICKE
 q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget, int prompt_budget, q3_batcher** out);
 void      q3_batcher_free(q3_batcher* b);
 /* Queue a request (deep copy: the caller's arrays may go away). want_pcm != 0: the finished row is vocoded
- * (q3_session_decode, ICL prompts included); else only its codes are kept. */
+ * (the samples of q3_session_decode, ICL prompts included); else only its codes are kept. Since round 6 the vocoder of a
+ * finished row runs on a worker thread and stream of the batcher while its row is refilled and the frames go on: the ticket
+ * reads RUNNING until its samples have landed (q3_batcher_poll), and q3_batcher_fetch waits for them. */
 q3_status q3_batcher_submit(q3_batcher* b, const q3_request* req, int want_pcm, int64_t* ticket);
 /* One scheduling round. A request that cannot be placed (prompt or text longer than a row holds) fails alone: its ticket
- * carries the status and message. n_finished counts tickets that reached DONE or FAILED in this call. */
+ * carries the status and message. n_finished counts tickets whose generation ended (or that failed) in this call; with
+ * want_pcm the samples of such a ticket may still be with the decode worker (it polls RUNNING until they land). A call
+ * that returns n_running == 0 and n_queued == 0 has waited for the worker: every such ticket polls DONE afterwards. */
 q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph, int* n_running, int* n_queued, int* n_finished);
 /* state (Q3_TICKET_*); n_frames: frames of a finished ticket, frames run so far of a running one; n_samples: PCM samples held */
 q3_status q3_batcher_poll(q3_batcher* b, int64_t ticket, int* state, int* n_frames, size_t* n_samples);

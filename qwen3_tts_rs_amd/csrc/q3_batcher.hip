@@ -1,6 +1,8 @@
 // q3_batcher.hip — continuous batching: q3_session_replace (side prefill + transplant) and the native batcher q3_batcher_*
 // (one of the five units of the engine: q3_engine.h says which holds what)
 #include "q3_engine.h"
+#include <condition_variable>
+#include <deque>
 
 // Continuous batching: swap a finished row of a running session for a new request (include/q3tts.h). The reference keeps all
 // per-utterance state per call (KV caches, sampling context, penalty mask, trailing text: lib.rs:743-756, 1484-1541); here
@@ -122,6 +124,8 @@ struct BatTicket {
     BatReq req; int state = Q3_TICKET_QUEUED; int row = -1; bool want_pcm = false;
     std::vector<uint32_t> codes; std::vector<float> pcm; int n_frames = 0;
     q3_status st = Q3_OK; std::string err;
+    // vocoded by the batcher's decode worker (below): queued / running there until dec_done; the row it ran in is long refilled
+    bool decoding = false; std::atomic<bool> dec_done{false}; q3_status dec_st = Q3_OK; std::string dec_err;
 };
 struct q3_batcher {
     q3_model* m = nullptr; int slots = 0, frame_budget = 0, prompt_budget = 0, chunk_frames = 0;
@@ -140,7 +144,80 @@ struct q3_batcher {
     struct Stage {
         int64_t id = -1; std::thread thr; q3_session* side = nullptr; q3_status st = Q3_OK; std::string err; int limit = 0;
     } stage;
+    std::unique_ptr<struct BatDecoder> dec;           // the decode worker of finished rows (below)
 };
+// Round 6: a finished row's vocoder no longer stalls the session either. bat_collect used to decode the row's samples on the session's
+// own stream before the row could be refilled — every live row stood still for ~20 ms per 640 frames. The codes are on the host
+// by then, so the decode goes to a worker thread with its own stream and workspace (one decode at a time, in order), the row is
+// idled and refilled at once, and the ticket counts as RUNNING until its samples have landed (poll; fetch waits for them). Same
+// kernels on the same codes as q3_session_decode: the same samples. ICL rows (reference frames prepended and cut, lib.rs:1022-1041)
+// and Q3_BAT_SYNC_DECODE=1 keep the synchronous decode.
+struct BatDecoder {
+    std::thread thr; std::mutex mu; std::condition_variable cv, cv_done; std::deque<BatTicket*> q; bool stop = false;
+    hipStream_t stream = nullptr; CodecWS ws;
+};
+static void decoder_main(q3_batcher* b);
+static void decoder_push(q3_batcher* b, BatTicket* t) {
+    BatDecoder& d = *b->dec;
+    std::lock_guard<std::mutex> g(d.mu);
+    if (!d.thr.joinable()) d.thr = std::thread(decoder_main, b);
+    d.q.push_back(t);
+    d.cv.notify_one();
+}
+static void ticket_wait_decode(q3_batcher* b, BatTicket& t) {
+    if (!t.decoding) return;
+    BatDecoder& d = *b->dec;
+    {
+        std::unique_lock<std::mutex> lk(d.mu);
+        d.cv_done.wait(lk, [&] { return t.dec_done.load(); });
+    }
+    t.decoding = false;
+    if (t.dec_st != Q3_OK) { t.state = Q3_TICKET_FAILED; t.st = t.dec_st; t.err = t.dec_err; t.pcm.clear(); }
+    else t.state = Q3_TICKET_DONE;
+}
+static void decoder_stop(q3_batcher* b) {
+    BatDecoder& d = *b->dec;
+    {
+        std::lock_guard<std::mutex> g(d.mu);
+        d.stop = true; d.cv.notify_all();
+    }
+    if (d.thr.joinable()) d.thr.join();
+    if (d.stream) { (void)hipStreamSynchronize(d.stream); (void)hipStreamDestroy(d.stream); d.stream = nullptr; }
+    d.ws.release();
+}
+static q3_status decoder_run(q3_batcher* b, BatTicket& t) {
+    BatDecoder& d = *b->dec;
+    const q3_model* m = b->m;
+    HIPC(hipSetDevice(m->device));
+    if (!d.stream) HIPC(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    const int n = t.n_frames;
+    Q3C(codec_reserve(m, d.ws, n));
+    HIPC(hipMemcpyAsync(d.ws.frames, t.codes.data(), (size_t)n * 16 * 4, hipMemcpyHostToDevice, d.stream));
+    Q3C(codec_decode_dev(m, d.ws, n, d.stream, nullptr));
+    HIPC(hipMemcpyAsync(t.pcm.data(), d.ws.pcm, t.pcm.size() * 4, hipMemcpyDeviceToHost, d.stream));
+    HIPC(hipStreamSynchronize(d.stream));
+    return Q3_OK;
+}
+static void decoder_main(q3_batcher* b) {
+    BatDecoder& d = *b->dec;
+    for (;;) {
+        BatTicket* t = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(d.mu);
+            d.cv.wait(lk, [&] { return d.stop || !d.q.empty(); });
+            if (d.q.empty()) return;                 // stop, and nothing left to decode
+            t = d.q.front(); d.q.pop_front();
+        }
+        const q3_status st = decoder_run(b, *t);
+        t->dec_st = st;
+        if (st != Q3_OK) t->dec_err = q3_last_error();
+        {
+            std::lock_guard<std::mutex> g(d.mu);
+            t->dec_done.store(true);
+        }
+        d.cv_done.notify_all();
+    }
+}
 static void stage_join(q3_batcher* b) { if (b->stage.thr.joinable()) b->stage.thr.join(); }
 static void stage_drop(q3_batcher* b) {
     stage_join(b);
@@ -197,12 +274,14 @@ extern "C" q3_status q3_batcher_create(q3_model* m, int slots, int frame_budget,
     std::unique_ptr<q3_batcher> b(new q3_batcher());
     b->m = m; b->slots = slots; b->frame_budget = frame_budget; b->prompt_budget = prompt_budget;
     b->owner.assign(slots, -1); b->commit.assign(slots, 0);
+    b->dec.reset(new BatDecoder());
     *out = b.release();
     return Q3_OK;
 }
 extern "C" void q3_batcher_free(q3_batcher* b) {
     if (!b) return;
     stage_drop(b);
+    if (b->dec) decoder_stop(b);                       // finishes what is queued (tickets nobody will fetch included), then ends the worker
     if (b->s) q3_session_free(b->s);
     delete b;
 }
@@ -229,13 +308,22 @@ static q3_status bat_collect(q3_batcher* b, int row) {
     Q3C(q3_session_codes(b->s, row, nullptr, 0, &n));
     t.codes.resize((size_t)n * 16); t.n_frames = n;
     if (n > 0) Q3C(q3_session_codes(b->s, row, t.codes.data(), n, &n));
+    bool async = false;
     if (t.want_pcm && n > 0) {
-        size_t ns = 0;
+        static const bool sync_decode = getenv("Q3_BAT_SYNC_DECODE") != nullptr;
         t.pcm.resize((size_t)n * samples_per_frame(b->m->cfg));
-        Q3C(q3_session_decode(b->s, row, 0, n, t.pcm.data(), t.pcm.size(), &ns));
-        t.pcm.resize(ns);
+        if (!sync_decode && b->s->seq[(size_t)row].ref_codes.empty()) {
+            // the worker vocodes it from the host copy of the codes while the row is refilled and the frames go on
+            t.decoding = true; t.dec_done.store(false);
+            try { decoder_push(b, &t); async = true; } catch (...) { t.decoding = false; }
+        }
+        if (!async) {
+            size_t ns = 0;
+            Q3C(q3_session_decode(b->s, row, 0, n, t.pcm.data(), t.pcm.size(), &ns));
+            t.pcm.resize(ns);
+        }
     }
-    t.state = Q3_TICKET_DONE; t.row = -1;
+    t.state = async ? Q3_TICKET_RUNNING : Q3_TICKET_DONE; t.row = -1;
     b->owner[row] = -1; b->commit[row] = 0;
     // the device freezes a row at its frame limit, not at EOS: idle it now so that it stops advancing — and taking pages — while
     // the queue is empty or waits for room; its pages but one go back to the pool
@@ -414,6 +502,10 @@ extern "C" q3_status q3_batcher_step(q3_batcher* b, int n_frames, int use_graph,
     Q3C(fill());                                   // the next step starts with full rows
     int running = 0;
     for (int r = 0; r < b->slots; ++r) running += b->owner[r] >= 0 ? 1 : 0;
+    // Nothing runs and nothing waits: the rows that just ended may still be with the decode worker. Their samples are waited for
+    // HERE, so that a host loop that stops on "running == 0 && queued == 0" finds every ticket DONE, as it always did.
+    if (running == 0 && b->queue.empty())
+        for (auto& kv : b->t) ticket_wait_decode(b, *kv.second);
     if (n_running) *n_running = running;
     if (n_queued) *n_queued = (int)b->queue.size();
     if (n_finished) *n_finished = finished;
@@ -424,15 +516,16 @@ extern "C" q3_status q3_batcher_poll(q3_batcher* b, int64_t ticket, int* state, 
     if (!b) return set_err(Q3_INVALID_ARG, "q3_batcher_poll: null batcher");
     auto it = b->t.find(ticket);
     if (it == b->t.end()) return set_err(Q3_INVALID_ARG, "q3_batcher_poll: unknown ticket %lld", (long long)ticket);
-    const BatTicket& t = *it->second;
-    if (state) *state = t.state;
+    BatTicket& t = *it->second;
+    if (t.decoding && t.dec_done.load()) ticket_wait_decode(b, t);      // its samples have landed: DONE (or FAILED) from here on
+    if (state) *state = t.state;                                         // a ticket still being vocoded reads RUNNING
     int nf = t.n_frames;
     if (t.state == Q3_TICKET_RUNNING && b->s && t.row >= 0) {       // frames run so far (an EOS inside them is only looked at when the row is collected)
         const SeqInfo& q = b->s->seq[t.row];
         nf = b->s->frames_run - q.start_run; if (nf > q.limit) nf = q.limit; if (nf < 0) nf = 0;
     }
     if (n_frames) *n_frames = nf;
-    if (n_samples) *n_samples = t.pcm.size();
+    if (n_samples) *n_samples = t.pcm.size();         // (of a ticket still being vocoded: the samples it WILL hold — the size q3_batcher_fetch wants)
     return Q3_OK;
 }
 
@@ -441,6 +534,7 @@ extern "C" q3_status q3_batcher_fetch(q3_batcher* b, int64_t ticket, uint32_t* c
     auto it = b->t.find(ticket);
     if (it == b->t.end()) return set_err(Q3_INVALID_ARG, "q3_batcher_fetch: unknown ticket %lld", (long long)ticket);
     BatTicket& t = *it->second;
+    ticket_wait_decode(b, t);                         // a row that ended but is still being vocoded: wait for its samples
     if (t.state == Q3_TICKET_FAILED) {
         const q3_status st = t.st; const std::string err = t.err;
         b->t.erase(it);

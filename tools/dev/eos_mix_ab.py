@@ -22,11 +22,11 @@ mix = []
 for i, L in enumerate(lens):
     u = q.Utterance(synthetic_prompt(512, i), q.Speaker.Ryan, q.Language.English, seed=42 + i); u.max_length = L
     mix.append(u)
-def run(reqs, poll):
+def run(reqs, poll, want_pcm=os.environ.get('EOS_MIX_PCM') == '1'):
     bt = q.Batcher(model, slots=B, frame_budget=FR, prompt_budget=0, options=opts)
     try:
         ta = time.perf_counter()
-        tickets = [bt.submit(u, want_pcm=False) for u in reqs]
+        tickets = [bt.submit(u, want_pcm=want_pcm) for u in reqs]
         steady = None
         while True:
             running, queued, _ = bt.step(poll, True)
@@ -34,11 +34,12 @@ def run(reqs, poll):
                 steady = (sum(bt.poll(t)[1] for t in tickets), time.perf_counter() - ta)
             if running == 0 and queued == 0:
                 break
+        frames = sum(int(bt.fetch(t)[0].shape[0]) for t in tickets)
         wall = time.perf_counter() - ta
-        return sum(int(bt.fetch(t)[0].shape[0]) for t in tickets), wall, steady
+        return frames, wall, steady
     finally:
         bt.close()
 run(mix[:B + 2], 8)
 for r in range(reps):
     fr, wall, steady = run(mix, 8)
-    print(f"Q3_BAT_NO_STAGE={os.environ.get('Q3_BAT_NO_STAGE', '-')}: continuous {fr / wall:.1f} frames/s ({fr} frames, {wall * 1e3:.1f} ms), until the queue ran dry {steady[0] / steady[1]:.1f}", flush=True)
+    print(f"Q3_BAT_NO_STAGE={os.environ.get('Q3_BAT_NO_STAGE', '-')} Q3_BAT_SYNC_DECODE={os.environ.get('Q3_BAT_SYNC_DECODE', '-')} pcm={os.environ.get('EOS_MIX_PCM', '0')}: continuous {fr / wall:.1f} frames/s ({fr} frames, {wall * 1e3:.1f} ms), until the queue ran dry {steady[0] / steady[1]:.1f}", flush=True)
