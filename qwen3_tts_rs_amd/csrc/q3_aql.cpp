@@ -53,6 +53,7 @@ struct Hsa {
     Q3_HSA_FN(hsa_signal_store_relaxed) Q3_HSA_FN(hsa_signal_store_screlease) Q3_HSA_FN(hsa_signal_wait_scacquire) Q3_HSA_FN(hsa_signal_load_scacquire)
     Q3_HSA_FN(hsa_queue_load_read_index_scacquire) Q3_HSA_FN(hsa_queue_load_write_index_relaxed) Q3_HSA_FN(hsa_queue_store_write_index_relaxed)
 #undef Q3_HSA_FN
+    hsa_status_t (*hsa_amd_queue_cu_set_mask)(const hsa_queue_t*, uint32_t, const uint32_t*) = nullptr;      // optional (aql_restrict_cus)
     bool ok = false;
 } hsa;
 
@@ -72,6 +73,7 @@ bool load_hsa(std::string* why) {
         Q3_HSA_GET(hsa_signal_store_relaxed) Q3_HSA_GET(hsa_signal_store_screlease) Q3_HSA_GET(hsa_signal_wait_scacquire) Q3_HSA_GET(hsa_signal_load_scacquire)
         Q3_HSA_GET(hsa_queue_load_read_index_scacquire) Q3_HSA_GET(hsa_queue_load_write_index_relaxed) Q3_HSA_GET(hsa_queue_store_write_index_relaxed)
 #undef Q3_HSA_GET
+        hsa.hsa_amd_queue_cu_set_mask = (decltype(hsa.hsa_amd_queue_cu_set_mask))dlsym(hsa.h, "hsa_amd_queue_cu_set_mask");
         hsa.ok = all && hsa.hsa_init() == HSA_STATUS_SUCCESS;       // reference-counted: HIP initialised ROCr first
     });
     if (!hsa.ok && why) *why = "libhsa-runtime64 is not available";
@@ -236,6 +238,7 @@ struct Runtime {
     std::map<std::string, KernelSym> kernels;            // by the name HIP reports
     hsa_queue_t* queue = nullptr; uint64_t write_idx = 0;
     std::mutex mu;                                       // one submitter at a time
+    int restricted = 0;                                  // aql_restrict_cus holders (the mask is the queue's: every program on it sees it)
 };
 std::mutex g_mu;
 std::map<int, Runtime*> g_rt;
@@ -482,6 +485,28 @@ bool aql_submit(AqlProgram* p, int frames, std::string* why, int* submitted) {
         }
     }
     if (submitted) *submitted = frames;
+    return true;
+}
+
+// The CU mask is a property of the hardware queue (KFD rewrites the queue's descriptor: an ioctl, ~0.1 ms — not for the inner loop).
+// Bit i names CU i / 8 of XCD i % 8 on this part (KFD deals the bits round the XCDs, and inside one round its shader engines), so the
+// first n bits are n / 8 CUs of EVERY XCD and workgroup b still lands on XCD b % 8.
+bool aql_restrict_cus(AqlProgram* p, int first_cus, std::string* why) {
+    std::string dummy; if (!why) why = &dummy;
+    if (!p || !p->rt) { *why = "aql_restrict_cus: no program"; return false; }
+    if (!hsa.hsa_amd_queue_cu_set_mask) { *why = "hsa_amd_queue_cu_set_mask is not exported by this ROCr"; return false; }
+    Runtime* rt = p->rt;
+    std::lock_guard<std::mutex> lk(rt->mu);
+    const bool release = first_cus <= 0;
+    if (release) { if (rt->restricted == 0 || --rt->restricted > 0) return true; }
+    else if (rt->restricted++ > 0) return true;          // the first holder's mask stays until the last one lets go
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w) {
+        const int lo = w * 32, n = release ? 32 : (first_cus - lo < 0 ? 0 : (first_cus - lo > 32 ? 32 : first_cus - lo));
+        mask[w] = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+    }
+    const hsa_status_t st = hsa.hsa_amd_queue_cu_set_mask(rt->queue, 256, mask);
+    if (st != HSA_STATUS_SUCCESS) { if (!release) --rt->restricted; *why = hsa_err("hsa_amd_queue_cu_set_mask", st); return false; }
     return true;
 }
 

@@ -35,5 +35,8 @@ void aql_program_fence_free(const AqlProgram* p, int* acquire_free, int* release
 bool aql_submit(AqlProgram* p, int frames, std::string* why, int* submitted = nullptr);
 // Blocks until every submitted replay has completed (system-scope release: the results are visible to HIP streams and host).
 bool aql_wait(AqlProgram* p, std::string* why);
+// Confines the queue the program submits to (one per device: every program on it) to the first `first_cus` bits of the CU mask —
+// first_cus / 8 CUs of each XCD; first_cus <= 0 gives the whole chip back. Calls nest (a count); the caller has waited for its replays.
+bool aql_restrict_cus(AqlProgram* p, int first_cus, std::string* why);
 
 }  // namespace q3

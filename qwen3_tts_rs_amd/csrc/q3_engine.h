@@ -410,7 +410,7 @@ struct q3_session {
     // overlapped segment decode (q3_session_run): vocoder segments run on their own stream while the frame loop continues
     hipStream_t dec_stream = nullptr; hipEvent_t dec_ev = nullptr;
     std::vector<CodecWS> par_ws; std::vector<hipStream_t> par_streams;     // q3_session_run: utterances vocoded side by side
-    CodecWS seg_ws; float* pcm_all = nullptr; size_t pcm_all_floats = 0;
+    CodecWS seg_ws;                                          // q3_session_run: segments vocoded beside the frame loop
     std::vector<uint32_t> codes_host; bool codes_host_valid = false;
     int stream_pos = 0;    // streaming: frames already decoded
     int stream_mode = 0;   // 0 = context-free chunk decode (reference behaviour), 1 = continuous (left context re-run: seamless)

@@ -682,7 +682,6 @@ q3_session::~q3_session() {
     for (auto st : par_streams) (void)hipStreamDestroy(st);
     cws.release(); seg_ws.release();
     for (auto& w : par_ws) w.release();
-    if (pcm_all) dev_free(pcm_all);
     if (dec_ev) (void)hipEventDestroy(dec_ev);
     if (dec_stream) (void)hipStreamDestroy(dec_stream);
     if (stream && owns_stream) {                   // synchronised above: idle, handed to the next session of this model
@@ -1170,6 +1169,7 @@ static q3_status frame_capture(q3_session* s, bool stream_busy) {
             std::string why;
             s->aql = q3::aql_program_create(s->graph, s->m->device, pol, &why);
             if (s->aql) s->aql_mode = mode == 2 ? 2 : mode == 3 ? 3 : 1;
+            if (s->aql) if (const char* c = getenv("Q3_FRAME_CUS")) { std::string w; if (atoi(c) > 0) q3::aql_restrict_cus(s->aql, atoi(c), &w); }   // measurement aid: the queue keeps this mask
             else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
         }
     }
@@ -1346,24 +1346,14 @@ extern "C" q3_status q3_session_decode(q3_session* s, int b, int f0, int f1, flo
     return decode_range_on(s, b, f0, f1, s->stream, pcm_host, cap, n_samples);
 }
 
-// Enqueue (no host sync) the vocoder for frames [a, e) of sequence b on the decode stream; PCM lands in s->pcm_all.
-static q3_status seg_decode_enqueue(q3_session* s, int b, int a, int e) {
-    const int spf = samples_per_frame(s->m->cfg);
-    const int c0 = a > CODEC_CTX_FRAMES ? a - CODEC_CTX_FRAMES : 0;
-    HIPC(hipMemcpyAsync(s->seg_ws.frames, s->codes + (size_t)b * s->max_frames * 16, (size_t)e * 16 * 4, hipMemcpyDeviceToDevice, s->dec_stream));
-    Q3C(codec_decode_dev(s->m, s->seg_ws, e, s->dec_stream, nullptr, c0));
-    HIPC(hipMemcpyAsync(s->pcm_all + ((size_t)b * s->max_frames + a) * spf, s->seg_ws.pcm + (size_t)(a - c0) * spf,
-                        (size_t)(e - a) * spf * 4, hipMemcpyDeviceToDevice, s->dec_stream));
-    return Q3_OK;
-}
-
 // synthesize_with_timing for the whole batch. With Q3_DECODE_OVERLAP=1 (and no ICL sequence) the vocoder does not
 // wait for the last frame: every Q3_DECODE_SEG (default 128) generated frames a helper thread enqueues the segment's
 // decode (exact: CODEC_CTX_FRAMES of left context re-run, see codec_decode_dev) on a second stream beside the frame
-// loop. OFF by default: measured on MI355X (1.7B, 8 x 640 frames) the frame loop slows from 2785 to 3308 ms while the
-// decode tail only shrinks from 639 to 289 ms (3444 -> 3620 ms per step) — the frame loop's workgroups need a whole
-// CU's registers, so vocoder waves already resident on a CU block them, and neither stream priorities nor a CU mask
-// on the decode stream (32 / 64 / 96 / 128 CUs: 5624 / 3949 / 3757 / 3607 ms) recover it.
+// loop, the samples going straight to the caller's buffers; the last Q3_DECODE_TAIL (32) frames of a row are the only
+// segment nothing overlaps. OFF by default — measured again in round 6 (1.7B, 8 x 640 frames, frames on the own queue):
+// the frame loop slows from 1636 to 1767 ms while the decode tail shrinks from 155 to 54 ms (2843 -> 2797 frames/s); the
+// frame loop's workgroups need a whole CU's registers, so vocoder waves already resident on a CU hold them up, and
+// splitting the chip between the two (Q3_DECODE_CUS below) costs the frames more than the vocoder takes.
 extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_host, const size_t* cap, size_t* n_samples, q3_timing* timing) {
     if (!s) return set_err(Q3_INVALID_ARG, "null session");
     using clk = std::chrono::steady_clock;
@@ -1431,24 +1421,30 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
         return Q3_OK;
     }
     HIPC(hipSetDevice(s->m->device));
+    // Q3_DECODE_CUS=n (measurement aid, default 0 = off) SPLITS the chip while both run: the frames keep the first 256 - n bits of the CU
+    // mask on their own queue, the decode stream gets the last n (n / 8 CUs of every XCD, see aql_restrict_cus), so a frame kernel's
+    // workgroups are never dealt onto a CU the vocoder holds. Measured in round 6 (profiles/r6_split_chip_overlap_ab.txt): the vocoder
+    // beside the frames then costs them only 3 %, but the frames ALONE on 224 / 192 / 128 CUs are 16 / 15 / 23 % slower — their grids are
+    // one workgroup per CU of the whole chip, and the slowest workgroup of every one of 549 dependent launches sets the pace.
+    static const int cus = [] { const char* e = getenv("Q3_DECODE_CUS"); const int v = e ? atoi(e) : 0; return v <= 0 ? 0 : (v < 8 ? 8 : (v > 248 ? 248 : v & ~7)); }();
     if (!s->dec_stream) {
-        static const int cus = [] { const char* e = getenv("Q3_DECODE_CUS"); return e ? atoi(e) : 0; }();   // tuning aid
-        int least = 0, greatest = 0;
-        HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (cus > 0) {
+        if (cus) {
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < cus && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+            for (int i = 256 - cus; i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
             HIPC(hipExtStreamCreateWithCUMask(&s->dec_stream, 8, mask));
         } else {
+            int least = 0, greatest = 0;
+            HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIPC(hipStreamCreateWithPriority(&s->dec_stream, hipStreamNonBlocking, least));
         }
     }
     Q3C(codec_reserve(s->m, s->seg_ws, seg_env + CODEC_CTX_FRAMES, s->max_frames));
-    if (s->pcm_all_floats < (size_t)s->B * s->max_frames * spf) {
-        if (s->pcm_all) dev_free(s->pcm_all);
-        s->pcm_all_floats = (size_t)s->B * s->max_frames * spf;
-        HIPC(dev_malloc((void**)&s->pcm_all, s->pcm_all_floats * 4));
-    }
+    struct Split {                                         // the whole chip goes back to the frames' queue on every way out
+        q3::AqlProgram* p = nullptr;
+        void release() { if (p) { std::string why; q3::aql_restrict_cus(p, 0, &why); p = nullptr; } }
+        ~Split() { release(); }
+    } split;
+    if (cus && s->aql && !s->aql_failed) { std::string why; if (q3::aql_restrict_cus(s->aql, 256 - cus, &why)) split.p = s->aql; }
     std::vector<int> dec_pos((size_t)s->B, 0);
     std::thread worker; q3_status wst = Q3_OK; std::string werr;
     auto join = [&]() -> q3_status {
@@ -1457,7 +1453,17 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
         return Q3_OK;
     };
     struct Job { int b, a, e; };
-    auto dispatch = [&](bool final_pass) -> q3_status {
+    // one segment: codes -> workspace, vocoder over [a - context, e), the samples of [a, e) straight to the caller's buffer
+    auto seg_enqueue = [s, spf, pcm_host, cap](const Job& j, CodecWS& ws, hipStream_t st) -> q3_status {
+        const int c0 = j.a > CODEC_CTX_FRAMES ? j.a - CODEC_CTX_FRAMES : 0;
+        if (pcm_host && pcm_host[j.b] && (!cap || cap[j.b] < (size_t)j.e * spf)) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
+        HIPC(hipMemcpyAsync(ws.frames, s->codes + (size_t)j.b * s->max_frames * 16, (size_t)j.e * 16 * 4, hipMemcpyDeviceToDevice, st));
+        Q3C(codec_decode_dev(s->m, ws, j.e, st, nullptr, c0));
+        if (pcm_host && pcm_host[j.b])
+            HIPC(hipMemcpyAsync(pcm_host[j.b] + (size_t)j.a * spf, ws.pcm + (size_t)(j.a - c0) * spf, (size_t)(j.e - j.a) * spf * 4, hipMemcpyDeviceToHost, st));
+        return Q3_OK;
+    };
+    auto collect = [&](bool final_pass) {
         std::vector<Job> jobs;
         for (int b = 0; b < s->B; ++b) {
             const SeqInfo& q = s->seq[b];
@@ -1468,36 +1474,56 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
                 dec_pos[(size_t)b] = e;
             }
         }
+        return jobs;
+    };
+    auto dispatch = [&]() -> q3_status {
+        std::vector<Job> jobs = collect(false);
         if (jobs.empty()) return Q3_OK;
         Q3C(join());
-        worker = std::thread([s, jobs, &wst, &werr]() {
+        worker = std::thread([s, jobs, seg_enqueue, &wst, &werr]() {
             if (hipSetDevice(s->m->device) != hipSuccess) { wst = Q3_HIP_ERROR; werr = "hipSetDevice failed in the decode thread"; return; }
             for (const Job& j : jobs) {
-                const q3_status st = seg_decode_enqueue(s, j.b, j.a, j.e);
+                const q3_status st = seg_enqueue(j, s->seg_ws, s->dec_stream);
                 if (st != Q3_OK) { wst = st; werr = q3_last_error(); return; }
             }
         });
         return Q3_OK;
     };
+    // the last segment of a row is the only one nothing overlaps: it is kept short (Q3_DECODE_TAIL frames, default 32)
+    static const int tail_env = [] { const char* e = getenv("Q3_DECODE_TAIL"); const int v = e ? atoi(e) : 32; return v < 16 ? 16 : v; }();
     q3_status st = Q3_OK;
     while (st == Q3_OK && session_remaining(s) > 0 && !all_done(s)) {
-        st = q3_session_generate(s, seg_env, use_graph);
+        int n = seg_env;
+        const int left = session_remaining(s);
+        if (left > tail_env && left - n < tail_env) n = left - tail_env;        // ... so the step before it stops tail_env frames short of the end
+        st = q3_session_generate(s, n, use_graph);
         if (st == Q3_OK) st = refresh_codes(s);
-        if (st == Q3_OK && session_remaining(s) > 0 && !all_done(s)) st = dispatch(false);
+        if (st == Q3_OK && session_remaining(s) > 0 && !all_done(s)) st = dispatch();
     }
     const auto t2 = clk::now();
-    if (st == Q3_OK) st = dispatch(true);
+    split.release();
     { const q3_status js = join(); if (st == Q3_OK) st = js; }
     if (st != Q3_OK) { hipStreamSynchronize(s->dec_stream); return st; }
+    // what is left runs on the whole chip beside the confined stream's backlog: utterances side by side as in the plain path
+    {
+        std::vector<Job> jobs = collect(true);
+        const int conc = 2;
+        while ((int)s->par_ws.size() < conc - 1) {
+            s->par_ws.emplace_back();
+            hipStream_t pst = nullptr;
+            HIPC(hipStreamCreateWithFlags(&pst, hipStreamNonBlocking));
+            s->par_streams.push_back(pst);
+        }
+        auto ws_of = [&](int k) -> CodecWS& { return k == 0 ? s->cws : s->par_ws[(size_t)k - 1]; };
+        auto st_of = [&](int k) { return k == 0 ? s->stream : s->par_streams[(size_t)k - 1]; };
+        for (int k = 0; k < conc; ++k) Q3C(codec_reserve(s->m, ws_of(k), seg_env + CODEC_CTX_FRAMES, s->max_frames));
+        for (size_t i = 0; i < jobs.size(); ++i) Q3C(seg_enqueue(jobs[i], ws_of((int)(i % conc)), st_of((int)(i % conc))));
+        for (int k = 0; k < conc; ++k) HIPC(hipStreamSynchronize(st_of(k)));
+    }
     HIPC(hipStreamSynchronize(s->dec_stream));
     int total = 0;
     for (int b = 0; b < s->B; ++b) {
-        const size_t n = (size_t)s->seq[b].n_frames * spf;
-        if (n_samples) n_samples[b] = n;
-        if (pcm_host && pcm_host[b] && n) {
-            if (!cap || cap[b] < n) return set_err(Q3_INVALID_ARG, "pcm buffer too small");
-            HIPC(q3_hipMemcpy(pcm_host[b], s->pcm_all + (size_t)b * s->max_frames * spf, n * 4, hipMemcpyDeviceToHost));
-        }
+        if (n_samples) n_samples[b] = (size_t)s->seq[b].n_frames * spf;
         total += s->seq[b].n_frames;
     }
     const auto t3 = clk::now();
