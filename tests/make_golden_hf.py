@@ -11,6 +11,10 @@ the same published blocks:
   code predictor  ...Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration (round 5): the 15-pass LOOP itself (A3) — which
       A3 / A10    embedding table and which lm_head each pass uses, the two-token first pass, cache positions — driven by the module's
                   own forward() with its own KV cache, greedy (`python tests/make_golden_hf.py cp_loop` -> hf_cp_loop.npz)
+  frame loop      ...Qwen3OmniMoeTalkerForConditionalGeneration (round 6): the talker's OUTER loop (A1 / A10, lib.rs:530-656) — upstream's
+      A1 / A10    own generate() with its own prepare_inputs_for_generation(): talker step -> code 0 -> its code predictor's generate()
+                  -> the next input = sum of the 16 code embeddings + trailing_text_hidden[step] or tts_pad_embed, on its own KV
+                  caches (`python tests/make_golden_hf.py frame_loop` -> hf_frame_loop.npz)
 
 The script loads the repo's seeded synthetic checkpoint (tiny config) into those modules, runs the chain stage by stage
 and writes tests/golden/hf_crosscheck.npz; tests/test_oracle_vs_hf.py then holds the C oracle to it.
@@ -273,6 +277,102 @@ def cp_loop_fixture():
     print("wrote", path, {k: v.shape for k, v in res.items()})
 
 
+def frame_loop_fixture():
+    """A1 + A10 (lib.rs:530-656: the frame loop — sample code 0 from the talker's logits, run the code predictor on
+    [last hidden, embed(code 0)], feed the talker the SUM of the sixteen code embeddings plus the next trailing-text row, or the
+    tts_pad embedding once the text has run out) against upstream's own loop: Qwen3OmniMoeTalkerForConditionalGeneration.generate()
+    -> prepare_inputs_for_generation() (modeling_qwen3_omni_moe.py) on the module's own KV caches, its own
+    code_predictor.generate() inside, greedy. Until round 6 this loop was only ever compared with tests/np_reference.py (same author).
+    What is NOT under test: the prompt assembly (the oracle's prefill embeddings, trailing rows and pad row are the loop's inputs).
+    Differences from /root/reference handled here, explicitly:
+      * the Qwen3-Omni talker is a sparse MoE; Qwen3-TTS's is dense. Every layer's `mlp` is replaced by upstream's own dense SwiGLU
+        module (Qwen3OmniMoeTalkerTextMLP) before the weights are loaded — the loop, the attention, the norms, the caches, the rotary
+        embedding (3-axis interleaved M-RoPE, which with the text-only positions used here IS plain RoPE) stay upstream's;
+      * upstream's code predictor has the talker's width: the fixture uses the 0.6B topology (no small_to_mtp_projection;
+        `tiny_same_width`), where the reference's loop is exactly upstream's (lib.rs sums the UNprojected embeddings in either case);
+      * upstream samples; the loop is run greedy on both sides, once with the plain logits and once with the reference's default
+        penalties carried through the loop (repetition penalty 1.05, min_new_tokens 2 with the EOS id live; with these weights the
+        greedy path never revisits a token, so they ride along without changing a choice — the rules themselves are held to
+        upstream's processors by hf_sampling.npz) — upstream's RepetitionPenalty /
+        SuppressTokens / MinNewTokens logits processors against q3o_apply_penalties (lib.rs:1271-1322);
+      * upstream's standalone talker config lacks `spatial_merge_size` (read by its __init__, only used for vision inputs): set by hand.
+    Two configurations: the tiny one and one with three talker layers, 2-way GQA and the production code-predictor depth."""
+    import dataclasses
+    import oracle as O
+    from common import oracle_model
+    from transformers.models.qwen3_omni_moe.configuration_qwen3_omni_moe import Qwen3OmniMoeTalkerConfig
+    res = {}
+    base = q.tiny_same_width()
+    cases = {"tiny": base,
+             "mid": dataclasses.replace(base, hidden=128, inter=256, n_layers=3, n_heads=4, n_kv_heads=2, cp_hidden=128, cp_inter=192, cp_layers=5, cp_heads=4, cp_kv_heads=2)}
+    runs = {"plain": dict(repetition_penalty=1.0, min_new_tokens=0, eos_token_id=None),
+            "penalties": dict(repetition_penalty=1.05, min_new_tokens=2, eos_token_id=q.api.CODEC_EOS_TOKEN_ID)}
+    N = 24
+    for tag, cfg in cases.items():
+        W = checkpoint(cfg, SEED)
+        hd6 = cfg.head_dim // 6
+        text = dict(vocab_size=cfg.codec_vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.n_layers,
+                    num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_eps,
+                    rope_parameters=dict(rope_type="default", rope_theta=cfg.rope_theta, mrope_section=[cfg.head_dim // 2 - 2 * hd6, hd6, hd6], interleaved=True),
+                    moe_intermediate_size=8, shared_expert_intermediate_size=cfg.inter, num_experts=2, num_experts_per_tok=1, max_position_embeddings=4096)
+        cp = dict(vocab_size=cfg.cp_vocab, hidden_size=cfg.cp_hidden, intermediate_size=cfg.cp_inter, num_hidden_layers=cfg.cp_layers,
+                  num_attention_heads=cfg.cp_heads, num_key_value_heads=cfg.cp_kv_heads, head_dim=cfg.head_dim, hidden_act="silu",
+                  rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, attention_bias=False, attention_dropout=0.0, sliding_window=None,
+                  max_position_embeddings=64, num_code_groups=cfg.n_groups, use_cache=True)
+        tc = Qwen3OmniMoeTalkerConfig(text_config=text, code_predictor_config=cp, num_code_groups=cfg.n_groups, thinker_hidden_size=cfg.hidden)
+        tc.spatial_merge_size = 2
+        tc._attn_implementation = "eager"; tc.text_config._attn_implementation = "eager"; tc.code_predictor_config._attn_implementation = "eager"
+        talker = M.Qwen3OmniMoeTalkerForConditionalGeneration(tc)
+        for layer in talker.model.layers:
+            layer.mlp = M.Qwen3OmniMoeTalkerTextMLP(tc.text_config, intermediate_size=cfg.inter)
+        talker.eval()
+        sd = talker.state_dict(); got = 0
+        for k, v in sd.items():
+            if k.startswith(("text_projection.", "hidden_projection.")):
+                continue                                  # thinker -> talker adapters of Qwen3-Omni: outside the talker's forward, unused here
+            name = "talker." + k
+            assert name in W and W[name].numel() == v.numel(), (name, tuple(v.shape))
+            sd[k] = W[name].reshape(v.shape).clone(); got += 1
+        assert got == len(sd) - 8, (got, len(sd))
+        talker.load_state_dict(sd)
+        om = oracle_model(cfg, seed=SEED, which=1)
+        utt = q.Utterance(synthetic_prompt(9, 3), q.Speaker.Ryan, q.Language.English, seed=1)
+        for rn, ro in runs.items():
+            osess = O.OracleSession(om, utt, q.SynthesisOptions(max_length=N, seed=1, temperature=0.0, **ro))
+            emb = osess.prefill_embeds(); tr, pad = osess.trailing()
+            assert 0 < tr.shape[0] < N - 2                 # both branches of the text / pad choice are walked
+            S, V = emb.shape[0], cfg.codec_vocab
+            sup = [t for t in range(V - 1024, V) if t != q.api.CODEC_EOS_TOKEN_ID]        # generation/tts.rs:21-43
+            kw = dict(repetition_penalty=ro["repetition_penalty"]) if ro["repetition_penalty"] != 1.0 else {}
+            if ro["eos_token_id"] is not None:
+                kw.update(eos_token_id=ro["eos_token_id"], min_new_tokens=ro["min_new_tokens"])
+            talker.rope_deltas = None
+            out = talker.generate(inputs_embeds=torch.from_numpy(emb)[None], attention_mask=torch.ones(1, S, dtype=torch.long),
+                                  talker_input_ids=torch.zeros(1, S, dtype=torch.long), trailing_text_hidden=torch.from_numpy(tr)[None],
+                                  tts_pad_embed=torch.from_numpy(pad)[None, None], max_new_tokens=N, do_sample=False, suppress_tokens=sup,
+                                  output_hidden_states=True, output_logits=True, return_dict_in_generate=True, use_cache=True, pad_token_id=0, **kw)
+            code0 = out.sequences[0].numpy().astype(np.uint32)
+            resid = np.stack([h[1][0].numpy() for h in out.hidden_states[1:]]).astype(np.uint32)     # step i carries frame i - 1's sixteen codes
+            logits = np.stack([l[0].numpy() for l in out.logits]).astype(np.float32)                 # raw talker logits of every step
+            assert (resid[:, 0] == code0[:resid.shape[0]]).all()
+            oc, otl, ocl = osess.generate(capture=True)
+            n = min(len(oc), len(code0))
+            print(f"[frame_loop {tag}/{rn}] upstream {len(code0)} frames, oracle {len(oc)}; code 0 equal {bool((oc[:n, 0] == code0[:n]).all())}, "
+                  f"all 16 codes of the first {resid.shape[0]} frames equal {bool((oc[:resid.shape[0]] == resid[:len(oc)]).all())}, "
+                  f"max |talker logit diff| {np.abs(otl[:n] - logits[:n]).max():.2e}")
+            osess.close()
+            st = np.sort(logits.astype(np.float64), axis=1)
+            res.update({f"{tag}_{rn}_prefill_embeds": emb, f"{tag}_{rn}_trailing": tr, f"{tag}_{rn}_pad": pad, f"{tag}_{rn}_code0": code0,
+                        f"{tag}_{rn}_codes": resid, f"{tag}_{rn}_top2_margin": (st[:, -1] - st[:, -2]).astype(np.float32)})
+            if rn == "plain":
+                res[f"{tag}_{rn}_logits"] = logits
+        om.close()
+        res[f"{tag}_cfg"] = np.array([cfg.hidden, cfg.inter, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.cp_hidden, cfg.cp_inter, cfg.cp_layers, cfg.cp_heads, cfg.cp_kv_heads], np.int32)
+    path = os.path.join(os.path.dirname(OUT), "hf_frame_loop.npz")
+    np.savez_compressed(path, **res)
+    print("wrote", path, {k: v.shape for k, v in res.items()})
+
+
 def test_clip(n, seed):
     """deterministic speech-like test signal in [-0.6, 0.6]"""
     t = np.arange(n) / 24000.0
@@ -370,6 +470,8 @@ if __name__ == "__main__":
         mimi_fixture()
     elif "cp_loop" in sys.argv[1:]:
         cp_loop_fixture()
+    elif "frame_loop" in sys.argv[1:]:
+        frame_loop_fixture()
     elif "sampling" in sys.argv[1:]:
         sampling_fixture()
     else:

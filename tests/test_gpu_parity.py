@@ -1277,3 +1277,24 @@ def test_batcher_bad_first_request_fails_alone(pair):
             np.testing.assert_array_equal(codes, s1.codes(0)); s1.close()
     finally:
         b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_engine_frame_loop_matches_upstream_talker_generate(tag):
+    """The PRODUCT (HIP engine through the C-ABI) against third-party code directly: the codes of 24 greedy frames equal those of
+    Hugging Face's own talker loop (Qwen3OmniMoeTalkerForConditionalGeneration.generate() with its own code predictor and caches,
+    tests/golden/hf_frame_loop.npz; what differs from the reference is listed in make_golden_hf.py::frame_loop_fixture) — not via the
+    same-author oracle. Both runs of the fixture: plain logits, and the default penalties riding along."""
+    from test_oracle_vs_hf import _frame_loop_case, check_codes_against_upstream_loop, SEED as HF_SEED
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_frame_loop.npz"))
+    cfg, utt, runs = _frame_loop_case(fx, tag)
+    gm, om = model_pair(cfg, seed=HF_SEED)
+    for rn, ro in runs.items():
+        n = len(fx[f"{tag}_{rn}_code0"])
+        s = gm.session([utt], q.SynthesisOptions(max_length=n, seed=1, temperature=0.0, **ro))
+        s.prefill(); s.generate(n, use_graph=True)
+        codes = np.asarray(s.codes(0))
+        s.close()
+        check_codes_against_upstream_loop(fx, tag, rn, codes)
+    gm.close(); om.close()

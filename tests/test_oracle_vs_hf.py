@@ -101,6 +101,62 @@ def test_code_predictor_loop_matches_hf_code_predictor_module():
         s.close(); om.close()
 
 
+def _frame_loop_case(fx, tag):
+    import dataclasses
+    c = [int(x) for x in fx[f"{tag}_cfg"]]
+    cfg = dataclasses.replace(q.tiny_same_width(), hidden=c[0], inter=c[1], n_layers=c[2], n_heads=c[3], n_kv_heads=c[4], cp_hidden=c[5], cp_inter=c[6],
+                              cp_layers=c[7], cp_heads=c[8], cp_kv_heads=c[9])
+    utt = q.Utterance(synthetic_prompt(9, 3), q.Speaker.Ryan, q.Language.English, seed=1)
+    runs = {"plain": dict(repetition_penalty=1.0, min_new_tokens=0, eos_token_id=None),
+            "penalties": dict(repetition_penalty=1.05, min_new_tokens=2, eos_token_id=q.api.CODEC_EOS_TOKEN_ID)}
+    return cfg, utt, runs
+
+
+def check_codes_against_upstream_loop(fx, tag, rn, codes):
+    """`codes` [n][16] of one run against upstream's: code 0 of every frame, all sixteen codes of every frame but the last (upstream
+    computes a frame's residual codes while preparing the NEXT step). Only an upstream near-tie of the talker may excuse a divergence."""
+    want0, want = fx[f"{tag}_{rn}_code0"], fx[f"{tag}_{rn}_codes"]
+    marg = fx[f"{tag}_{rn}_top2_margin"]
+    assert len(codes) == len(want0), (tag, rn, len(codes), len(want0))
+    same0 = np.asarray(codes)[:, 0] == want0
+    if not same0.all():
+        fb = int(np.argmin(same0))
+        assert marg[fb] < 1e-4, (tag, rn, "code 0 differs at frame", fb, "upstream margin", float(marg[fb]))
+        raise AssertionError(f"{tag}/{rn}: upstream near-tie at frame {fb} — regenerate the fixture with another prompt seed")
+    np.testing.assert_array_equal(np.asarray(codes)[:len(want)], want)
+
+
+def test_frame_loop_matches_hf_talker_generate():
+    """A1 + A10 (lib.rs:530-656): the oracle's frame loop — q3o_session_generate: code 0 from the talker's logits, the code
+    predictor on [last hidden, embed(code 0)], the next talker input = the sum of the sixteen code embeddings + the next
+    trailing-text row or the tts_pad row, one KV position per frame — against Hugging Face's own loop for this model family:
+    Qwen3OmniMoeTalkerForConditionalGeneration.generate() with its prepare_inputs_for_generation() and the code predictor's
+    generate() inside, on the module's own caches (the loop had only ever met tests/np_reference.py, same
+    author). 24 frames, two configurations, greedy, with and without the default penalties riding along: every code of every
+    compared frame equal, talker logits of every step within 5e-5. The documented differences (dense MLP swapped into upstream's
+    MoE layer, 0.6B topology, greedy) are in make_golden_hf.py::frame_loop_fixture."""
+    fx = np.load(os.path.join(os.path.dirname(FX), "hf_frame_loop.npz"))
+    for tag in ("tiny", "mid"):
+        cfg, utt, runs = _frame_loop_case(fx, tag)
+        om = oracle_model(cfg, seed=SEED, which=1)
+        for rn, ro in runs.items():
+            s = O.OracleSession(om, utt, q.SynthesisOptions(max_length=len(fx[f"{tag}_{rn}_code0"]), seed=1, temperature=0.0, **ro))
+            # the loop's inputs are the ones upstream was given (the prompt assembly is not what this test holds)
+            np.testing.assert_array_equal(s.prefill_embeds(), fx[f"{tag}_{rn}_prefill_embeds"])
+            tr, pad = s.trailing()
+            np.testing.assert_array_equal(tr, fx[f"{tag}_{rn}_trailing"]); np.testing.assert_array_equal(pad, fx[f"{tag}_{rn}_pad"])
+            assert 0 < tr.shape[0] < len(fx[f"{tag}_{rn}_code0"]) - 2          # text rows first, then the pad row: both branches
+            codes, tl, _ = s.generate(capture=True)
+            check_codes_against_upstream_loop(fx, tag, rn, codes)
+            if rn == "plain":
+                ref = fx[f"{tag}_{rn}_logits"]
+                for i in range(len(ref)):
+                    e = float(np.abs(tl[i] - ref[i]).max())
+                    assert e <= 5e-5 * max(1.0, float(np.abs(ref[i]).max())), (tag, i, e)
+            s.close()
+        om.close()
+
+
 def _speech_oracle(scfg):
     from qwen3_tts_rs_amd.speech_encoder import SpeechEncoder, synthetic_speech_checkpoint
     enc = SpeechEncoder(scfg, device=-1)              # manifest-only handle: names / sizes (no GPU)
