@@ -1504,23 +1504,29 @@ extern "C" q3_status q3_session_run(q3_session* s, int use_graph, float** pcm_ho
     split.release();
     { const q3_status js = join(); if (st == Q3_OK) st = js; }
     if (st != Q3_OK) { hipStreamSynchronize(s->dec_stream); return st; }
-    // what is left runs on the whole chip beside the confined stream's backlog: utterances side by side as in the plain path
+    // what is left runs on the whole chip beside the confined stream's backlog: utterances side by side as in the plain path.
+    // Whatever happens, nothing returns while a stream may still be copying samples into the caller's buffers.
     {
-        std::vector<Job> jobs = collect(true);
         const int conc = 2;
-        while ((int)s->par_ws.size() < conc - 1) {
-            s->par_ws.emplace_back();
-            hipStream_t pst = nullptr;
-            HIPC(hipStreamCreateWithFlags(&pst, hipStreamNonBlocking));
-            s->par_streams.push_back(pst);
-        }
         auto ws_of = [&](int k) -> CodecWS& { return k == 0 ? s->cws : s->par_ws[(size_t)k - 1]; };
         auto st_of = [&](int k) { return k == 0 ? s->stream : s->par_streams[(size_t)k - 1]; };
-        for (int k = 0; k < conc; ++k) Q3C(codec_reserve(s->m, ws_of(k), seg_env + CODEC_CTX_FRAMES, s->max_frames));
-        for (size_t i = 0; i < jobs.size(); ++i) Q3C(seg_enqueue(jobs[i], ws_of((int)(i % conc)), st_of((int)(i % conc))));
-        for (int k = 0; k < conc; ++k) HIPC(hipStreamSynchronize(st_of(k)));
+        auto tail = [&]() -> q3_status {
+            std::vector<Job> jobs = collect(true);
+            while ((int)s->par_ws.size() < conc - 1) {
+                hipStream_t pst = nullptr;
+                HIPC(hipStreamCreateWithFlags(&pst, hipStreamNonBlocking));
+                s->par_ws.emplace_back(); s->par_streams.push_back(pst);
+            }
+            for (int k = 0; k < conc; ++k) Q3C(codec_reserve(s->m, ws_of(k), seg_env + CODEC_CTX_FRAMES, s->max_frames));
+            for (size_t i = 0; i < jobs.size(); ++i) Q3C(seg_enqueue(jobs[i], ws_of((int)(i % conc)), st_of((int)(i % conc))));
+            return Q3_OK;
+        };
+        st = tail();
+        hipError_t he = hipStreamSynchronize(s->dec_stream);
+        for (int k = 0; k < conc && k <= (int)s->par_streams.size(); ++k) { const hipError_t e2 = hipStreamSynchronize(st_of(k)); if (he == hipSuccess) he = e2; }
+        if (st != Q3_OK) return st;
+        HIPC(he);
     }
-    HIPC(hipStreamSynchronize(s->dec_stream));
     int total = 0;
     for (int b = 0; b < s->B; ++b) {
         if (n_samples) n_samples[b] = (size_t)s->seq[b].n_frames * spf;
