@@ -1168,9 +1168,10 @@ static q3_status frame_capture(q3_session* s, bool stream_busy) {
             }
             std::string why;
             s->aql = q3::aql_program_create(s->graph, s->m->device, pol, &why);
-            if (s->aql) s->aql_mode = mode == 2 ? 2 : mode == 3 ? 3 : 1;
-            if (s->aql) if (const char* c = getenv("Q3_FRAME_CUS")) { std::string w; if (atoi(c) > 0) q3::aql_restrict_cus(s->aql, atoi(c), &w); }   // measurement aid: the queue keeps this mask
-            else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
+            if (s->aql) {
+                s->aql_mode = mode == 2 ? 2 : mode == 3 ? 3 : 1;
+                if (const char* c = getenv("Q3_FRAME_CUS")) { std::string w; if (atoi(c) > 0) q3::aql_restrict_cus(s->aql, atoi(c), &w); }   // measurement aid: the queue keeps this mask
+            } else if (getenv("Q3_AQL_VERBOSE")) fprintf(stderr, "[q3] AQL submission unavailable, staying on hipGraphLaunch: %s\n", why.c_str());
         }
     }
     if (!s->aql && !s->graph_exec) HIPC(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
